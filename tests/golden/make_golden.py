@@ -1,0 +1,283 @@
+#!/opt/conda/bin/python3.9
+"""Golden-vector generator.  Runs ONLY in the build container (needs /root/reference);
+its outputs (*.npz in this directory) are committed and are what travels to the GPU box.
+
+What it does:
+  * pre-seeds sys.modules with empty stand-ins for the heavy third-party imports of the
+    reference modules (keras / numba / hickle / zstd are absent from this image), puts
+    /root/reference/src on sys.path and imports `compress`, `decompress`, `data_utils`;
+  * calls the reference's own numpy helpers (error_bound, finding_difference x2,
+    replacing_based_on_frequency x2, data_padding, padding_size) on seeded inputs and
+    records inputs + outputs;
+  * runs the reference's compress.run / decompress.run END TO END with the Keras model
+    replaced by tests/golden/fake_predictor.py (the predictor arithmetic lives in
+    keras==2.2.4/tensorflow==1.15, which are not under /root/reference: parity of the
+    predictor itself is unpinned) and `zstd` replaced by the identity, so
+    the recorded `entropy.dat` / `key_frame.dat` are the PRE-zstd byte streams.
+
+Run:  /opt/conda/bin/python3.9 tests/golden/make_golden.py
+(python3.9 + numpy 1.26 because the reference calls ndarray.tostring(), removed in numpy 2.)
+Nothing from the reference's source text is written to the fixtures: only arrays.
+"""
+import io
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import fake_predictor  # noqa: E402
+
+REF = "/root/reference/src"
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+# ---- fake Keras surface used by compress.run / decompress.run -------------------------
+class _FakeLayer:
+    def __init__(self, hp, wp):
+        self.batch_input_shape = (None, 2, hp, wp, 3)
+
+    def get_config(self):
+        return {"output_mode": "error", "data_format": "channels_last"}
+
+    def get_weights(self):
+        return []
+
+
+class _FakeTrainModel:
+    hp = wp = None
+
+    def __init__(self):
+        self.layers = [_FakeLayer(self.hp, self.wp), _FakeLayer(self.hp, self.wp)]
+
+    def load_weights(self, path):
+        return None
+
+
+class _Shape(tuple):
+    pass
+
+
+class _FakeTensor:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class _FakeTestModel:
+    calls = []
+
+    def __init__(self, inputs=None, outputs=None):
+        self.input = _FakeTensor((None, None, _FakeTrainModel.hp, _FakeTrainModel.wp, 3))
+
+    def predict(self, X, batch_size=None):
+        _FakeTestModel.calls.append(tuple(X.shape))
+        return fake_predictor.predict(X)
+
+
+def _install_stubs():
+    K = _stub("keras.backend", image_data_format=lambda: "channels_last")
+    keras = _stub("keras", backend=K)
+    _stub("keras.models", Model=_FakeTestModel, model_from_json=lambda s, custom_objects=None: _FakeTrainModel())
+    _stub("keras.layers", Input=lambda shape=None: _FakeTensor(shape), Dense=None, Flatten=None,
+          Recurrent=object, Conv2D=None, UpSampling2D=None, MaxPooling2D=None)
+    _stub("keras.engine", InputSpec=None)
+    _stub("keras.legacy")
+    _stub("keras.legacy.interfaces", generate_legacy_interface=lambda **k: (lambda f: f),
+          recurrent_args_preprocessor=None)
+    _stub("keras.preprocessing")
+    _stub("keras.preprocessing.image", Iterator=object)
+    keras.activations = _stub("keras.activations")
+    _stub("numba", cuda=None)
+    _stub("hickle")
+    # identity "zstd": the files then hold the pre-zstd streams
+    _stub("zstd", compress=lambda data, level=3: bytes(data), decompress=lambda data: bytes(data))
+    sys.path.insert(0, REF)
+
+
+def _helpers(compress, decompress, data_utils, out):
+    rng = np.random.default_rng(20261004)
+
+    # --- error_bound: the real call site passes int64 (1,H,W) slabs (compress.py:310-319)
+    cases = []
+    specs = [
+        ("abs", [2.0]), ("abs", [0.4]), ("abs", [-3.0]), ("abs", [7.5]), ("abs", [0.0]),
+        ("rel", [0.01]), ("rel", [0.1]), ("rel", [0.0]),
+        ("absrel", [3.0, 0.01]), ("absrel", [1.0, 0.5]), ("absrel", [2.0, 0.0]), ("absrel", [0.0, 0.1]),
+        ("pwrel", [0.05]), ("pwrel", [0.5]), ("pwrel", [1.0]),  # pwrel<0 raises inside the reference (NaN -> int)
+    ]
+    for k, (mode, val) in enumerate(specs):
+        for shape, kind in [((1, 9, 13), "noise"), ((1, 16, 24), "smooth"), ((1, 1, 1), "noise"), ((1, 7, 64), "flat")]:
+            n = int(np.prod(shape))
+            orig = rng.integers(0, 256, size=shape).astype(np.int64)
+            if kind == "noise":
+                diff = rng.integers(-255, 256, size=shape).astype(np.int64)
+            elif kind == "smooth":
+                diff = np.round(np.cumsum(rng.normal(0, 1.2, size=n))).astype(np.int64).reshape(shape)
+                diff = np.clip(diff, -255, 255)
+            else:
+                diff = np.full(shape, int(rng.integers(-3, 4)), dtype=np.int64)
+                diff.reshape(-1)[rng.integers(0, n, size=3)] += rng.integers(-9, 10, size=3)
+                orig = np.full(shape, 128, dtype=np.int64)
+                orig.reshape(-1)[::7] = 3
+            res = compress.error_bound(orig.copy(), diff.copy(), mode, val, False, np)
+            # the caller assigns the result into an int64 array (compress.py:319): truncation
+            res_int = np.empty(shape, dtype=np.int64)
+            res_int[...] = res
+            cases.append((mode, val, orig, diff, res_int))
+    out["eb_n"] = np.array(len(cases))
+    for i, (mode, val, orig, diff, res) in enumerate(cases):
+        out["eb_%d_mode" % i] = np.array(mode)
+        out["eb_%d_val" % i] = np.array(val, dtype=np.float64)
+        out["eb_%d_orig" % i] = orig
+        out["eb_%d_diff" % i] = diff
+        out["eb_%d_res" % i] = res
+    # doc KAT (docs/img/img33.png) with the float inputs of the figure
+    E = np.array([6, 4, 2, 4, 2, 6, 2, 2, 6], dtype=np.float64)
+    D = np.array([0, 0, -5, -5, 10, 5, -5, -5, 0], dtype=np.float64)
+    out["eb_doc_float"] = compress.error_bound(E.copy(), D.copy(), "pwrel", [1.0], False, np)
+
+    # --- finding_difference, encoder and decoder (int16, wrap-around included)
+    for i, n in enumerate([1, 2, 9, 1000]):
+        a = rng.integers(-255, 256, size=(1, n)).astype(np.int16)
+        out["fd_enc_in_%d" % i] = a
+        out["fd_enc_out_%d" % i] = compress.finding_difference(a.copy())
+        out["fd_dec_out_%d" % i] = decompress.finding_difference(out["fd_enc_out_%d" % i].copy())
+    w = rng.integers(-32768, 32768, size=(3, 5, 7)).astype(np.int16)
+    out["fd_wrap_in"] = w
+    with np.errstate(over="ignore"):
+        out["fd_wrap_enc"] = compress.finding_difference(w.copy())
+        out["fd_wrap_dec"] = decompress.finding_difference(w.copy())
+
+    # --- rank remap, both directions
+    sym = (1600 - rng.integers(-40, 41, size=5000)).astype(np.int16)
+    table = np.array([1600, 1599, 1601, 1580, 1625, 1610], dtype=np.int16)
+    out["rp_in"] = sym
+    out["rp_table"] = table
+    out["rp_enc"] = compress.replacing_based_on_frequency(sym.copy(), table, np)
+    ranks = rng.integers(0, len(table), size=5000).astype(np.int16)
+    out["rp_dec_in"] = ranks
+    out["rp_dec"] = decompress.replacing_based_on_frequency(ranks.copy(), table, np)
+
+    # --- padding
+    x = rng.random((1, 3, 21, 30, 3)).astype(np.float32)
+    out["pad_in"] = x
+    out["pad_out"] = data_utils.data_padding(x)
+    out["pad_sizes_in"] = np.array([1, 7, 8, 9, 64, 375, 1242, 512, 1023])
+    out["pad_sizes_out"] = np.array([data_utils.padding_size(int(v)) for v in out["pad_sizes_in"]])
+
+
+def _make_frames(rng, nt, h, w, gray):
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    frames = []
+    for t in range(nt):
+        base = 120 + 60 * np.sin((xx + 2 * t) / 5.0) + 40 * np.cos((yy - t) / 4.0)
+        img = np.stack([base, base * 0.7 + 30, 255 - base * 0.5], axis=-1)
+        img = img + rng.normal(0, 3.0, size=img.shape)
+        img = np.clip(np.round(img), 0, 255).astype(np.uint8)
+        if t == 0:
+            img[0, 0] = (0, 0, 0)
+            img[-1, -1] = (255, 255, 255)
+        frames.append(img[..., 0] if gray else img)
+    return np.stack(frames)
+
+
+def _runs(compress, decompress, out):
+    from PIL import Image
+    rng = np.random.default_rng(777)
+    runs = [
+        # name, nt, H, W, gray, p, w, t, mode, bound, entropy
+        ("swp_p2_w4_lossless", 14, 21, 30, False, 2, 4, None, "abs", [0.0], True),
+        ("swp_p0_w5_abs4", 12, 16, 24, False, 0, 5, None, "abs", [4.0], True),
+        ("dwp_p0_rel", 13, 21, 30, False, 0, None, 0.011, "rel", [0.02], False),
+        ("swp_p1_w3_pwrel_gray", 11, 19, 17, True, 1, 3, None, "pwrel", [0.05], True),
+        ("swp_p0_w6_absrel", 13, 8, 40, False, 0, 6, None, "absrel", [3.0, 0.01], True),
+        ("swp_p0_w4_lastkey", 9, 16, 16, False, 0, 4, None, "abs", [1.0], True),
+        ("dwp_p2_lossless", 12, 10, 12, False, 2, None, 0.0045, "abs", [0.0], True),
+    ]
+    out["run_names"] = np.array([r[0] for r in runs])
+    for name, nt, h, w, gray, p, win, thr, mode, bound, entropy in runs:
+        frames = _make_frames(rng, nt, h, w, gray)
+        hp, wp = ((h + 7) // 8) * 8, ((w + 7) // 8) * 8
+        _FakeTrainModel.hp, _FakeTrainModel.wp = hp, wp
+        _FakeTestModel.calls = []
+        tmp = tempfile.mkdtemp(prefix="tzgold_")
+        try:
+            ddir, cdir, udir, mdir = (os.path.join(tmp, d) for d in ("data", "comp", "out", "model"))
+            os.mkdir(ddir)
+            os.mkdir(mdir)
+            open(os.path.join(mdir, "prednet_model.json"), "w").write("{}")
+            names = []
+            for t in range(nt):
+                fn = "frame_%03d.png" % t
+                Image.fromarray(frames[t], mode="L" if gray else "RGB").save(os.path.join(ddir, fn))
+                names.append(fn)
+            stdout = sys.stdout
+            sys.stdout = io.StringIO()
+            try:
+                compress.run(mdir, ddir, cdir, p, win, thr, mode, bound, False, True, entropy)
+                mse_log = sys.stdout.getvalue()
+                enc_calls = list(_FakeTestModel.calls)
+                _FakeTestModel.calls = []
+                decompress.run(mdir, cdir, udir, False, False)
+            finally:
+                sys.stdout = stdout
+            dec_calls = list(_FakeTestModel.calls)
+            key = np.frombuffer(open(os.path.join(cdir, "key_frame.dat"), "rb").read(), dtype=np.uint8)
+            ent = np.frombuffer(open(os.path.join(cdir, "entropy.dat"), "rb").read(), dtype="<i2")
+            ftxt = open(os.path.join(cdir, "filename.txt"), encoding="UTF-8").read()
+            dec = np.stack([np.array(Image.open(os.path.join(udir, fn))) for fn in names])
+            mses = [float(l.split("MSE:")[1]) for l in mse_log.splitlines() if l.startswith("MSE:")]
+            pre = "run_%s_" % name
+            out[pre + "frames"] = frames
+            out[pre + "params"] = np.array([p, -1 if win is None else win, int(gray), int(entropy)], dtype=np.int64)
+            out[pre + "thr"] = np.array(-1.0 if thr is None else thr)
+            out[pre + "mode"] = np.array(mode)
+            out[pre + "bound"] = np.array(bound, dtype=np.float64)
+            out[pre + "key_frame"] = key
+            out[pre + "entropy"] = ent
+            out[pre + "filename_txt"] = np.array(ftxt)
+            out[pre + "decoded"] = dec
+            out[pre + "mse"] = np.array(mses, dtype=np.float64)
+            out[pre + "enc_calls"] = np.array(enc_calls, dtype=np.int64).reshape(-1, 5)
+            out[pre + "dec_calls"] = np.array(dec_calls, dtype=np.int64).reshape(-1, 5)
+            kf = key.reshape(1, nt, h, w, 3)
+            keys = [i for i in range(nt) if kf[0, i].any()]
+            print("%-24s nt=%d keys=%s entropy_len=%d max|dec-orig|=%d" % (
+                name, nt, keys, ent.size,
+                int(np.abs(dec.astype(int) - (frames if not gray else np.repeat(frames[..., None], 3, -1)).astype(int)).max())))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
+def main():
+    _install_stubs()
+    import compress
+    import decompress
+    import data_utils
+    # the predictor layer is replaced wholesale by the fake model (see module docstring)
+    compress.PredNet = decompress.PredNet = lambda weights=None, **cfg: (lambda inputs: inputs)
+    helpers = {}
+    _helpers(compress, decompress, data_utils, helpers)
+    np.savez_compressed(os.path.join(HERE, "ref_helpers.npz"), **helpers)
+    print("ref_helpers.npz:", len(helpers), "arrays")
+    if not hasattr(np.ndarray, "tostring"):
+        print("numpy >= 2: skipping compress.run/decompress.run goldens (needs ndarray.tostring)")
+        return
+    runs = {}
+    _runs(compress, decompress, runs)
+    np.savez_compressed(os.path.join(HERE, "ref_runs.npz"), **runs)
+    print("ref_runs.npz:", len(runs), "arrays")
+
+
+if __name__ == "__main__":
+    main()
