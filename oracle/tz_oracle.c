@@ -1,0 +1,468 @@
+/* CPU ORACLE in C (test infrastructure, NOT product code; see oracle/oracle.py header).
+ *
+ * Two parts:
+ *  1. The integer/byte pipeline of the reference restated for big inputs (the numpy oracle
+ *     uses Python loops where the reference does): error_bound, delta, spatial delta,
+ *     histogram, remap, inverse scan, reconstruct.  Citations are into /root/reference/src.
+ *  2. The PredNet forward pass (prednet.py:143-308) in the canonical arithmetic "TZ-PA1":
+ *       conv[y,x,co] = b[co]; for source s in concat order, ky, kx, ci:
+ *                         acc = fmaf(in_s[y+ky-1][x+kx-1][ci], W[ky][kx][coff_s+ci][co], acc)
+ *     ('same' zero padding; upsampled sources read in[(y')>>1][(x')>>1]); activations from
+ *     tz_math.h.  The reference's predictor arithmetic lives in keras==2.2.4 /
+ *     tensorflow-gpu==1.15 (docs/index.rst:263-264), which are not under /root/reference and
+ *     not installable here: PARITY UNPINNED for the predictor.  TZ-PA1 is this build's own
+ *     bit-exact definition; it differs from any TF run only by float32 summation order.
+ *
+ * Build: make -C oracle   (gcc -O3 -ffp-contract=off -mfma -mavx2 -fopenmp)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "tz_math.h"
+
+#define TZO_MAXL 8
+
+/* ------------------------------------------------------------------ integer pipeline */
+
+/* compress.py:292-314: d = (int)(pred_f32*255.0f) - orig over the unpadded crop of one frame */
+void tzo_delta_frame(const float* pred_pad, const uint8_t* orig, int H, int W, int Hp, int Wp, int zero,
+                     int16_t* out) {
+    (void)Hp;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            for (int c = 0; c < 3; ++c) {
+                float v = pred_pad[((size_t)y * Wp + x) * 3 + c] * 255.0f;
+                int d = (int)v - (int)orig[((size_t)y * W + x) * 3 + c];
+                out[((size_t)y * W + x) * 3 + c] = zero ? 0 : (int16_t)d;
+            }
+}
+
+/* compress.py:23-70 on one (frame, channel) chain of n elements with element stride `stride`.
+ * mode: 0 abs, 1 rel, 2 absrel, 3 pwrel.  Returns 0, or -1 for pwrel with a negative bound
+ * (the reference raises there). In place on diff. */
+int tzo_error_bound(const uint8_t* orig, int16_t* diff, long n, long stride, int mode, double v0, double v1) {
+    if (v0 == 0.0) return 0;
+    double E = 0.0;
+    if (mode == 0) {
+        E = fabs(v0);
+    } else if (mode == 1 || mode == 2) {
+        if (mode == 2 && v1 == 0.0) return 0;
+        int mx = 0, mn = 255;
+        for (long i = 0; i < n; ++i) {
+            int b = orig[i * stride];
+            if (b > mx) mx = b;
+            if (b < mn) mn = b;
+        }
+        if (mode == 1) {
+            E = (double)(mx - mn) * v0;
+        } else {
+            double a = fabs(v0), r = (double)(mx - mn) * v1;
+            E = a < r ? a : r;
+        }
+    } else if (mode == 3) {
+        if (v0 < 0.0) return -1;
+    }
+    double u = INFINITY, l = -INFINITY;
+    long head = 0;
+    for (long i = 0; i < n; ++i) {
+        double e = mode == 3 ? (double)orig[i * stride] * v0 : E;
+        double df = (double)diff[i * stride];
+        double du = df + e, dl = df - e;
+        double tu = u < du ? u : du, tl = l > dl ? l : dl;
+        if (tu - tl < 0.0) {
+            int16_t q = (int16_t)(long)((u + l) / 2);
+            for (long j = head; j < i; ++j) diff[j * stride] = q;
+            u = INFINITY;
+            l = -INFINITY;
+            head = i;
+        }
+        if (du < u) u = du;
+        if (l < dl) l = dl;
+    }
+    if (n > 0) {
+        int16_t q = (int16_t)(long)((u + l) / 2);
+        for (long j = head; j < n; ++j) diff[j * stride] = q;
+    }
+    return 0;
+}
+
+/* compress.py:73-77 (+ 346-348 when offset!=0): out[0]=in[0], out[i]=in[i-1]-in[i]; y = 1600 - sd */
+void tzo_spatial_delta(const int16_t* in, long n, int apply_offset, int16_t* out) {
+    int16_t prev = 0;
+    for (long i = 0; i < n; ++i) {
+        int16_t cur = in[i];
+        int16_t sd = i == 0 ? cur : (int16_t)(prev - cur);
+        out[i] = apply_offset ? (int16_t)(1600 - sd) : sd;
+        prev = cur;
+    }
+}
+
+/* compress.py:354: bincount over the int16 symbols, bins 0..nbins-1 */
+void tzo_histogram(const int16_t* y, long n, long long* hist, int nbins) {
+    memset(hist, 0, sizeof(long long) * (size_t)nbins);
+    for (long i = 0; i < n; ++i) {
+        int v = y[i];
+        if (v >= 0 && v < nbins) hist[v]++;
+    }
+}
+
+/* compress.py:84-90 / decompress.py:31-36 through a 65536-entry LUT indexed by (v + 32768) */
+void tzo_lut_apply(const int16_t* in, long n, const int16_t* lut, int16_t* out) {
+    for (long i = 0; i < n; ++i) out[i] = lut[(int)in[i] + 32768];
+}
+
+/* decompress.py:22-29 (+236 when offset): x[0]=s[0], x[i]=x[i-1]-s[i] with int16 wrap */
+void tzo_spatial_undelta(const int16_t* in, long n, int apply_offset, int16_t* out) {
+    int16_t prev = 0;
+    for (long i = 0; i < n; ++i) {
+        int16_t s = apply_offset ? (int16_t)(1600 - in[i]) : in[i];
+        int16_t x = i == 0 ? s : (int16_t)(prev - s);
+        out[i] = x;
+        prev = x;
+    }
+}
+
+/* decompress.py:252-256,269 for one frame: pred*255 in DOUBLE minus diff, clip, truncate */
+void tzo_reconstruct_frame(const float* pred_pad, const uint8_t* key_or_null, const int16_t* diff, int H, int W,
+                           int Wp, uint8_t* out) {
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            for (int c = 0; c < 3; ++c) {
+                size_t o = ((size_t)y * W + x) * 3 + c;
+                double base = key_or_null ? ((double)key_or_null[o] / 255) * 255
+                                          : (double)pred_pad[((size_t)y * Wp + x) * 3 + c] * 255;
+                double r = base - (double)diff[o];
+                if (r > 255) r = 255;
+                if (r < 0) r = 0;
+                out[o] = (uint8_t)r;
+            }
+}
+
+/* compress.py:246 for one padded frame: sum of (x - pred)^2 in double, in the build's
+ * canonical blocked order (4096-element blocks, 256 strided partial sums, halving tree);
+ * key_u8 is the UNPADDED frame (pad region compares against 0). */
+double tzo_sse_frame(const uint8_t* key_u8, const float* pred_pad, int H, int W, int Hp, int Wp) {
+    long n = (long)Hp * Wp * 3;
+    double total = 0.0;
+    for (long b0 = 0; b0 < n; b0 += 4096) {
+        double s[256];
+        for (int t = 0; t < 256; ++t) {
+            double acc = 0.0;
+            for (int j = 0; j < 16; ++j) {
+                long i = b0 + (long)j * 256 + t;
+                double sq = 0.0;
+                if (i < n) {
+                    long pix = i / 3;
+                    int c = (int)(i % 3), y = (int)(pix / Wp), x = (int)(pix % Wp);
+                    float xv = 0.0f;
+                    if (y < H && x < W) xv = (float)key_u8[((size_t)y * W + x) * 3 + c] / 255.0f;
+                    double d = (double)xv - (double)pred_pad[i];
+                    sq = d * d;
+                }
+                acc = acc + sq;
+            }
+            s[t] = acc;
+        }
+        for (int st = 128; st >= 1; st >>= 1)
+            for (int t = 0; t < st; ++t) s[t] = s[t] + s[t + st];
+        total = total + s[0];
+    }
+    return total;
+}
+
+/* ---------------------------------------------------------------------------- PredNet */
+typedef struct {
+    int L;
+    int stack[TZO_MAXL];  /* A / Ahat channels per level (stack_sizes, train.py:51) */
+    int rstack[TZO_MAXL]; /* R channels per level (R_stack_sizes) */
+    int Hp, Wp;
+    /* weights, HWIO, borrowed pointers; order of the Keras weight list (prednet.py:212):
+       a[0..L-2], ahat[0..L-1], c[0..L-1], f[0..L-1], i[0..L-1], o[0..L-1], each kernel then bias */
+    const float *a_k[TZO_MAXL], *a_b[TZO_MAXL];
+    const float *ahat_k[TZO_MAXL], *ahat_b[TZO_MAXL];
+    const float *g_k[4][TZO_MAXL], *g_b[4][TZO_MAXL]; /* gate order here: 0=i 1=f 2=c 3=o */
+    /* t=0 state after the top-down pass (input independent), and Ahat at t=0 */
+    float *r0[TZO_MAXL], *c0[TZO_MAXL], *ahat0[TZO_MAXL];
+    int prepared;
+} tzo_model;
+
+static int lvl_h(const tzo_model* m, int l) { return m->Hp >> l; }
+static int lvl_w(const tzo_model* m, int l) { return m->Wp >> l; }
+
+typedef struct {
+    const float* p; /* NULL = all-zero source */
+    int C;
+    int up; /* 1: stored at half resolution, nearest-upsampled x2 on read (prednet.py:264) */
+} tzo_src;
+
+/* Canonical conv: out[y][x][co] = chain(bias; sources in order; ky; kx; ci). W is HWIO with
+ * I = sum of source channels. */
+static void conv3x3(const tzo_src* src, int nsrc, int H, int W, const float* Wt, const float* bias, int Cout,
+                    float* out) {
+    int Cin = 0;
+    for (int s = 0; s < nsrc; ++s) Cin += src[s].C;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; ++y) {
+        float* acc = (float*)malloc(sizeof(float) * (size_t)Cout);
+        for (int x = 0; x < W; ++x) {
+            for (int co = 0; co < Cout; ++co) acc[co] = bias[co];
+            int coff = 0;
+            for (int s = 0; s < nsrc; ++s) {
+                int C = src[s].C;
+                if (src[s].p) { /* an all-zero source leaves every chain unchanged */
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int kx = 0; kx < 3; ++kx) {
+                            int yy = y + ky - 1, xx = x + kx - 1;
+                            int inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                            const float* ip = NULL;
+                            if (inside)
+                                ip = src[s].up ? src[s].p + ((size_t)(yy >> 1) * (W >> 1) + (xx >> 1)) * C
+                                               : src[s].p + ((size_t)yy * W + xx) * C;
+                            const float* wp = Wt + ((size_t)(ky * 3 + kx) * Cin + coff) * Cout;
+                            for (int ci = 0; ci < C; ++ci) {
+                                float xv = inside ? ip[ci] : 0.0f;
+                                const float* wr = wp + (size_t)ci * Cout;
+                                for (int co = 0; co < Cout; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+                            }
+                        }
+                }
+                coff += C;
+            }
+            memcpy(out + ((size_t)y * W + x) * Cout, acc, sizeof(float) * (size_t)Cout);
+        }
+        free(acc);
+    }
+}
+
+tzo_model* tzo_model_create(int L, const int* stack, const int* rstack, int Hp, int Wp, const float* const* w) {
+    if (L < 1 || L > TZO_MAXL || (Hp % (1 << (L - 1))) || (Wp % (1 << (L - 1)))) return NULL;
+    tzo_model* m = (tzo_model*)calloc(1, sizeof(tzo_model));
+    m->L = L;
+    m->Hp = Hp;
+    m->Wp = Wp;
+    for (int l = 0; l < L; ++l) {
+        m->stack[l] = stack[l];
+        m->rstack[l] = rstack[l];
+    }
+    int k = 0;
+    for (int l = 0; l < L - 1; ++l) { m->a_k[l] = w[k++]; m->a_b[l] = w[k++]; }
+    for (int l = 0; l < L; ++l) { m->ahat_k[l] = w[k++]; m->ahat_b[l] = w[k++]; }
+    const int order[4] = {2, 1, 0, 3}; /* list order c, f, i, o -> our gate slots */
+    for (int g = 0; g < 4; ++g)
+        for (int l = 0; l < L; ++l) { m->g_k[order[g]][l] = w[k++]; m->g_b[order[g]][l] = w[k++]; }
+    return m;
+}
+
+void tzo_model_destroy(tzo_model* m) {
+    if (!m) return;
+    for (int l = 0; l < TZO_MAXL; ++l) { free(m->r0[l]); free(m->c0[l]); free(m->ahat0[l]); }
+    free(m);
+}
+
+/* One ConvLSTM update at level l (prednet.py:249-261).  r_prev/c_prev/e_prev may be NULL (zeros). */
+static void lstm_level(const tzo_model* m, int l, const float* r_prev, const float* c_prev, const float* e_prev,
+                       const float* r_up_half, float* r_out, float* c_out) {
+    int H = lvl_h(m, l), W = lvl_w(m, l), R = m->rstack[l];
+    tzo_src src[3];
+    int ns = 0;
+    src[ns++] = (tzo_src){r_prev, R, 0};
+    src[ns++] = (tzo_src){e_prev, 2 * m->stack[l], 0};
+    if (l < m->L - 1) src[ns++] = (tzo_src){r_up_half, m->rstack[l + 1], 1};
+    size_t n = (size_t)H * W * R;
+    float* g[4];
+    for (int k = 0; k < 4; ++k) {
+        g[k] = (float*)malloc(sizeof(float) * n);
+        conv3x3(src, ns, H, W, m->g_k[k][l], m->g_b[k][l], R, g[k]);
+    }
+    for (size_t j = 0; j < n; ++j) {
+        float i_ = tzo_hard_sigmoid(g[0][j]), f_ = tzo_hard_sigmoid(g[1][j]), o_ = tzo_hard_sigmoid(g[3][j]);
+        float g_ = tzo_tanh(g[2][j]);
+        float t1 = f_ * (c_prev ? c_prev[j] : 0.0f);
+        float t2 = i_ * g_;
+        float c = t1 + t2;
+        c_out[j] = c;
+        r_out[j] = o_ * tzo_tanh(c);
+    }
+    for (int k = 0; k < 4; ++k) free(g[k]);
+}
+
+/* ahat_l = relu(conv(r_l)) (+ min(.,1) at l=0)   prednet.py:268-271 */
+static void ahat_level(const tzo_model* m, int l, const float* r, float* out) {
+    int H = lvl_h(m, l), W = lvl_w(m, l);
+    tzo_src s = {r, m->rstack[l], 0};
+    conv3x3(&s, 1, H, W, m->ahat_k[l], m->ahat_b[l], m->stack[l], out);
+    size_t n = (size_t)H * W * m->stack[l];
+    for (size_t j = 0; j < n; ++j) {
+        float v = tzo_relu(out[j]);
+        if (l == 0 && v > 1.0f) v = 1.0f;
+        out[j] = v;
+    }
+}
+
+/* e_l = concat(relu(ahat - a), relu(a - ahat))   prednet.py:274-277 */
+static void err_level(const tzo_model* m, int l, const float* ahat, const float* a, float* e) {
+    int C = m->stack[l];
+    size_t npx = (size_t)lvl_h(m, l) * lvl_w(m, l);
+    for (size_t p = 0; p < npx; ++p)
+        for (int c = 0; c < C; ++c) {
+            float h = ahat[p * C + c], av = a[p * C + c];
+            float d1 = h - av, d2 = av - h;
+            e[p * 2 * C + c] = tzo_relu(d1);
+            e[p * 2 * C + C + c] = tzo_relu(d2);
+        }
+}
+
+/* a_{l+1} = maxpool2x2(relu(conv(e_l)))   prednet.py:289-291 */
+static void a_level(const tzo_model* m, int l, const float* e, float* a_next) {
+    int H = lvl_h(m, l), W = lvl_w(m, l), C = m->stack[l + 1];
+    float* full = (float*)malloc(sizeof(float) * (size_t)H * W * C);
+    tzo_src s = {e, 2 * m->stack[l], 0};
+    conv3x3(&s, 1, H, W, m->a_k[l], m->a_b[l], C, full);
+    int H2 = H / 2, W2 = W / 2;
+    for (int y = 0; y < H2; ++y)
+        for (int x = 0; x < W2; ++x)
+            for (int c = 0; c < C; ++c) {
+                float v = 0.0f; /* relu outputs are >= 0, so 0 is the identity of the max */
+                for (int dy = 0; dy < 2; ++dy)
+                    for (int dx = 0; dx < 2; ++dx) {
+                        float t = tzo_relu(full[((size_t)(2 * y + dy) * W + 2 * x + dx) * C + c]);
+                        if (t > v) v = t;
+                    }
+                a_next[((size_t)y * W2 + x) * C + c] = v;
+            }
+    free(full);
+}
+
+static float* falloc(size_t n) { return (float*)calloc(n ? n : 1, sizeof(float)); }
+
+/* t=0 top-down from zero state + Ahat at t=0 for every level (input independent). */
+void tzo_model_prepare(tzo_model* m) {
+    if (m->prepared) return;
+    for (int l = m->L - 1; l >= 0; --l) {
+        size_t n = (size_t)lvl_h(m, l) * lvl_w(m, l) * m->rstack[l];
+        m->r0[l] = falloc(n);
+        m->c0[l] = falloc(n);
+        lstm_level(m, l, NULL, NULL, NULL, l < m->L - 1 ? m->r0[l + 1] : NULL, m->r0[l], m->c0[l]);
+    }
+    for (int l = 0; l < m->L; ++l) {
+        m->ahat0[l] = falloc((size_t)lvl_h(m, l) * lvl_w(m, l) * m->stack[l]);
+        ahat_level(m, l, m->r0[l], m->ahat0[l]);
+    }
+    m->prepared = 1;
+}
+
+/* X_hat[0,0] (compress.py:197): the t=0 frame prediction = Ahat_0 at t=0 */
+void tzo_model_c0(tzo_model* m, float* out) {
+    tzo_model_prepare(m);
+    memcpy(out, m->ahat0[0], sizeof(float) * (size_t)m->Hp * m->Wp * m->stack[0]);
+}
+
+/* X_hat[0,1] = f(frame) (compress.py:224-229): t0 bottom-up with a_0 = frame, then the t1
+ * top-down pass and Ahat_0.  Live work only; tzo_predict2_literal does the same the long way.
+ * dbg (optional, may be NULL): array of 3*L pointers receiving e_l(t0), r_l(t1), c_l(t1). */
+void tzo_model_next(tzo_model* m, const float* frame, float* pred, float** dbg) {
+    tzo_model_prepare(m);
+    int L = m->L;
+    float *e[TZO_MAXL] = {0}, *r1[TZO_MAXL] = {0}, *c1[TZO_MAXL] = {0};
+    const float* a = frame;
+    float* a_own = NULL;
+    for (int l = 0; l < L; ++l) {
+        size_t npx = (size_t)lvl_h(m, l) * lvl_w(m, l);
+        e[l] = falloc(npx * 2 * m->stack[l]);
+        err_level(m, l, m->ahat0[l], a, e[l]);
+        if (l < L - 1) {
+            float* an = falloc((npx / 4) * m->stack[l + 1]);
+            a_level(m, l, e[l], an);
+            free(a_own);
+            a_own = an;
+            a = an;
+        }
+    }
+    free(a_own);
+    for (int l = L - 1; l >= 0; --l) {
+        size_t n = (size_t)lvl_h(m, l) * lvl_w(m, l) * m->rstack[l];
+        r1[l] = falloc(n);
+        c1[l] = falloc(n);
+        lstm_level(m, l, m->r0[l], m->c0[l], e[l], l < L - 1 ? r1[l + 1] : NULL, r1[l], c1[l]);
+    }
+    ahat_level(m, 0, r1[0], pred);
+    for (int l = 0; l < L; ++l) {
+        if (dbg) {
+            size_t npx = (size_t)lvl_h(m, l) * lvl_w(m, l);
+            if (dbg[l]) memcpy(dbg[l], e[l], sizeof(float) * npx * 2 * m->stack[l]);
+            if (dbg[L + l]) memcpy(dbg[L + l], r1[l], sizeof(float) * npx * m->rstack[l]);
+            if (dbg[2 * L + l]) memcpy(dbg[2 * L + l], c1[l], sizeof(float) * npx * m->rstack[l]);
+        }
+        free(e[l]);
+        free(r1[l]);
+        free(c1[l]);
+    }
+}
+
+/* Literal evaluation of predict on (1,2,Hp,Wp,C): two generic steps from zero state
+ * (prednet.py:235-308 via K.rnn), second input all zeros (compress.py:225-226).
+ * out0 = X_hat[0,0], out1 = X_hat[0,1].  Used to show the live-work shortcut is exact. */
+void tzo_predict2_literal(tzo_model* m, const float* frame, float* out0, float* out1) {
+    int L = m->L;
+    float *r[TZO_MAXL], *c[TZO_MAXL], *e[TZO_MAXL];
+    for (int l = 0; l < L; ++l) {
+        size_t npx = (size_t)lvl_h(m, l) * lvl_w(m, l);
+        r[l] = falloc(npx * m->rstack[l]);
+        c[l] = falloc(npx * m->rstack[l]);
+        e[l] = falloc(npx * 2 * m->stack[l]);
+    }
+    float* zeros = falloc((size_t)m->Hp * m->Wp * m->stack[0]);
+    for (int t = 0; t < 2; ++t) {
+        float *rn[TZO_MAXL], *cn[TZO_MAXL];
+        for (int l = L - 1; l >= 0; --l) {
+            size_t n = (size_t)lvl_h(m, l) * lvl_w(m, l) * m->rstack[l];
+            rn[l] = falloc(n);
+            cn[l] = falloc(n);
+            lstm_level(m, l, r[l], c[l], e[l], l < L - 1 ? rn[l + 1] : NULL, rn[l], cn[l]);
+        }
+        const float* a = t == 0 ? frame : zeros;
+        float* a_own = NULL;
+        for (int l = 0; l < L; ++l) {
+            size_t npx = (size_t)lvl_h(m, l) * lvl_w(m, l);
+            float* ah = falloc(npx * m->stack[l]);
+            ahat_level(m, l, rn[l], ah);
+            if (l == 0) memcpy(t == 0 ? out0 : out1, ah, sizeof(float) * npx * m->stack[0]);
+            err_level(m, l, ah, a, e[l]);
+            free(ah);
+            if (l < L - 1) {
+                float* an = falloc((npx / 4) * m->stack[l + 1]);
+                a_level(m, l, e[l], an);
+                free(a_own);
+                a_own = an;
+                a = an;
+            }
+        }
+        free(a_own);
+        for (int l = 0; l < L; ++l) {
+            free(r[l]);
+            free(c[l]);
+            r[l] = rn[l];
+            c[l] = cn[l];
+        }
+    }
+    for (int l = 0; l < L; ++l) { free(r[l]); free(c[l]); free(e[l]); }
+    free(zeros);
+}
+
+/* scalar function probes so tests can compare activations bit for bit with the device */
+void tzo_act_probe(const float* x, long n, float* hs, float* th) {
+    for (long i = 0; i < n; ++i) {
+        hs[i] = tzo_hard_sigmoid(x[i]);
+        th[i] = tzo_tanh(x[i]);
+    }
+}
+
+/* key-frame byte -> float32 model input: float32(k)/255 (compress.py:138) */
+void tzo_u8_to_f32_frame(const uint8_t* key, int H, int W, int Hp, int Wp, float* out) {
+    memset(out, 0, sizeof(float) * (size_t)Hp * Wp * 3);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            for (int c = 0; c < 3; ++c)
+                out[((size_t)y * Wp + x) * 3 + c] = (float)key[((size_t)y * W + x) * 3 + c] / 255.0f;
+}
