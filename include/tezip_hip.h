@@ -1,0 +1,154 @@
+/* tezip_hip.h -- C ABI of the MI355X-native TEZip hot path (libtezip_hip.so).
+ *
+ * The reference (kento/TEZip, /root/reference) is pure Python and has no FFI: the hot path
+ * sits behind compress.run / decompress.run (src/compress.py:93, src/decompress.py:39) and
+ * the operator seams inside them.  Each entry point below names the reference code it
+ * replaces.  A ctypes binding (tezip_amd/_lib.py) is the "reference-side stub"; see
+ * INTEGRATION.md for how the reference's own compress.py would call these.
+ *
+ * Conventions
+ *  - extern "C", int return: 0 = TZ_OK, negative = tz_status; no exceptions cross the ABI.
+ *  - Every data pointer may be HOST or DEVICE memory (detected with hipPointerGetAttributes);
+ *    host buffers are staged through the context.  Outputs are complete when the call
+ *    returns for host pointers; for device pointers the work is enqueued on the context's
+ *    stream (tz_ctx_synchronize to wait).
+ *  - One context per GPU/process; a context is not thread-safe; contexts are independent.
+ *  - Frames are HWC, 3 channels; "padded" means H,W rounded up to a multiple of 8
+ *    (data_utils.py:77-107) with pitch Wp*3.
+ *  - All integer streams are int16, C-order over (frame, y, x, channel) (compress.py:329-340).
+ */
+#ifndef TEZIP_HIP_H
+#define TEZIP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tz_ctx tz_ctx;
+
+typedef enum {
+    TZ_OK = 0,
+    TZ_ERR_INVALID = -1,     /* bad argument (the reference prints + exit()s or raises) */
+    TZ_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+    TZ_ERR_HIP = -3,         /* a HIP runtime call failed: see tz_last_error */
+    TZ_ERR_STATE = -4,       /* call order (no model / not prepared / no rollout) */
+    TZ_ERR_NOMEM = -5,
+    TZ_ERR_UNSUPPORTED = -6  /* model shape outside what the kernels cover */
+} tz_status;
+
+/* -m abs|rel|absrel|pwrel (tezip.py:96, compress.py:28-45) */
+typedef enum { TZ_MODE_ABS = 0, TZ_MODE_REL = 1, TZ_MODE_ABSREL = 2, TZ_MODE_PWREL = 3 } tz_mode;
+
+#define TZ_OFFSET 1600   /* compress.py:348 */
+#define TZ_NBINS 2111    /* symbols 1600 - sd, sd in [-510, 510] (docs/index.rst:1222-1232) */
+#define TZ_MAX_TABLE 1021
+#define TZ_MAX_LEVELS 8
+
+int tz_version(void);
+const char* tz_strerror(int status);
+const char* tz_last_error(const tz_ctx* ctx);
+
+/* ---- context -------------------------------------------------------------------------
+ * Replaces the device probe + TF session of tezip.py:16-26 / compress.py:281-287.
+ * hip_stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL to let the
+ * context create its own. */
+int tz_ctx_create(int device, void* hip_stream, tz_ctx** out);
+int tz_ctx_destroy(tz_ctx* ctx);
+int tz_ctx_synchronize(tz_ctx* ctx);
+void* tz_ctx_stream(tz_ctx* ctx);
+
+/* ---- predictor (prednet.py:24-325 used through Model.predict, compress.py:155-173,227) ----
+ * weights: the Keras weight list of the PredNet layer (prednet.py:210-227): for key in
+ * sorted(a, ahat, c, f, i, o), for level: kernel (3,3,Cin,Cout) HWIO float32, bias (Cout).
+ * 2*(6*nb_layers-1) arrays.  Only 3x3 filters (train.py:53-55). */
+int tz_model_load(tz_ctx* ctx, int nb_layers, const int* stack_sizes, const int* r_stack_sizes,
+                  const float* const* weights);
+/* Fix the padded frame size and the largest number of windows advanced together; allocates
+ * activations and evaluates everything that does not depend on the input (t=0 states). */
+int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch);
+/* X_hat[0,0] of predict((1,2,Hp,Wp,3)) (compress.py:197): input independent. out: Hp*Wp*3 f32 */
+int tz_predict_c0(tz_ctx* ctx, float* out);
+/* X_hat[0,1] for n independent padded float32 frames (compress.py:224-229). */
+int tz_predict_next(tz_ctx* ctx, const float* frames, int n, float* out);
+/* Debug/parity taps of the last tz_predict_next call with n == 1: kind 0 = e_l(t0),
+ * 1 = r_l(t1); out sized (Hp>>l)*(Wp>>l)*channels. */
+int tz_predict_tap(tz_ctx* ctx, int kind, int level, float* out);
+
+/* ---- rollout (compress.py:183-268 encoder; decompress.py:115-186 decoder) -----------------
+ * frames: nt*H*W*3 uint8.  window > 0: SWP (-w); window == 0: DWP with `threshold` (-t).
+ * key_mask[nt] (host) receives 1 for key frames.  mse_log (host, nt doubles, may be NULL)
+ * receives the per-step window MSE of compress.py:246 (entries 0..warm_up are 0); it is
+ * always computed for DWP and only on request for SWP.
+ * The prediction stack (nt padded float32 frames; key slots hold C0) and the frames stay in
+ * the context for tz_encode.  Rejects nt < warm_up+2 (the reference misbehaves there). */
+int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int W, int warm_up, int window,
+               double threshold, uint8_t* key_mask, double* mse_log);
+/* Decoder replay: key_frames = the key_frame.dat stack (zeros except key frames); key
+ * positions are recovered as decompress.py:123-129 does (any non-zero sample). */
+int tz_rollout_decode(tz_ctx* ctx, const uint8_t* key_frames, int nt, int H, int W, int warm_up,
+                      uint8_t* key_mask);
+/* Copy out the prediction stack of the last rollout: nt*Hp*Wp*3 float32. */
+int tz_get_predictions(tz_ctx* ctx, float* out);
+
+/* ---- encoder back half on the context-resident rollout (compress.py:289-373) ---------------
+ * payload: nt*H*W*3 int16 = rank(1600 - sd) when entropy != 0, else sd.
+ * table: >= TZ_MAX_TABLE int16 (host), *table_len receives T (or -1 when entropy == 0).
+ * delta_out (may be NULL): the int16 delta stack after quantisation, before the spatial delta. */
+int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t* payload,
+              int16_t* table, int* table_len, int16_t* delta_out);
+/* ---- decoder back half (decompress.py:203-256): payload (+table) -> nt*H*W*3 uint8 frames,
+ * using the prediction stack of the last tz_rollout_decode. */
+int tz_decode(tz_ctx* ctx, const int16_t* payload, const int16_t* table, int table_len,
+              uint8_t* frames_out);
+
+/* ---- operator seams, usable stand-alone (each mirrors one reference helper) -----------------
+ * tz_delta_encode: compress.py:292-314.  pred: nframes padded f32 frames; orig: nframes
+ * unpadded u8 frames; zero_mask[nframes] (host): 1 => that frame's delta is forced to 0. */
+int tz_delta_encode(tz_ctx* ctx, const float* pred, const uint8_t* orig, const uint8_t* zero_mask,
+                    int nframes, int H, int W, int16_t* out);
+/* tz_error_bound: compress.py:23-70 applied per frame and channel as compress.py:316-319 does.
+ * diff is updated in place; skip_mask[nframes] (host): 1 => frame left untouched. */
+int tz_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8_t* skip_mask,
+                   int nframes, int H, int W, int mode, double b0, double b1);
+/* tz_spatial_delta: compress.py:73-77 (+ the 1600 offset of :348 when apply_offset).
+ * has_carry: treat `carry` as the element preceding in[0] (shard boundary). hist (may be
+ * NULL): TZ_NBINS uint64 counts of the output symbols are ADDED (compress.py:354). */
+int tz_spatial_delta(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, int16_t carry,
+                     int apply_offset, int16_t* out, unsigned long long* hist);
+/* tz_build_table: compress.py:352-361 (host): count desc, ties ascending symbol. */
+int tz_build_table(const unsigned long long* hist, int nbins, int16_t* table, int* table_len);
+/* tz_remap: compress.py:84-90 (symbol -> rank). */
+int tz_remap(tz_ctx* ctx, const int16_t* in, size_t n, const int16_t* table, int table_len, int16_t* out);
+/* tz_unmap: decompress.py:31-36 (+ 1600 - x of :236 when apply_offset). */
+int tz_unmap(tz_ctx* ctx, const int16_t* in, size_t n, const int16_t* table, int table_len,
+             int apply_offset, int16_t* out);
+/* tz_spatial_undelta: decompress.py:22-29 as a wrap-around prefix scan. has_carry: `carry`
+ * is the decoded element preceding in[0]. */
+int tz_spatial_undelta(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, int16_t carry,
+                       int16_t* out);
+/* tz_reconstruct: decompress.py:252-256,269.  key_mask[nframes] (host): 1 => the base is
+ * the key byte (key_frames), else trunc(pred*255). */
+int tz_reconstruct(tz_ctx* ctx, const float* pred, const uint8_t* key_frames, const uint8_t* key_mask,
+                   const int16_t* diff, int nframes, int H, int W, uint8_t* out);
+/* tz_window_sse: the inner sum of compress.py:246 for nframes (sum over the padded frame of
+ * (x/255 - pred)^2 in float64, fixed summation order). sse: nframes doubles (host). */
+int tz_window_sse(tz_ctx* ctx, const uint8_t* orig, const float* pred, int nframes, int H, int W, double* sse);
+
+/* ---- timing helper: HIP events on the context's stream (bench.py) -------------------------- */
+int tz_timer_start(tz_ctx* ctx);
+int tz_timer_stop(tz_ctx* ctx, float* ms);
+/* Per-kernel-class accumulated device time since the last reset, measured with HIP events
+ * around every launch of that class when profiling is enabled (adds a sync per query only).
+ * names: tz_prof_name(i), i < tz_prof_count(). */
+int tz_prof_enable(tz_ctx* ctx, int on);
+int tz_prof_count(void);
+const char* tz_prof_name(int i);
+int tz_prof_get(tz_ctx* ctx, int i, double* total_ms, long long* launches);
+int tz_prof_reset(tz_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,261 @@
+"""GPU parity tests (run with -m gpu on a MI355X): every HIP entry point against the CPU
+oracle on the same seeded inputs.  Integer/byte work and -- thanks to the TZ-PA1 fixed
+fmaf-chain arithmetic -- the float32 predictor are compared BIT-EXACT."""
+import numpy as np
+import pytest
+
+from oracle import coracle
+from oracle import oracle as O
+from tezip_amd.prednet import PredNetConfig
+
+pytestmark = pytest.mark.gpu
+
+SMALL = PredNetConfig(stack_sizes=(3, 16, 32))
+FULL = PredNetConfig()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tezip_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _frames(rng, nt, h, w):
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    out = []
+    for t in range(nt):
+        base = 120 + 60 * np.sin((xx + 2 * t) / 5.0) + 40 * np.cos((yy - t) / 4.0)
+        img = np.stack([base, base * 0.7 + 30, 255 - base * 0.5], axis=-1) + rng.normal(0, 3.0, (h, w, 3))
+        out.append(np.clip(np.round(img), 0, 255).astype(np.uint8))
+    return np.stack(out)
+
+
+def _pad(h):
+    return (h + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------------ codec ops
+@pytest.mark.parametrize("h,w", [(64, 64), (21, 30), (128, 160)])
+def test_delta_encode(ctx, h, w):
+    rng = np.random.default_rng(1)
+    n = 5
+    pred = rng.random((n, _pad(h), _pad(w), 3), dtype=np.float32)
+    pred[0, 0, 0] = [0.0, 1.0, 0.5]
+    orig = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    zero = np.array([1, 0, 0, 1, 0], np.uint8)
+    got = ctx.delta_encode(pred, orig, zero)
+    ref = np.stack([coracle.delta_frame(pred[i], orig[i], bool(zero[i])) for i in range(n)])
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("mode,bound", [("abs", [2.0]), ("abs", [0.4]), ("abs", [-3.0]), ("abs", [0.0]),
+                                        ("rel", [0.01]), ("rel", [0.1]), ("absrel", [3.0, 0.01]),
+                                        ("absrel", [1.0, 0.5]), ("absrel", [2.0, 0.0]), ("pwrel", [0.05]),
+                                        ("pwrel", [1.0])])
+def test_error_bound(ctx, mode, bound):
+    rng = np.random.default_rng(2)
+    n, h, w = 4, 37, 53  # chains longer than one staged chunk (1024 px) and one fill block (2048 px)
+    orig = _frames(rng, n, h, w)
+    noise = rng.integers(-255, 256, (n, h, w, 3))
+    smooth = np.clip(np.round(np.cumsum(rng.normal(0, 0.7, (n, h * w, 3)), axis=1)), -255, 255).reshape(n, h, w, 3)
+    diff = np.where(np.arange(n)[:, None, None, None] % 2 == 0, noise, smooth).astype(np.int16)
+    diff[3] = 0
+    diff[3, 10, 5:9] = [3, -7, 9, 1]
+    skip = np.array([0, 0, 1, 0], np.uint8)
+    got = ctx.error_bound(orig, diff.copy(), mode, bound, skip)
+    for i in range(n):
+        ref = diff[i] if skip[i] else coracle.error_bound_frame(orig[i], diff[i], mode, bound)
+        np.testing.assert_array_equal(got[i], ref, err_msg="frame %d" % i)
+
+
+def test_error_bound_rejects_negative_pwrel(ctx):
+    from tezip_amd._lib import TezipError
+    o = np.zeros((1, 8, 8, 3), np.uint8)
+    d = np.zeros((1, 8, 8, 3), np.int16)
+    with pytest.raises(TezipError):
+        ctx.error_bound(o, d, "pwrel", [-0.1])
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 4099, 3 * 64 * 64 * 5 + 3])
+@pytest.mark.parametrize("offset", [0, 1])
+def test_spatial_delta_histogram_and_inverse(ctx, n, offset):
+    rng = np.random.default_rng(3)
+    x = np.clip(np.round(rng.normal(0, 6, n)), -255, 255).astype(np.int16)
+    hist = np.zeros(2111, np.uint64)
+    hist[5] = 7  # counts are ADDED
+    y = ctx.spatial_delta(x, offset, hist=hist if offset else None)
+    np.testing.assert_array_equal(y, coracle.spatial_delta(x, offset))
+    if offset:
+        ref_h = coracle.histogram(y).astype(np.uint64)
+        ref_h[5] += 7
+        np.testing.assert_array_equal(hist, ref_h)
+        table = ctx.build_table(coracle.histogram(y))
+        np.testing.assert_array_equal(table, O.build_table(y))
+        ranks = ctx.remap(y, table)
+        np.testing.assert_array_equal(ranks, O.remap_enc(y, table))
+        np.testing.assert_array_equal(ctx.unmap(ranks, table, offset=True), (1600 - y.astype(np.int32)).astype(np.int16))
+        back = ctx.spatial_undelta(ctx.unmap(ranks, table, offset=True))
+    else:
+        back = ctx.spatial_undelta(y)
+    np.testing.assert_array_equal(back, x)
+    # shard carry: second half given the last element of the first half
+    if n > 16:
+        k = (n // 2) & ~7
+        y2 = ctx.spatial_delta(x[k:].copy(), offset, carry=int(x[k - 1]))
+        np.testing.assert_array_equal(y2, y[k:])
+        sd2 = y[k:] if not offset else (1600 - y[k:].astype(np.int32)).astype(np.int16)
+        np.testing.assert_array_equal(ctx.spatial_undelta(sd2.copy(), carry=int(x[k - 1])), x[k:])
+
+
+def test_undelta_wraparound_matches_reference_loop(ctx):
+    rng = np.random.default_rng(4)
+    s = rng.integers(-32768, 32768, 10007).astype(np.int16)
+    np.testing.assert_array_equal(ctx.spatial_undelta(s), coracle.spatial_undelta(s, 0))
+    np.testing.assert_array_equal(ctx.spatial_undelta(s), O.finding_difference_dec(s))
+
+
+def test_unmap_chained_table(ctx):
+    rng = np.random.default_rng(5)
+    table = np.array([3, 0, 5, 4, 9, 1], dtype=np.int16)
+    ranks = rng.integers(-2, 12, size=999).astype(np.int16)
+    np.testing.assert_array_equal(ctx.unmap(ranks, table, offset=False), O.remap_dec(ranks, table))
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (21, 30)])
+def test_reconstruct_and_sse(ctx, h, w):
+    rng = np.random.default_rng(6)
+    n = 4
+    pred = rng.random((n, _pad(h), _pad(w), 3), dtype=np.float32)
+    key = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    diff = rng.integers(-300, 300, (n, h, w, 3)).astype(np.int16)
+    km = np.array([1, 0, 0, 1], np.uint8)
+    got = ctx.reconstruct(pred, key, km, diff)
+    for i in range(n):
+        ref = coracle.reconstruct_frame(pred[i], key[i] if km[i] else None, diff[i])
+        np.testing.assert_array_equal(got[i], ref)
+    sse = ctx.window_sse(key, pred)
+    for i in range(n):
+        assert sse[i] == coracle.sse_frame(key[i], pred[i])  # same summation order => bit-exact
+        x = np.zeros((_pad(h), _pad(w), 3))
+        x[:h, :w] = key[i].astype(np.float32) / np.float32(255)
+        np.testing.assert_allclose(sse[i], ((x - pred[i].astype(np.float64)) ** 2).sum(), rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------ predictor
+@pytest.mark.parametrize("cfg,hp,wp,bias", [(SMALL, 16, 24, 0.3), (SMALL, 40, 48, 0.2), (FULL, 64, 64, 0.1),
+                                            (FULL, 72, 88, 0.0)])
+def test_prednet_bit_exact_vs_canonical_oracle(ctx, cfg, hp, wp, bias):
+    rng = np.random.default_rng(7)
+    w = cfg.init_weights(seed=11, bias_scale=bias)
+    net = coracle.CPredNet(w, cfg.stack_sizes, cfg.R_stack_sizes, hp, wp)
+    ctx.load_model(cfg, w)
+    ctx.prepare(hp, wp, max_batch=2)
+    np.testing.assert_array_equal(ctx.predict_c0(), net.c0())
+    frames = rng.integers(0, 256, (3, hp, wp, 3)).astype(np.float32) / np.float32(255)
+    got = ctx.predict_next(frames)  # 3 frames through a max_batch of 2: batch invariance
+    for i in range(3):
+        ref, dbg = net.next(frames[i], debug=True)
+        if i == 2:  # taps hold the last batch (n == 1)
+            for l in range(cfg.nb_layers):
+                np.testing.assert_array_equal(ctx.predict_tap(0, l), dbg["e"][l], err_msg="e level %d" % l)
+            for l in reversed(range(cfg.nb_layers)):
+                np.testing.assert_array_equal(ctx.predict_tap(1, l), dbg["r"][l], err_msg="r level %d" % l)
+        np.testing.assert_array_equal(got[i], ref, err_msg="frame %d" % i)
+    # recursion: feed predictions back
+    again = ctx.predict_next(got[:1])
+    np.testing.assert_array_equal(again[0], net.next(got[0]))
+
+
+def test_prednet_matches_independent_numpy_restatement(ctx):
+    from oracle import prednet_np
+    cfg, hp, wp = SMALL, 16, 24
+    rng = np.random.default_rng(8)
+    w = cfg.init_weights(seed=5, bias_scale=0.3)
+    ctx.load_model(cfg, w)
+    ctx.prepare(hp, wp, 1)
+    f = rng.integers(0, 256, (hp, wp, 3)).astype(np.float32) / np.float32(255)
+    ref = prednet_np.predict(w, cfg.stack_sizes, cfg.R_stack_sizes, np.stack([f, np.zeros_like(f)]))
+    np.testing.assert_allclose(ctx.predict_c0(), ref[0], atol=2e-5)  # tolerance: float32 summation order
+    np.testing.assert_allclose(ctx.predict_next(f[None])[0], ref[1], atol=2e-5)
+
+
+# ------------------------------------------------------------------- rollout + full pipeline
+class _OraclePredictor:
+    def __init__(self, net):
+        self.net = net
+
+    def c0(self, hp, wp):
+        return self.net.c0()
+
+    def next(self, frame):
+        return self.net.next(np.asarray(frame, dtype=np.float32))
+
+
+CASES = [
+    # nt, h, w, p, window, thr, mode, bound, entropy
+    (11, 21, 30, 2, 4, None, "abs", [0.0], True),
+    (12, 16, 24, 0, 5, None, "abs", [4.0], True),
+    (9, 16, 16, 0, 4, None, "rel", [0.02], False),   # boundary on the last frame
+    (11, 21, 30, 1, 3, None, "pwrel", [0.05], True),
+    (10, 24, 16, 0, None, "auto", "absrel", [3.0, 0.05], True),
+    (10, 24, 16, 2, None, "auto", "abs", [0.0], True),
+]
+
+
+@pytest.mark.parametrize("nt,h,w,p,window,thr,mode,bound,entropy", CASES)
+def test_compress_decompress_matches_oracle(ctx, nt, h, w, p, window, thr, mode, bound, entropy):
+    cfg = SMALL
+    rng = np.random.default_rng(9)
+    frames = _frames(rng, nt, h, w)
+    hp, wp = _pad(h), _pad(w)
+    wts = cfg.init_weights(seed=3, bias_scale=0.2)
+    pred = _OraclePredictor(coracle.CPredNet(wts, cfg.stack_sizes, cfg.R_stack_sizes, hp, wp))
+    if thr == "auto":  # pick a threshold inside the observed MSE range so windows have mixed lengths
+        probe = O.rollout(frames, p, None, 1e9, pred)
+        thr = float(np.median(probe["mse"]))
+    ref = O.compress_oracle(frames, p, window, thr, mode, bound, pred, entropy)
+    ctx.load_model(cfg, wts)
+    ctx.prepare(hp, wp, max_batch=4)
+    key, mse = ctx.rollout(frames, p, window, thr, want_mse=True)
+    np.testing.assert_array_equal(key, ref["key"])
+    # predictions: every slot the encoder uses (slot 0 of each group is a placeholder)
+    stack = ctx.get_predictions()
+    for start, preds in ref["rollout"]["groups"]:
+        for j, pr in enumerate(preds):
+            if j > 0 or start < p:
+                np.testing.assert_array_equal(stack[start + j], pr, err_msg="prediction of frame %d" % (start + j))
+    if window is None:  # DWP decisions come from the MSE: same order of summation => same bits
+        got_mse = [m for m in mse[p + 1:]]
+        np.testing.assert_allclose(got_mse, ref["mse"], rtol=1e-12)
+    payload, table, delta = ctx.encode(mode, bound, entropy, want_delta=True)
+    np.testing.assert_array_equal(delta, ref["delta"])
+    stream_payload, ref_table, shape, warm = O.parse_stream(ref["stream"])
+    np.testing.assert_array_equal(payload, stream_payload)
+    if entropy:
+        np.testing.assert_array_equal(table, ref_table)
+    else:
+        assert table is None and ref_table is None
+    # decode on the GPU and compare with the oracle's decoder and (lossless) the input
+    key_stack = ref["key_frame"].reshape(nt, h, w, 3)
+    kd = ctx.rollout_decode(key_stack, p)
+    np.testing.assert_array_equal(kd, ref["key"])
+    dec = ctx.decode(payload, table)
+    np.testing.assert_array_equal(dec, O.decode_stream(ref["stream"], ref["key_frame"], pred))
+    if bound[0] == 0:
+        np.testing.assert_array_equal(dec, frames)
+
+
+def test_rollout_rejects_short_sequences_and_bad_sizes(ctx):
+    from tezip_amd._lib import TezipError
+    cfg = SMALL
+    ctx.load_model(cfg, cfg.init_weights(seed=1))
+    ctx.prepare(16, 16, 1)
+    f = np.zeros((3, 16, 16, 3), np.uint8)
+    with pytest.raises(TezipError):
+        ctx.rollout(f[:1], 0, 2)
+    with pytest.raises(TezipError):
+        ctx.rollout(f, 2, 2)
+    with pytest.raises(TezipError):  # compress.py:178-181
+        ctx.rollout(np.zeros((3, 24, 16, 3), np.uint8), 0, 2)

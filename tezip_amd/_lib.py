@@ -1,0 +1,304 @@
+"""ctypes binding of libtezip_hip.so (the C ABI declared in include/tezip_hip.h).
+
+This is the whole Python <-> native boundary: plain pointers and sizes.  Arguments may be
+numpy arrays (host memory) or torch CUDA tensors (device memory; only `.data_ptr()` is
+used).  There is NO CPU fallback: if the library is missing or no GPU is usable the calls
+raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libtezip_hip.so")
+
+TZ_OK = 0
+TZ_NBINS = 2111
+TZ_MAX_TABLE = 1021
+MODES = {"abs": 0, "rel": 1, "absrel": 2, "pwrel": 3}
+
+_SIGS = {
+    "tz_version": (C.c_int, []),
+    "tz_strerror": (C.c_char_p, [C.c_int]),
+    "tz_last_error": (C.c_char_p, [C.c_void_p]),
+    "tz_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "tz_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "tz_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "tz_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "tz_model_load": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tz_model_prepare": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "tz_predict_c0": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tz_predict_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "tz_predict_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tz_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                             C.c_void_p, C.c_void_p]),
+    "tz_rollout_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "tz_get_predictions": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tz_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                            C.POINTER(C.c_int), C.c_void_p]),
+    "tz_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "tz_delta_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "tz_error_bound": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_double, C.c_double]),
+    "tz_spatial_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int16, C.c_int, C.c_void_p, C.c_void_p]),
+    "tz_build_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    "tz_remap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
+    "tz_unmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tz_spatial_undelta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int16, C.c_void_p]),
+    "tz_reconstruct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p]),
+    "tz_window_sse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "tz_timer_start": (C.c_int, [C.c_void_p]),
+    "tz_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "tz_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "tz_prof_count": (C.c_int, []),
+    "tz_prof_name": (C.c_char_p, [C.c_int]),
+    "tz_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "tz_prof_reset": (C.c_int, [C.c_void_p]),
+}
+EXPORTS = sorted(_SIGS)
+
+_LIB = None
+
+
+class TezipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("tezip_hip status %d: %s" % (status, message))
+        self.status = status
+
+
+def load():
+    """Load libtezip_hip.so; raises if it has not been built (python -m tezip_amd.build)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `python -m tezip_amd.build` "
+                              "(there is no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = lib
+    return _LIB
+
+
+def pad8(v):
+    return (v + 7) // 8 * 8
+
+
+def _ptr(x, dtype=None):
+    """Pointer of a numpy array (host) or torch tensor (device or host)."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        if dtype is not None and x.dtype != dtype:
+            raise TypeError("expected %s, got %s" % (dtype, x.dtype))
+        if not x.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return x.data_ptr()
+    raise TypeError("unsupported buffer type %r" % type(x))
+
+
+class Context:
+    """One context per GPU/process (tz_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.tz_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != TZ_OK:
+            raise TezipError(rc, self.lib.tz_strerror(rc).decode() + " (tz_ctx_create; a MI355X is required)")
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tz_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc != TZ_OK:
+            msg = self.lib.tz_last_error(self.h).decode() or self.lib.tz_strerror(rc).decode()
+            raise TezipError(rc, msg)
+
+    def synchronize(self):
+        self._ck(self.lib.tz_ctx_synchronize(self.h))
+
+    # ---- model
+    def load_model(self, config, weights):
+        ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+        shapes = config.weight_shapes()
+        if len(ws) != len(shapes) or any(tuple(w.shape) != s for w, (_, s) in zip(ws, shapes)):
+            raise ValueError("weight list does not match the model (prednet.py:210-227 order)")
+        ptrs = (C.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+        st = np.array(config.stack_sizes, dtype=np.int32)
+        rs = np.array(config.R_stack_sizes, dtype=np.int32)
+        self._ck(self.lib.tz_model_load(self.h, config.nb_layers, st.ctypes.data, rs.ctypes.data,
+                                        C.cast(ptrs, C.c_void_p)))
+        self.config = config
+
+    def prepare(self, hp, wp, max_batch=1):
+        self._ck(self.lib.tz_model_prepare(self.h, hp, wp, max_batch))
+        self.hp, self.wp = hp, wp
+
+    def predict_c0(self):
+        out = np.empty((self.hp, self.wp, 3), np.float32)
+        self._ck(self.lib.tz_predict_c0(self.h, out.ctypes.data))
+        return out
+
+    def predict_next(self, frames, out=None):
+        n = frames.shape[0]
+        if out is None:
+            out = np.empty((n, self.hp, self.wp, 3), np.float32)
+        self._ck(self.lib.tz_predict_next(self.h, _ptr(frames, np.float32), n, _ptr(out, np.float32)))
+        return out
+
+    def predict_tap(self, kind, level):
+        st, rs = self.config.stack_sizes, self.config.R_stack_sizes
+        ch = 2 * st[level] if kind == 0 else rs[level]
+        out = np.empty((self.hp >> level, self.wp >> level, ch), np.float32)
+        self._ck(self.lib.tz_predict_tap(self.h, kind, level, out.ctypes.data))
+        return out
+
+    # ---- rollout + encode / decode
+    def rollout(self, frames, warm_up, window, threshold=0.0, want_mse=False):
+        nt, h, w = frames.shape[:3]
+        key = np.zeros(nt, np.uint8)
+        mse = np.zeros(nt, np.float64) if want_mse else None
+        self._ck(self.lib.tz_rollout(self.h, _ptr(frames, np.uint8), nt, h, w, warm_up, int(window or 0),
+                                     float(threshold or 0.0), key.ctypes.data, _ptr(mse)))
+        self._shape = (nt, h, w)
+        return key.astype(bool), mse
+
+    def rollout_decode(self, key_frames, warm_up):
+        nt, h, w = key_frames.shape[:3]
+        key = np.zeros(nt, np.uint8)
+        self._ck(self.lib.tz_rollout_decode(self.h, _ptr(key_frames, np.uint8), nt, h, w, warm_up, key.ctypes.data))
+        self._shape = (nt, h, w)
+        return key.astype(bool)
+
+    def get_predictions(self):
+        nt, h, w = self._shape
+        out = np.empty((nt, pad8(h), pad8(w), 3), np.float32)
+        self._ck(self.lib.tz_get_predictions(self.h, out.ctypes.data))
+        return out
+
+    def encode(self, mode, bound, entropy=True, payload=None, want_delta=False):
+        nt, h, w = self._shape
+        b0 = float(bound[0])
+        b1 = float(bound[1]) if len(bound) > 1 else 0.0
+        if payload is None:
+            payload = np.empty(nt * h * w * 3, np.int16)
+        table = np.zeros(TZ_MAX_TABLE, np.int16)
+        tlen = C.c_int(0)
+        delta = np.empty((nt, h, w, 3), np.int16) if want_delta else None
+        self._ck(self.lib.tz_encode(self.h, MODES[mode], b0, b1, int(bool(entropy)), _ptr(payload), table.ctypes.data,
+                                    C.byref(tlen), _ptr(delta)))
+        t = table[: tlen.value].copy() if tlen.value >= 0 else None
+        return payload, t, delta
+
+    def decode(self, payload, table, out=None):
+        nt, h, w = self._shape
+        if out is None:
+            out = np.empty((nt, h, w, 3), np.uint8)
+        tl = -1 if table is None else len(table)
+        tb = None if table is None else np.ascontiguousarray(table, np.int16)
+        self._ck(self.lib.tz_decode(self.h, _ptr(payload), _ptr(tb), tl, _ptr(out)))
+        return out
+
+    # ---- operator seams
+    def delta_encode(self, pred, orig, zero_mask=None, out=None):
+        n, h, w = orig.shape[:3]
+        if out is None:
+            out = np.empty((n, h, w, 3), np.int16)
+        zm = None if zero_mask is None else np.ascontiguousarray(zero_mask, np.uint8)
+        self._ck(self.lib.tz_delta_encode(self.h, _ptr(pred), _ptr(orig), _ptr(zm), n, h, w, _ptr(out)))
+        return out
+
+    def error_bound(self, orig, diff, mode, bound, skip_mask=None):
+        n, h, w = orig.shape[:3]
+        b1 = float(bound[1]) if len(bound) > 1 else 0.0
+        sk = None if skip_mask is None else np.ascontiguousarray(skip_mask, np.uint8)
+        self._ck(self.lib.tz_error_bound(self.h, _ptr(orig), _ptr(diff), _ptr(sk), n, h, w, MODES[mode], float(bound[0]), b1))
+        return diff
+
+    def spatial_delta(self, x, offset, carry=None, hist=None, out=None):
+        n = int(np.prod(x.shape))
+        if out is None:
+            out = np.empty(n, np.int16)
+        self._ck(self.lib.tz_spatial_delta(self.h, _ptr(x), n, int(carry is not None), int(carry or 0), int(offset),
+                                           _ptr(out), _ptr(hist)))
+        return out
+
+    def build_table(self, hist):
+        hist = np.ascontiguousarray(hist, np.uint64)
+        table = np.zeros(TZ_MAX_TABLE, np.int16)
+        tlen = C.c_int(0)
+        self._ck(self.lib.tz_build_table(hist.ctypes.data, len(hist), table.ctypes.data, C.byref(tlen)))
+        return table[: tlen.value].copy()
+
+    def remap(self, x, table, out=None):
+        n = int(np.prod(x.shape))
+        if out is None:
+            out = np.empty(n, np.int16)
+        tb = np.ascontiguousarray(table, np.int16)
+        self._ck(self.lib.tz_remap(self.h, _ptr(x), n, tb.ctypes.data, len(tb), _ptr(out)))
+        return out
+
+    def unmap(self, x, table, offset=True, out=None):
+        n = int(np.prod(x.shape))
+        if out is None:
+            out = np.empty(n, np.int16)
+        tb = np.ascontiguousarray(table, np.int16)
+        self._ck(self.lib.tz_unmap(self.h, _ptr(x), n, tb.ctypes.data, len(tb), int(offset), _ptr(out)))
+        return out
+
+    def spatial_undelta(self, x, carry=None, out=None):
+        n = int(np.prod(x.shape))
+        if out is None:
+            out = np.empty(n, np.int16)
+        self._ck(self.lib.tz_spatial_undelta(self.h, _ptr(x), n, int(carry is not None), int(carry or 0), _ptr(out)))
+        return out
+
+    def reconstruct(self, pred, key_frames, key_mask, diff, out=None):
+        n, h, w = diff.shape[:3]
+        if out is None:
+            out = np.empty((n, h, w, 3), np.uint8)
+        km = None if key_mask is None else np.ascontiguousarray(key_mask, np.uint8)
+        self._ck(self.lib.tz_reconstruct(self.h, _ptr(pred), _ptr(key_frames), _ptr(km), _ptr(diff), n, h, w, _ptr(out)))
+        return out
+
+    def window_sse(self, orig, pred):
+        n, h, w = orig.shape[:3]
+        sse = np.zeros(n, np.float64)
+        self._ck(self.lib.tz_window_sse(self.h, _ptr(orig), _ptr(pred), n, h, w, sse.ctypes.data))
+        return sse
+
+    # ---- timing
+    def timer_start(self):
+        self._ck(self.lib.tz_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        self._ck(self.lib.tz_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def prof_enable(self, on=True):
+        self._ck(self.lib.tz_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        self._ck(self.lib.tz_prof_reset(self.h))
+
+    def prof_get(self):
+        out = {}
+        for i in range(self.lib.tz_prof_count()):
+            ms, n = C.c_double(0), C.c_longlong(0)
+            self._ck(self.lib.tz_prof_get(self.h, i, C.byref(ms), C.byref(n)))
+            out[self.lib.tz_prof_name(i).decode()] = (ms.value, n.value)
+        return out

@@ -1,0 +1,833 @@
+// Context, staging helpers, rollout state machine and the encode/decode drivers of
+// libtezip_hip.so.  Reference control flow: /root/reference/src/compress.py:183-373 and
+// /root/reference/src/decompress.py:105-256 (cited per function).
+#include <stdarg.h>
+
+#include <algorithm>
+
+#include "tz_internal.h"
+
+// ------------------------------------------------------------------------------ errors
+int tz_fail(tz_ctx* ctx, int status, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->last_error = buf;
+    return status;
+}
+
+extern "C" int tz_version(void) { return 100; }
+
+extern "C" const char* tz_strerror(int s) {
+    switch (s) {
+        case TZ_OK: return "ok";
+        case TZ_ERR_INVALID: return "invalid argument";
+        case TZ_ERR_NO_DEVICE: return "no HIP device";
+        case TZ_ERR_HIP: return "HIP runtime error";
+        case TZ_ERR_STATE: return "call order / missing state";
+        case TZ_ERR_NOMEM: return "out of device memory";
+        case TZ_ERR_UNSUPPORTED: return "unsupported model shape";
+    }
+    return "unknown status";
+}
+
+extern "C" const char* tz_last_error(const tz_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+// ----------------------------------------------------------------------------- context
+extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
+    if (!out) return TZ_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TZ_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return TZ_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return TZ_ERR_NO_DEVICE;
+    tz_ctx* ctx = new tz_ctx();
+    ctx->device = device;
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return TZ_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    (void)hipEventCreate(&ctx->ev0);
+    (void)hipEventCreate(&ctx->ev1);
+    *out = ctx;
+    return TZ_OK;
+}
+
+extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
+    if (!ctx) return TZ_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    tz_model_free(ctx);
+    tz_pool_release_all(ctx);
+    for (auto& p : ctx->pool) (void)hipFree(p.first);
+    if (ctx->d_frames) (void)hipFree(ctx->d_frames);
+    if (ctx->d_pred) (void)hipFree(ctx->d_pred);
+    for (auto& s : ctx->prof)
+        for (auto& e : s.pending) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return TZ_OK;
+}
+
+extern "C" int tz_ctx_synchronize(tz_ctx* ctx) {
+    if (!ctx) return TZ_ERR_INVALID;
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TZ_OK;
+}
+
+extern "C" void* tz_ctx_stream(tz_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ---------------------------------------------------------------------- memory helpers
+bool tz_is_device_ptr(const void* p) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // unregistered host memory: clear the sticky error
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+static constexpr size_t kPoolUsed = (size_t)1 << 63;  // top bit of the size marks "handed out"
+
+int tz_pool_alloc(tz_ctx* ctx, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pool.size(); ++i) {
+        size_t sz = ctx->pool[i].second;
+        if ((sz & kPoolUsed) || sz < bytes) continue;
+        if (best < 0 || sz < ctx->pool[best].second) best = i;
+    }
+    if (best >= 0 && ctx->pool[best].second <= 2 * bytes + (1 << 20)) {
+        ctx->pool[best].second |= kPoolUsed;
+        *out = ctx->pool[best].first;
+        return TZ_OK;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return tz_fail(ctx, TZ_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    ctx->pool.push_back({p, bytes | kPoolUsed});
+    *out = p;
+    return TZ_OK;
+}
+
+void tz_pool_release_all(tz_ctx* ctx) {
+    for (auto& e : ctx->pool) e.second &= ~kPoolUsed;
+}
+
+int tz_ensure(tz_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *buf) return TZ_OK;
+    if (*buf) {
+        TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(*buf);
+        *buf = nullptr;
+        *cap = 0;
+    }
+    hipError_t e = hipMalloc(buf, bytes ? bytes : 16);
+    if (e != hipSuccess) return tz_fail(ctx, TZ_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    *cap = bytes;
+    return TZ_OK;
+}
+
+int tz_dev_in(tz_ctx* ctx, const void* p, size_t bytes, const void** dev) {
+    if (bytes == 0 || tz_is_device_ptr(p)) {
+        *dev = p;
+        return TZ_OK;
+    }
+    void* d;
+    TZ_TRY(tz_pool_alloc(ctx, bytes, &d));
+    TZ_HIP(ctx, hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev = d;
+    return TZ_OK;
+}
+
+int tz_dev_out(tz_ctx* ctx, void* p, size_t bytes, tz_out* o) {
+    o->bytes = bytes;
+    if (bytes == 0 || tz_is_device_ptr(p)) {
+        o->host = nullptr;
+        o->dev = p;
+        return TZ_OK;
+    }
+    o->host = p;
+    return tz_pool_alloc(ctx, bytes, &o->dev);
+}
+
+int tz_dev_out_finish(tz_ctx* ctx, std::vector<tz_out>& outs) {
+    bool any = false;
+    for (auto& o : outs)
+        if (o.host && o.bytes) {
+            TZ_HIP(ctx, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
+            any = true;
+        }
+    if (any) TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TZ_OK;
+}
+
+// --------------------------------------------------------------------------- profiling
+tz_prof_scope::tz_prof_scope(tz_ctx* c, int k) : ctx(c), cls(k) {
+    if (!ctx->prof_on) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        a = b = nullptr;
+        return;
+    }
+    (void)hipEventRecord(a, ctx->stream);
+}
+tz_prof_scope::~tz_prof_scope() {
+    if (!a || !b) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->prof[cls].pending.push_back({a, b});
+}
+
+static const char* kProfNames[TZP_COUNT] = {"conv3x3_mfma", "err0", "delta", "quant", "spatial_delta_hist",
+                                            "lut_remap", "undelta_scan", "reconstruct", "sse"};
+
+extern "C" int tz_prof_enable(tz_ctx* ctx, int on) {
+    if (!ctx) return TZ_ERR_INVALID;
+    ctx->prof_on = on != 0;
+    return TZ_OK;
+}
+extern "C" int tz_prof_count(void) { return TZP_COUNT; }
+extern "C" const char* tz_prof_name(int i) { return (i >= 0 && i < TZP_COUNT) ? kProfNames[i] : ""; }
+
+static int prof_drain(tz_ctx* ctx) {
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& s : ctx->prof) {
+        for (auto& e : s.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+                s.total_ms += ms;
+                s.launches += 1;
+            }
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        s.pending.clear();
+    }
+    return TZ_OK;
+}
+
+extern "C" int tz_prof_get(tz_ctx* ctx, int i, double* total_ms, long long* launches) {
+    if (!ctx || i < 0 || i >= TZP_COUNT) return TZ_ERR_INVALID;
+    TZ_TRY(prof_drain(ctx));
+    if (total_ms) *total_ms = ctx->prof[i].total_ms;
+    if (launches) *launches = ctx->prof[i].launches;
+    return TZ_OK;
+}
+
+extern "C" int tz_prof_reset(tz_ctx* ctx) {
+    if (!ctx) return TZ_ERR_INVALID;
+    TZ_TRY(prof_drain(ctx));
+    for (auto& s : ctx->prof) {
+        s.total_ms = 0;
+        s.launches = 0;
+    }
+    return TZ_OK;
+}
+
+extern "C" int tz_timer_start(tz_ctx* ctx) {
+    if (!ctx) return TZ_ERR_INVALID;
+    TZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return TZ_OK;
+}
+extern "C" int tz_timer_stop(tz_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return TZ_ERR_INVALID;
+    TZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    TZ_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    TZ_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return TZ_OK;
+}
+
+// ------------------------------------------------------------------------------ rollout
+static int pad8(int v) { return (v + 7) / 8 * 8; }  // data_utils.py:103-107
+
+__global__ void k_any_nonzero(const uint8_t* __restrict__ frames, size_t frame_bytes, int* __restrict__ flags) {
+    int f = blockIdx.y;
+    const uint8_t* p = frames + (size_t)f * frame_bytes;
+    int any = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < frame_bytes; i += (size_t)gridDim.x * blockDim.x)
+        any |= p[i] != 0;
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&flags[f], 1);
+}
+
+__global__ void k_bcast_frame(const float* __restrict__ src, size_t fe, const int* __restrict__ slots, int nslots,
+                              float* __restrict__ stack) {
+    int s = blockIdx.y;
+    if (s >= nslots) return;
+    float* dst = stack + (size_t)slots[s] * fe;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < fe; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+static int rollout_setup(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int W, int warm_up) {
+    if (!ctx->model) return tz_fail(ctx, TZ_ERR_STATE, "no model loaded");
+    if (nt < 1 || H < 1 || W < 1 || warm_up < 0 || nt > 32767 || H > 32767 || W > 32767)
+        return tz_fail(ctx, TZ_ERR_INVALID, "bad sequence shape nt=%d H=%d W=%d warm_up=%d (int16 trailer limits)", nt, H, W, warm_up);
+    int Hp, Wp, maxB;
+    TZ_TRY(tz_model_dims(ctx, &Hp, &Wp, &maxB));
+    if (pad8(H) != Hp || pad8(W) != Wp)
+        return tz_fail(ctx, TZ_ERR_INVALID,
+                       "Image size is out of scope for this model: compatible sizes are height %d to %d and width %d to %d",
+                       Hp - 7, Hp, Wp - 7, Wp);  // compress.py:178-181
+    ctx->nt = nt;
+    ctx->H = H;
+    ctx->W = W;
+    ctx->Hp = Hp;
+    ctx->Wp = Wp;
+    ctx->warm_up = warm_up;
+    ctx->have_rollout = false;
+    size_t fb = (size_t)nt * H * W * 3, pb = (size_t)nt * Hp * Wp * 3 * 4;
+    TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_frames, &ctx->cap_frames, fb));
+    TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_pred, &ctx->cap_pred, pb));
+    TZ_HIP(ctx, hipMemcpyAsync(ctx->d_frames, frames, fb, hipMemcpyDefault, ctx->stream));
+    return TZ_OK;
+}
+
+// copy C0 into the given slots of the prediction stack
+static int fill_c0(tz_ctx* ctx, const std::vector<int>& slots) {
+    if (slots.empty()) return TZ_OK;
+    const float* c0;
+    TZ_TRY(tz_model_c0_dev(ctx, &c0));
+    size_t fe = (size_t)ctx->Hp * ctx->Wp * 3;
+    void* d_slots;
+    TZ_TRY(tz_pool_alloc(ctx, slots.size() * sizeof(int), &d_slots));
+    TZ_HIP(ctx, hipMemcpyAsync(d_slots, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    int gx = (int)std::min<size_t>((fe + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_bcast_frame, dim3(gx, (unsigned)slots.size()), dim3(256), 0, ctx->stream, c0, fe,
+                       (const int*)d_slots, (int)slots.size(), ctx->d_pred);
+    TZ_HIP(ctx, hipGetLastError());
+    return TZ_OK;
+}
+
+// Run a static schedule: items (out frame, from_key, in frame) grouped by depth; every depth
+// is one batched predictor call over all windows (their recursions are independent).
+struct PredItem {
+    int out, from_key, in, depth;
+};
+static int run_schedule(tz_ctx* ctx, std::vector<PredItem>& items) {
+    int Hp, Wp, maxB;
+    TZ_TRY(tz_model_dims(ctx, &Hp, &Wp, &maxB));
+    std::stable_sort(items.begin(), items.end(), [](const PredItem& a, const PredItem& b) { return a.depth < b.depth; });
+    size_t i = 0;
+    while (i < items.size()) {
+        size_t j = i;
+        while (j < items.size() && items[j].depth == items[i].depth && (int)(j - i) < maxB) ++j;
+        std::vector<int> isk, ii, oi;
+        for (size_t k = i; k < j; ++k) {
+            isk.push_back(items[k].from_key);
+            ii.push_back(items[k].in);
+            oi.push_back(items[k].out);
+        }
+        TZ_TRY(tz_model_predict_batch(ctx, (int)(j - i), isk.data(), ii.data(), oi.data(), ctx->d_frames, ctx->H, ctx->W,
+                                      ctx->d_pred, ctx->d_pred));
+        i = j;
+    }
+    return TZ_OK;
+}
+
+extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int W, int warm_up, int window,
+                          double threshold, uint8_t* key_mask, double* mse_log) {
+    if (!ctx || !frames) return TZ_ERR_INVALID;
+    if (window < 0) return tz_fail(ctx, TZ_ERR_INVALID, "window must be >= 0");
+    if (nt < warm_up + 2)  // the reference breaks here
+        return tz_fail(ctx, TZ_ERR_INVALID, "need at least warm_up+2 frames (nt=%d, warm_up=%d)", nt, warm_up);
+    int rc = rollout_setup(ctx, frames, nt, H, W, warm_up);
+    if (rc != TZ_OK) return rc;
+    const int p = warm_up;
+    const bool dwp = window == 0;
+    const bool want_mse = dwp || mse_log != nullptr;
+    std::vector<uint8_t> key(nt, 0), gfirst(nt, 0), qskip(nt, 0);
+    std::vector<double> mse(nt, 0.0);
+    std::vector<int> c0_slots;
+    // compress.py:188-211: warm-up frames are key frames whose "prediction" is C0
+    for (int i = 0; i < p; ++i) {
+        key[i] = 1;
+        qskip[i] = 1;  // error_bound is skipped for group 0 (compress.py:315)
+        c0_slots.push_back(i);
+    }
+    gfirst[0] = 1;
+    if (p > 0) {
+        gfirst[p] = 1;
+        c0_slots.push_back(p);
+    } else {
+        c0_slots.push_back(0);
+    }
+    const size_t fe_pad = (size_t)ctx->Hp * ctx->Wp * 3;
+    if (!dwp) {
+        // SWP: window boundaries are known up front (compress.py:249: (idx-p) % w == 0), so all
+        // windows advance together; the prediction dropped at a boundary (251-253) is never made.
+        std::vector<PredItem> items;
+        int key_idx = p + 1;
+        for (int idx = p + 1; idx < nt; ++idx) {
+            bool from_key = idx == key_idx;
+            if (from_key) key[idx - 1] = 1;
+            bool trig = (idx - p) % window == 0;
+            if (trig) {
+                gfirst[idx] = 1;
+                c0_slots.push_back(idx);
+                if (idx == nt - 1) key[idx] = 1;  // compress.py:260-262
+                key_idx = idx + 1;
+            } else {
+                items.push_back(PredItem{idx, from_key ? 1 : 0, idx - 1, idx - (key_idx - 1)});
+            }
+        }
+        rc = fill_c0(ctx, c0_slots);
+        if (rc == TZ_OK) rc = run_schedule(ctx, items);
+        if (rc == TZ_OK && want_mse) {
+            // verbose-only in the reference (compress.py:245-247); note the reference's value at
+            // a boundary frame includes the dropped prediction, which SWP never evaluates here:
+            // those entries are reported as 0.
+            std::vector<double> sse(nt, 0.0);
+            rc = tzk_sse(ctx, ctx->d_frames, ctx->d_pred, nt, H, W, ctx->Hp, ctx->Wp, sse.data());
+            int k0 = p + 1;
+            double run = 0.0;
+            for (int idx = p + 1; idx < nt && rc == TZ_OK; ++idx) {
+                if (gfirst[idx]) {
+                    k0 = idx + 1;
+                    run = 0.0;
+                    continue;
+                }
+                run = run + sse[idx];
+                mse[idx] = run / (double)((size_t)(idx - k0 + 1) * fe_pad);
+            }
+        }
+    } else {
+        // DWP: boundaries depend on the window MSE of the padded frames (compress.py:245-249)
+        rc = fill_c0(ctx, c0_slots);
+        int key_idx = p + 1;
+        double run = 0.0;
+        for (int idx = p + 1; idx < nt && rc == TZ_OK; ++idx) {
+            bool from_key = idx == key_idx;
+            if (from_key) key[idx - 1] = 1;
+            int isk = from_key ? 1 : 0, in = idx - 1, out = idx;
+            rc = tz_model_predict_batch(ctx, 1, &isk, &in, &out, ctx->d_frames, H, W, ctx->d_pred, ctx->d_pred);
+            if (rc != TZ_OK) break;
+            double sse = 0.0;
+            rc = tzk_sse(ctx, ctx->d_frames + (size_t)idx * H * W * 3, ctx->d_pred + (size_t)idx * fe_pad, 1, H, W,
+                         ctx->Hp, ctx->Wp, &sse);
+            if (rc != TZ_OK) break;
+            run = run + sse;
+            double stop = run / (double)((size_t)(idx - key_idx + 1) * fe_pad);
+            mse[idx] = stop;
+            if (stop > threshold) {
+                gfirst[idx] = 1;
+                std::vector<int> one(1, idx);
+                if (idx != nt - 1) rc = fill_c0(ctx, one);  // slot 0 of the new group holds C0 (258)
+                if (idx == nt - 1) key[idx] = 1;           // ... or keeps the prediction (260-262)
+                key_idx = idx + 1;
+                run = 0.0;
+            }
+        }
+    }
+    for (int i = 0; i < nt; ++i)
+        if (gfirst[i]) qskip[i] = 1;
+    if (rc == TZ_OK) {
+        ctx->key_mask = key;
+        ctx->group_first = gfirst;
+        ctx->quant_skip = qskip;
+        ctx->have_rollout = true;
+        ctx->rollout_is_decode = false;
+        if (key_mask) memcpy(key_mask, key.data(), nt);
+        if (mse_log) memcpy(mse_log, mse.data(), sizeof(double) * nt);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "rollout failed: %s", hipGetErrorString(e));
+    }
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+extern "C" int tz_rollout_decode(tz_ctx* ctx, const uint8_t* key_frames, int nt, int H, int W, int warm_up,
+                                 uint8_t* key_mask) {
+    if (!ctx || !key_frames) return TZ_ERR_INVALID;
+    int rc = rollout_setup(ctx, key_frames, nt, H, W, warm_up);
+    if (rc != TZ_OK) return rc;
+    // decompress.py:123-129: a frame is a key frame iff it has a non-zero sample
+    std::vector<int> flags(nt, 0);
+    void* d_flags;
+    rc = tz_pool_alloc(ctx, sizeof(int) * nt, &d_flags);
+    if (rc == TZ_OK) {
+        size_t fb = (size_t)H * W * 3;
+        hipError_t e = hipMemsetAsync(d_flags, 0, sizeof(int) * nt, ctx->stream);
+        int gx = (int)std::min<size_t>((fb + 255) / 256, 64);
+        hipLaunchKernelGGL(k_any_nonzero, dim3(gx, nt), dim3(256), 0, ctx->stream, ctx->d_frames, fb, (int*)d_flags);
+        if (e == hipSuccess) e = hipMemcpyAsync(flags.data(), d_flags, sizeof(int) * nt, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "key discovery failed: %s", hipGetErrorString(e));
+    }
+    if (rc != TZ_OK) {
+        tz_pool_release_all(ctx);
+        return rc;
+    }
+    std::vector<int> kfc;
+    for (int i = 0; i < nt; ++i)
+        if (flags[i]) kfc.push_back(i);
+    kfc.push_back(nt);
+    // decompress.py:138-179: warm_up copies of C0, then for every key interval: the key frame
+    // itself, one prediction from the key frame, then recursion on the previous prediction.
+    std::vector<uint8_t> recon_key(nt, 0);
+    std::vector<int> c0_slots;
+    std::vector<PredItem> items;
+    int produced = warm_up;
+    for (int i = 0; i < warm_up && i < nt; ++i) c0_slots.push_back(i);
+    for (int k = warm_up; k + 1 < (int)kfc.size(); ++k)
+        for (int pi = kfc[k]; pi < kfc[k + 1]; ++pi, ++produced) {
+            if (produced != pi || pi >= nt) {
+                tz_pool_release_all(ctx);
+                return tz_fail(ctx, TZ_ERR_INVALID, "key frames do not cover the sequence (frame %d)", pi);
+            }
+            if (pi == kfc[k]) {
+                recon_key[pi] = 1;
+                c0_slots.push_back(pi);  // slot content is never used for reconstruction
+            } else {
+                items.push_back(PredItem{pi, pi == kfc[k] + 1 ? 1 : 0, pi - 1, pi - kfc[k]});
+            }
+        }
+    if (produced != nt) {
+        tz_pool_release_all(ctx);
+        return tz_fail(ctx, TZ_ERR_INVALID, "key frames do not cover the sequence (%d of %d frames)", produced, nt);
+    }
+    recon_key[0] = 1;  // decompress.py:186
+    rc = fill_c0(ctx, c0_slots);
+    if (rc == TZ_OK) rc = run_schedule(ctx, items);
+    if (rc == TZ_OK) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "decode rollout failed: %s", hipGetErrorString(e));
+    }
+    if (rc == TZ_OK) {
+        ctx->key_mask = recon_key;
+        ctx->have_rollout = true;
+        ctx->rollout_is_decode = true;
+        if (key_mask)
+            for (int i = 0; i < nt; ++i) key_mask[i] = flags[i] ? 1 : 0;
+    }
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+extern "C" int tz_get_predictions(tz_ctx* ctx, float* out) {
+    if (!ctx || !out) return TZ_ERR_INVALID;
+    if (!ctx->have_rollout) return tz_fail(ctx, TZ_ERR_STATE, "no rollout in this context");
+    size_t bytes = (size_t)ctx->nt * ctx->Hp * ctx->Wp * 3 * 4;
+    TZ_HIP(ctx, hipMemcpyAsync(out, ctx->d_pred, bytes, hipMemcpyDefault, ctx->stream));
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TZ_OK;
+}
+
+// --------------------------------------------------------------------- table / LUT (host)
+extern "C" int tz_build_table(const unsigned long long* hist, int nbins, int16_t* table, int* table_len) {
+    if (!hist || !table || !table_len || nbins < 1 || nbins > 32767) return TZ_ERR_INVALID;
+    // compress.py:352-361: symbols with count > 0, count descending; Python's stable sort with
+    // reverse=True keeps ascending symbol order among equal counts.
+    std::vector<int> syms;
+    for (int s = 0; s < nbins; ++s)
+        if (hist[s]) syms.push_back(s);
+    std::stable_sort(syms.begin(), syms.end(), [&](int a, int b) { return hist[a] > hist[b]; });
+    if ((int)syms.size() > TZ_MAX_TABLE) return TZ_ERR_INVALID;
+    for (size_t i = 0; i < syms.size(); ++i) table[i] = (int16_t)syms[i];
+    *table_len = (int)syms.size();
+    return TZ_OK;
+}
+
+static int build_enc_lut(tz_ctx* ctx, const int16_t* table, int T, std::vector<int16_t>* lut) {
+    lut->resize(TZ_NBINS + 1);
+    for (int v = 0; v <= TZ_NBINS; ++v) (*lut)[v] = (int16_t)v;
+    for (int idx = 0; idx < T; ++idx) {
+        int s = table[idx];
+        // compress.py:87-88 applied to arbitrary tables would chain substitutions; the
+        // encoder only ever sees its own table (symbols >= 1090 > any rank), so reject others.
+        if (s < TZ_MAX_TABLE || s > TZ_NBINS) return tz_fail(ctx, TZ_ERR_INVALID, "table symbol %d outside [%d, %d]", s, TZ_MAX_TABLE, TZ_NBINS);
+        (*lut)[s] = (int16_t)idx;
+    }
+    return TZ_OK;
+}
+
+// decompress.py:31-36 sequential-pass semantics (incl. chained substitutions) + optional 1600-x
+static void build_dec_lut(const int16_t* table, int T, int apply_offset, std::vector<int16_t>* lut) {
+    lut->resize(TZ_NBINS + 1);
+    for (int v = 0; v <= TZ_NBINS; ++v) {
+        int cur = v, last = -1;
+        while (cur >= 0 && cur < T && cur > last) {
+            last = cur;
+            cur = table[cur];
+        }
+        (*lut)[v] = (int16_t)(apply_offset ? TZ_OFFSET - cur : cur);
+    }
+}
+
+// ------------------------------------------------------------------------ encode / decode
+extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t* payload, int16_t* table,
+                         int* table_len, int16_t* delta_out) {
+    if (!ctx || !payload || !table_len || (entropy && !table)) return TZ_ERR_INVALID;
+    if (!ctx->have_rollout || ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode needs a tz_rollout first");
+    const int nt = ctx->nt, H = ctx->H, W = ctx->W;
+    const size_t N = (size_t)nt * H * W * 3;
+    std::vector<tz_out> outs;
+    tz_out o_pay, o_delta;
+    void *d_delta = nullptr, *d_mask = nullptr, *d_hist = nullptr, *d_sd = nullptr;
+    int rc = tz_dev_out(ctx, payload, N * 2, &o_pay);
+    if (rc == TZ_OK) outs.push_back(o_pay);
+    if (rc == TZ_OK && delta_out) {
+        rc = tz_dev_out(ctx, delta_out, N * 2, &o_delta);
+        if (rc == TZ_OK) {
+            outs.push_back(o_delta);
+            d_delta = o_delta.dev;
+        }
+    } else if (rc == TZ_OK) {
+        rc = tz_pool_alloc(ctx, N * 2, &d_delta);
+    }
+    if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_mask);
+    if (rc == TZ_OK) {
+        hipError_t e = hipMemcpyAsync(d_mask, ctx->group_first.data(), nt, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
+    }
+    // compress.py:292-314
+    if (rc == TZ_OK) rc = tzk_delta(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt, H, W, ctx->Hp, ctx->Wp, (int16_t*)d_delta);
+    // compress.py:315-319
+    if (rc == TZ_OK) rc = tzk_error_bound(ctx, ctx->d_frames, (int16_t*)d_delta, ctx->quant_skip.data(), nt, H, W, mode, b0, b1);
+    if (rc == TZ_OK && !entropy) {
+        // compress.py:339-340 only
+        rc = tzk_spatial_delta(ctx, (const int16_t*)d_delta, N, 0, 0, 0, (int16_t*)o_pay.dev, nullptr);
+        *table_len = -1;
+    } else if (rc == TZ_OK) {
+        rc = tz_pool_alloc(ctx, TZ_NBINS * sizeof(unsigned long long), &d_hist);
+        if (rc == TZ_OK) rc = tz_pool_alloc(ctx, N * 2, &d_sd);
+        std::vector<unsigned long long> hist(TZ_NBINS, 0);
+        if (rc == TZ_OK) {
+            hipError_t e = hipMemsetAsync(d_hist, 0, TZ_NBINS * sizeof(unsigned long long), ctx->stream);
+            if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "hist memset: %s", hipGetErrorString(e));
+        }
+        // compress.py:339-355
+        if (rc == TZ_OK) rc = tzk_spatial_delta(ctx, (const int16_t*)d_delta, N, 0, 0, 1, (int16_t*)d_sd, (unsigned long long*)d_hist);
+        if (rc == TZ_OK) {
+            hipError_t e = hipMemcpyAsync(hist.data(), d_hist, TZ_NBINS * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "hist download: %s", hipGetErrorString(e));
+        }
+        std::vector<int16_t> lut;
+        if (rc == TZ_OK) rc = tz_build_table(hist.data(), TZ_NBINS, table, table_len);  // 356-361
+        if (rc == TZ_OK) rc = build_enc_lut(ctx, table, *table_len, &lut);
+        if (rc == TZ_OK) rc = tzk_lut(ctx, (const int16_t*)d_sd, N, lut.data(), 0, 0, (int16_t*)o_pay.dev);  // 369
+    }
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, const int16_t* table, int table_len, uint8_t* frames_out) {
+    if (!ctx || !payload || !frames_out) return TZ_ERR_INVALID;
+    if (!ctx->have_rollout || !ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_decode needs a tz_rollout_decode first");
+    if (table_len > TZ_NBINS || (table_len >= 0 && !table && table_len > 0)) return tz_fail(ctx, TZ_ERR_INVALID, "bad table");
+    const int nt = ctx->nt, H = ctx->H, W = ctx->W;
+    const size_t N = (size_t)nt * H * W * 3;
+    std::vector<tz_out> outs;
+    tz_out o;
+    const void* d_pay = nullptr;
+    void *d_sd = nullptr, *d_diff = nullptr, *d_mask = nullptr;
+    int rc = tz_dev_in(ctx, payload, N * 2, &d_pay);
+    if (rc == TZ_OK) rc = tz_dev_out(ctx, frames_out, N, &o);
+    if (rc == TZ_OK) outs.push_back(o);
+    if (rc == TZ_OK) rc = tz_pool_alloc(ctx, N * 2, &d_diff);
+    if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_mask);
+    if (rc == TZ_OK) {
+        hipError_t e = hipMemcpyAsync(d_mask, ctx->key_mask.data(), nt, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
+    }
+    const int16_t* sd = (const int16_t*)d_pay;
+    if (rc == TZ_OK && table_len >= 0) {  // decompress.py:203-236
+        std::vector<int16_t> lut;
+        build_dec_lut(table, table_len, 1, &lut);
+        rc = tz_pool_alloc(ctx, N * 2, &d_sd);
+        if (rc == TZ_OK) rc = tzk_lut(ctx, (const int16_t*)d_pay, N, lut.data(), 0, 1, (int16_t*)d_sd);
+        sd = (const int16_t*)d_sd;
+    }
+    if (rc == TZ_OK) rc = tzk_undelta(ctx, sd, N, 0, 0, (int16_t*)d_diff);  // decompress.py:240-245
+    if (rc == TZ_OK)                                                        // decompress.py:252-256,269
+        rc = tzk_reconstruct(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, (const int16_t*)d_diff, nt, H, W,
+                             ctx->Hp, ctx->Wp, (uint8_t*)o.dev);
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+// ------------------------------------------------------------------ stand-alone operators
+extern "C" int tz_delta_encode(tz_ctx* ctx, const float* pred, const uint8_t* orig, const uint8_t* zero_mask, int nframes,
+                               int H, int W, int16_t* out) {
+    if (!ctx || !pred || !orig || !out || nframes < 0 || H < 1 || W < 1) return TZ_ERR_INVALID;
+    int Hp = pad8(H), Wp = pad8(W);
+    size_t N = (size_t)nframes * H * W * 3;
+    std::vector<uint8_t> zm(nframes, 0);
+    if (zero_mask) memcpy(zm.data(), zero_mask, nframes);
+    const void *dp, *dor;
+    void* dm;
+    tz_out o;
+    std::vector<tz_out> outs;
+    int rc = tz_dev_in(ctx, pred, (size_t)nframes * Hp * Wp * 3 * 4, &dp);
+    if (rc == TZ_OK) rc = tz_dev_in(ctx, orig, N, &dor);
+    if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nframes, &dm);
+    if (rc == TZ_OK && nframes) {
+        hipError_t e = hipMemcpyAsync(dm, zm.data(), nframes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
+    }
+    if (rc == TZ_OK) rc = tz_dev_out(ctx, out, N * 2, &o);
+    if (rc == TZ_OK) {
+        outs.push_back(o);
+        rc = tzk_delta(ctx, (const float*)dp, (const uint8_t*)dor, (const uint8_t*)dm, nframes, H, W, Hp, Wp, (int16_t*)o.dev);
+    }
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    if (rc == TZ_OK && !outs.empty() && !outs[0].host) rc = tz_ctx_synchronize(ctx);  // zm is a stack-local upload
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+extern "C" int tz_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8_t* skip_mask, int nframes, int H,
+                              int W, int mode, double b0, double b1) {
+    if (!ctx || !orig || !diff || nframes < 0 || H < 1 || W < 1) return TZ_ERR_INVALID;
+    size_t N = (size_t)nframes * H * W * 3;
+    std::vector<uint8_t> sk(nframes, 0);
+    if (skip_mask) memcpy(sk.data(), skip_mask, nframes);
+    const void* dor;
+    tz_out o;
+    std::vector<tz_out> outs;
+    int rc = tz_dev_in(ctx, orig, N, &dor);
+    if (rc == TZ_OK) rc = tz_dev_out(ctx, diff, N * 2, &o);
+    if (rc == TZ_OK && o.host) {
+        hipError_t e = hipMemcpyAsync(o.dev, diff, N * 2, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "diff upload: %s", hipGetErrorString(e));
+    }
+    if (rc == TZ_OK) {
+        outs.push_back(o);
+        rc = tzk_error_bound(ctx, (const uint8_t*)dor, (int16_t*)o.dev, sk.data(), nframes, H, W, mode, b0, b1);
+    }
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    if (rc == TZ_OK && !outs.empty() && !outs[0].host) rc = tz_ctx_synchronize(ctx);
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+extern "C" int tz_spatial_delta(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, int16_t carry, int apply_offset,
+                                int16_t* out, unsigned long long* hist) {
+    if (!ctx || !in || !out) return TZ_ERR_INVALID;
+    const void* din;
+    tz_out o, oh;
+    std::vector<tz_out> outs;
+    int rc = tz_dev_in(ctx, in, n * 2, &din);
+    if (rc == TZ_OK) rc = tz_dev_out(ctx, out, n * 2, &o);
+    if (rc == TZ_OK) outs.push_back(o);
+    void* dh = nullptr;
+    if (rc == TZ_OK && hist) {
+        rc = tz_dev_out(ctx, hist, TZ_NBINS * sizeof(unsigned long long), &oh);
+        if (rc == TZ_OK) {
+            dh = oh.dev;
+            if (oh.host) {  // counts are ADDED to what the caller holds
+                hipError_t e = hipMemcpyAsync(dh, hist, TZ_NBINS * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream);
+                if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "hist upload: %s", hipGetErrorString(e));
+            }
+            outs.push_back(oh);
+        }
+    }
+    if (rc == TZ_OK) rc = tzk_spatial_delta(ctx, (const int16_t*)din, n, has_carry, carry, apply_offset, (int16_t*)o.dev, (unsigned long long*)dh);
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+static int lut_op(tz_ctx* ctx, const int16_t* in, size_t n, const std::vector<int16_t>& lut, int post, int16_t* out) {
+    const void* din;
+    tz_out o;
+    std::vector<tz_out> outs;
+    int rc = tz_dev_in(ctx, in, n * 2, &din);
+    if (rc == TZ_OK) rc = tz_dev_out(ctx, out, n * 2, &o);
+    if (rc == TZ_OK) {
+        outs.push_back(o);
+        rc = tzk_lut(ctx, (const int16_t*)din, n, lut.data(), 0, post, (int16_t*)o.dev);
+    }
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    if (rc == TZ_OK && !o.host) rc = tz_ctx_synchronize(ctx);  // the LUT upload reads a local vector
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+extern "C" int tz_remap(tz_ctx* ctx, const int16_t* in, size_t n, const int16_t* table, int table_len, int16_t* out) {
+    if (!ctx || !in || !out || !table || table_len < 0 || table_len > TZ_MAX_TABLE) return TZ_ERR_INVALID;
+    std::vector<int16_t> lut;
+    TZ_TRY(build_enc_lut(ctx, table, table_len, &lut));
+    return lut_op(ctx, in, n, lut, 0, out);
+}
+
+extern "C" int tz_unmap(tz_ctx* ctx, const int16_t* in, size_t n, const int16_t* table, int table_len, int apply_offset,
+                        int16_t* out) {
+    if (!ctx || !in || !out || !table || table_len < 0 || table_len > TZ_NBINS) return TZ_ERR_INVALID;
+    std::vector<int16_t> lut;
+    build_dec_lut(table, table_len, apply_offset, &lut);
+    return lut_op(ctx, in, n, lut, apply_offset, out);
+}
+
+extern "C" int tz_spatial_undelta(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, int16_t carry, int16_t* out) {
+    if (!ctx || !in || !out) return TZ_ERR_INVALID;
+    const void* din;
+    tz_out o;
+    std::vector<tz_out> outs;
+    int rc = tz_dev_in(ctx, in, n * 2, &din);
+    if (rc == TZ_OK) rc = tz_dev_out(ctx, out, n * 2, &o);
+    if (rc == TZ_OK) {
+        outs.push_back(o);
+        rc = tzk_undelta(ctx, (const int16_t*)din, n, has_carry, carry, (int16_t*)o.dev);
+    }
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+extern "C" int tz_reconstruct(tz_ctx* ctx, const float* pred, const uint8_t* key_frames, const uint8_t* key_mask,
+                              const int16_t* diff, int nframes, int H, int W, uint8_t* out) {
+    if (!ctx || !pred || !diff || !out || nframes < 0 || H < 1 || W < 1) return TZ_ERR_INVALID;
+    int Hp = pad8(H), Wp = pad8(W);
+    size_t N = (size_t)nframes * H * W * 3;
+    std::vector<uint8_t> km(nframes, 0);
+    if (key_mask && key_frames) memcpy(km.data(), key_mask, nframes);
+    const void *dp, *dk = nullptr, *dd;
+    void* dm;
+    tz_out o;
+    std::vector<tz_out> outs;
+    int rc = tz_dev_in(ctx, pred, (size_t)nframes * Hp * Wp * 3 * 4, &dp);
+    if (rc == TZ_OK && key_frames) rc = tz_dev_in(ctx, key_frames, N, &dk);
+    if (rc == TZ_OK) rc = tz_dev_in(ctx, diff, N * 2, &dd);
+    if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nframes, &dm);
+    if (rc == TZ_OK && nframes) {
+        hipError_t e = hipMemcpyAsync(dm, km.data(), nframes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
+    }
+    if (rc == TZ_OK) rc = tz_dev_out(ctx, out, N, &o);
+    if (rc == TZ_OK) {
+        outs.push_back(o);
+        rc = tzk_reconstruct(ctx, (const float*)dp, (const uint8_t*)dk, (const uint8_t*)dm, (const int16_t*)dd, nframes, H,
+                             W, Hp, Wp, (uint8_t*)o.dev);
+    }
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    if (rc == TZ_OK && !o.host) rc = tz_ctx_synchronize(ctx);
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+extern "C" int tz_window_sse(tz_ctx* ctx, const uint8_t* orig, const float* pred, int nframes, int H, int W, double* sse) {
+    if (!ctx || !orig || !pred || !sse || nframes < 0 || H < 1 || W < 1) return TZ_ERR_INVALID;
+    int Hp = pad8(H), Wp = pad8(W);
+    const void *dor, *dp;
+    int rc = tz_dev_in(ctx, orig, (size_t)nframes * H * W * 3, &dor);
+    if (rc == TZ_OK) rc = tz_dev_in(ctx, pred, (size_t)nframes * Hp * Wp * 3 * 4, &dp);
+    if (rc == TZ_OK) rc = tzk_sse(ctx, (const uint8_t*)dor, (const float*)dp, nframes, H, W, Hp, Wp, sse);
+    tz_pool_release_all(ctx);
+    return rc;
+}

@@ -1,0 +1,123 @@
+// Internal declarations shared by the translation units of libtezip_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/tezip_hip.h"
+
+#define TZ_SENTINEL ((int16_t)0x7FFF)
+
+enum tz_prof_class {
+    TZP_CONV = 0,   // implicit-GEMM MFMA convolutions (all PredNet convs)
+    TZP_ERR0,       // level-0 error unit
+    TZP_DELTA,      // pred/orig -> int16 delta
+    TZP_QUANT,      // error-bound quantiser kernels
+    TZP_SDELTA,     // spatial delta (+offset, histogram)
+    TZP_LUT,        // rank remap / unmap
+    TZP_SCAN,       // inverse spatial delta (prefix scan)
+    TZP_RECON,      // reconstruct
+    TZP_SSE,        // window MSE partial sums
+    TZP_COUNT
+};
+
+struct tz_conv_job;   // tz_prednet.hip
+struct tz_model;      // tz_prednet.hip
+
+struct tz_prof_slot {
+    double total_ms = 0;
+    long long launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct tz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    // staging pool for host-pointer arguments (grown on demand, reused)
+    std::vector<void*> scratch;       // device allocations handed out this call
+    std::vector<std::pair<void*, size_t>> pool;  // (ptr, bytes) free list
+    // model + rollout state
+    tz_model* model = nullptr;
+    // rollout-resident data
+    int nt = 0, H = 0, W = 0, Hp = 0, Wp = 0, warm_up = 0;
+    uint8_t* d_frames = nullptr;      // nt*H*W*3 (encoder: originals; decoder: key stack)
+    float* d_pred = nullptr;          // nt*Hp*Wp*3
+    size_t cap_frames = 0, cap_pred = 0;
+    std::vector<uint8_t> key_mask;    // nt
+    std::vector<uint8_t> group_first; // nt: 1 where a group starts (delta slot 0 -> 0)
+    std::vector<uint8_t> quant_skip;  // nt: 1 where error_bound is not applied
+    bool have_rollout = false, rollout_is_decode = false;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool prof_on = false;
+    tz_prof_slot prof[TZP_COUNT];
+};
+
+int tz_fail(tz_ctx* ctx, int status, const char* fmt, ...);
+
+#define TZ_HIP(ctx, expr)                                                                      \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return tz_fail(ctx, TZ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                           __FILE__, __LINE__);                                                \
+    } while (0)
+
+#define TZ_TRY(expr)            \
+    do {                        \
+        int _s = (expr);        \
+        if (_s != TZ_OK) return _s; \
+    } while (0)
+
+// ---- device memory helpers -------------------------------------------------------------
+bool tz_is_device_ptr(const void* p);
+int tz_pool_alloc(tz_ctx* ctx, size_t bytes, void** out);   // freed by tz_pool_release_all
+void tz_pool_release_all(tz_ctx* ctx);
+int tz_ensure(tz_ctx* ctx, void** buf, size_t* cap, size_t bytes);  // persistent buffer growth
+
+// Input argument: returns a device pointer holding `bytes` of *p (staging if host).
+int tz_dev_in(tz_ctx* ctx, const void* p, size_t bytes, const void** dev);
+// Output argument: returns a device pointer to write; tz_dev_out_finish copies back if host.
+struct tz_out {
+    void* host = nullptr;
+    void* dev = nullptr;
+    size_t bytes = 0;
+};
+int tz_dev_out(tz_ctx* ctx, void* p, size_t bytes, tz_out* o);
+int tz_dev_out_finish(tz_ctx* ctx, std::vector<tz_out>& outs);  // D2H copies + stream sync if any host
+
+// ---- profiling wrapper ------------------------------------------------------------------
+struct tz_prof_scope {
+    tz_ctx* ctx;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    tz_prof_scope(tz_ctx* c, int k);
+    ~tz_prof_scope();
+};
+
+// ---- kernels' host launchers (device pointers only) ---------------------------------------
+// tz_codec.hip
+int tzk_delta(tz_ctx*, const float* pred, const uint8_t* orig, const uint8_t* d_zero_mask, int nframes,
+              int H, int W, int Hp, int Wp, int16_t* out);
+int tzk_error_bound(tz_ctx*, const uint8_t* orig, int16_t* diff, const uint8_t* h_skip, int nframes, int H,
+                    int W, int mode, double b0, double b1);
+int tzk_spatial_delta(tz_ctx*, const int16_t* in, size_t n, int has_carry, int16_t carry, int apply_offset,
+                      int16_t* out, unsigned long long* d_hist);
+int tzk_lut(tz_ctx*, const int16_t* in, size_t n, const int16_t* h_lut2112, int lo, int post_offset, int16_t* out);
+int tzk_undelta(tz_ctx*, const int16_t* in, size_t n, int has_carry, int16_t carry, int16_t* out);
+int tzk_reconstruct(tz_ctx*, const float* pred, const uint8_t* key, const uint8_t* d_key_mask, const int16_t* diff,
+                    int nframes, int H, int W, int Hp, int Wp, uint8_t* out);
+int tzk_sse(tz_ctx*, const uint8_t* orig, const float* pred, int nframes, int H, int W, int Hp, int Wp,
+            double* h_sse);
+// tz_prednet.hip
+void tz_model_free(tz_ctx* ctx);
+int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int* h_in_idx, const int* h_out_idx,
+                           const uint8_t* d_frames_u8, int H, int W, const float* d_in_stack, float* d_out_stack);
+int tz_model_c0_dev(tz_ctx* ctx, const float** c0);
+int tz_model_dims(tz_ctx* ctx, int* Hp, int* Wp, int* max_batch);

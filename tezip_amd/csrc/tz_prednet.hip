@@ -1,0 +1,814 @@
+// PredNet predictor on MI355X: one LDS-tiled implicit-GEMM 3x3 convolution kernel on the
+// fp32 matrix cores (v_mfma_f32_16x16x4_f32), with the ConvLSTM / error-unit / max-pool
+// epilogues fused, and the host-side model driver.
+//
+// What is computed (reference: /root/reference/src/prednet.py:235-308, used through
+// Model.predict on a 2-step sequence from zero state, compress.py:224-229):
+//   * Everything that does not depend on the input frame is evaluated ONCE per
+//     (model, Hp, Wp) in tz_model_prepare: the t=0 top-down pass (r0_l, c0_l), Ahat_l at t=0,
+//     and G0_l = bias + conv(r0_l part of the t=1 gate convolution).
+//   * Per predicted frame only the live work runs: t=0 bottom-up (error units + A convs),
+//     t=1 top-down (gate convs over [e_l, up(r_{l+1})] starting from G0_l) and Ahat_0.
+//     The t=1 bottom-up pass and the zero second input are dead.
+//
+// Arithmetic contract TZ-PA1 (bit-exact with oracle/tz_oracle.c): every convolution output is
+// ONE float32 fmaf chain: acc = bias; for source in concat order, ky, kx, ci:
+// acc = fmaf(x, w, acc).  The MFMA k-loop below walks exactly that order; out-of-image taps
+// and channel padding contribute fmaf(0, w, acc) = acc.  No split-K, no atomics: results do
+// not depend on batch size, grid shape or device.
+//
+// Tiling: workgroup = 4 waves = 16x16 output pixels (256 GEMM rows) x NT*16 output columns;
+// each wave owns 64 rows x NT*16 columns = 4 x NT MFMA tiles (acc in registers).  K is
+// walked in chunks of 16 input channels of one (source, tap): A chunk 256x16 and B chunk
+// 16x(NT*16) are prefetched into registers while the previous chunk is multiplied out of LDS.
+// LDS row strides (18 / NT*16[+16] floats) make every ds_read_b32 of a fragment conflict free.
+// ~23.5 KB LDS and ~110 VGPRs per workgroup => 4 workgroups per CU hide the two barriers per
+// chunk behind each other's MFMAs.
+#include <algorithm>
+
+#include "tz_internal.h"
+#include "tz_math.hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { EPI_RAW = 0, EPI_RELU = 1, EPI_LSTM = 2, EPI_LSTM_PACKED = 3, EPI_POOL_ERR = 4 };
+
+struct ConvSrc {
+    const float* p;
+    long long nstride;  // elements between batch items (0 = broadcast constant)
+    int C;              // channels
+    int up;             // 1: stored at half resolution, nearest x2 on read (prednet.py:264)
+    int cpt;            // chunks per tap = ceil(C/16)
+    int chunk_base;     // first chunk index of this source
+};
+
+struct ConvArgs {
+    ConvSrc src[2];
+    int nsrc, nchunks;
+    int H, W, tiles_x, tiles_y, ncb;
+    const float* Wp;    // [nchunks*16][ncols]
+    int ncols;
+    const float* bias;  // [ncols]
+    const float* init;  // [H*W][ncols] accumulator start (G0), or null -> bias
+    int Cout;
+    const float* aux;   // LSTM: previous cell state [H*W][R] or null; POOL_ERR: Ahat(t0) of level l+1
+    float* out0;
+    long long out0_nstride;
+    float* out1;        // LSTM: cell state out (or null)
+    long long out1_nstride;
+    const int* out_idx; // optional: frame slot of batch item n in out0
+    int clip1;          // EPI_RELU: min(.,1)  (prednet.py:270)
+    int R;              // EPI_LSTM_PACKED: channels per gate
+};
+
+static constexpr int SA = 18;  // LDS row stride of the A chunk (floats)
+
+template <bool POOL>
+__device__ __forceinline__ void row_to_patch(int m, int& py, int& px) {
+    int w = m >> 6, mt = (m >> 4) & 3, r16 = m & 15;
+    if (POOL) {  // the 4 accumulator registers of a lane form one 2x2 pooling window
+        py = 4 * w + 2 * (mt >> 1) + ((r16 & 3) >> 1);
+        px = 8 * (mt & 1) + 2 * (r16 >> 2) + (r16 & 1);
+    } else {
+        py = 4 * w + mt;
+        px = r16;
+    }
+}
+
+template <int NT, int EPI>
+__global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvArgs a) {
+    constexpr bool POOL = EPI == EPI_POOL_ERR;
+    constexpr int NTC = NT * 16;
+    constexpr int SB = NTC + ((NTC % 32) == 0 ? 16 : 0);
+    constexpr int BVEC = 16 * NTC / 4;  // float4 loads for one B chunk
+    __shared__ float sA[256 * SA];
+    __shared__ float sB[16 * SB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int bid = blockIdx.x;
+    const int cb = bid % a.ncb;
+    bid /= a.ncb;
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int tile = bid % ntiles, n = bid / ntiles;
+    const int ty0 = (tile / a.tiles_x) * 16, tx0 = (tile % a.tiles_x) * 16;
+
+    // ---- staging roles: A: 4 rows per thread (row = (tid>>2) + 64 j), channel quad tid&3
+    const int q = tid & 3;
+    int gy[4], gx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int py, px;
+        row_to_patch<POOL>((tid >> 2) + 64 * j, py, px);
+        gy[j] = ty0 + py;
+        gx[j] = tx0 + px;
+    }
+    const int b_row = NT == 4 ? (tid >> 4) : (NT == 3 ? tid / 12 : (tid >> 2));
+    const int b_quad = NT == 4 ? (tid & 15) : (NT == 3 ? tid % 12 : (tid & 3));
+    const bool b_active = tid < BVEC;
+
+    float4 ra[4];
+    float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto load_chunk = [&](int chunk) {
+        const ConvSrc& s = (a.nsrc > 1 && chunk >= a.src[1].chunk_base) ? a.src[1] : a.src[0];
+        int local = chunk - s.chunk_base;
+        int tap = local / s.cpt, c0 = (local - tap * s.cpt) * 16 + 4 * q;
+        int ky = tap / 3 - 1, kx = tap % 3 - 1;
+        const float* base = s.p + (long long)n * s.nstride;
+        const int Ws = a.W >> s.up;
+        const bool vec = (s.C & 3) == 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int yy = gy[j] + ky, xx = gx[j] + kx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && c0 < s.C) {
+                const float* ptr = base + ((long long)(yy >> s.up) * Ws + (xx >> s.up)) * s.C + c0;
+                if (vec) {
+                    v = *(const float4*)ptr;
+                } else {
+                    v.x = ptr[0];
+                    if (c0 + 1 < s.C) v.y = ptr[1];
+                    if (c0 + 2 < s.C) v.z = ptr[2];
+                    if (c0 + 3 < s.C) v.w = ptr[3];
+                }
+            }
+            ra[j] = v;
+        }
+        if (b_active) rb = *(const float4*)(a.Wp + ((long long)chunk * 16 + b_row) * a.ncols + cb * NTC + 4 * b_quad);
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* d = sA + ((tid >> 2) + 64 * j) * SA + 4 * q;
+            *(float2*)d = make_float2(ra[j].x, ra[j].y);
+            *(float2*)(d + 2) = make_float2(ra[j].z, ra[j].w);
+        }
+        if (b_active) *(float4*)(sB + b_row * SB + 4 * b_quad) = rb;
+    };
+
+    // ---- accumulators: acc[mt][nt], element r <-> GEMM row (lane>>4)*4 + r, column lane&15
+    f32x4 acc[4][NT];
+    const int col0 = cb * NTC + (lane & 15);
+    int oy[4][4], ox[4][4];  // pixel of (mt, r) for this lane
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int py, px;
+            row_to_patch<POOL>(wv * 64 + mt * 16 + (lane >> 4) * 4 + r, py, px);
+            oy[mt][r] = ty0 + py;
+            ox[mt][r] = tx0 + px;
+        }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (a.init) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bool ok = oy[mt][r] < a.H && ox[mt][r] < a.W;
+                    acc[mt][nt][r] =
+                        ok ? a.init[((long long)oy[mt][r] * a.W + ox[mt][r]) * a.ncols + col0 + nt * 16] : 0.0f;
+                }
+            } else {
+                float b = a.bias[col0 + nt * 16];
+                acc[mt][nt] = (f32x4){b, b, b, b};
+            }
+        }
+
+    // ---- K loop
+    if (a.nchunks > 0) {
+        load_chunk(0);
+        store_chunk();
+        __syncthreads();
+        const float* pa = sA + (wv * 64 + (lane & 15)) * SA + (lane >> 4);
+        const float* pb = sB + (lane >> 4) * SB + (lane & 15);
+        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+            const bool more = chunk + 1 < a.nchunks;
+            if (more) load_chunk(chunk + 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float fa[4], fb[NT];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) fa[mt] = pa[mt * 16 * SA + 4 * kk];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fb[nt] = pb[4 * kk * SB + nt * 16];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                store_chunk();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogues
+    const int j = lane & 15;
+    if (EPI == EPI_RAW) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (oy[mt][r] >= a.H || ox[mt][r] >= a.W) continue;
+                long long pix = (long long)oy[mt][r] * a.W + ox[mt][r];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a.out0[pix * a.ncols + col0 + nt * 16] = acc[mt][nt][r];
+            }
+    } else if (EPI == EPI_RELU) {
+        float* o = a.out0 + (long long)(a.out_idx ? a.out_idx[n] : n) * a.out0_nstride;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (oy[mt][r] >= a.H || ox[mt][r] >= a.W) continue;
+                long long pix = (long long)oy[mt][r] * a.W + ox[mt][r];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    int ch = col0 + nt * 16;
+                    if (ch < a.Cout) {
+                        float v = tz_relu(acc[mt][nt][r]);
+                        if (a.clip1 && v > 1.0f) v = 1.0f;
+                        o[pix * a.Cout + ch] = v;
+                    }
+                }
+            }
+    } else if (EPI == EPI_LSTM) {
+        // columns of this block: [i | f | g | o] x 16 channels of channel group cb
+        // prednet.py:255-259: c = f*c_prev + i*g ; r = o*tanh(c)
+        const int ch = cb * 16 + j, R = a.Cout;
+        float* o0 = a.out0 + (long long)n * a.out0_nstride;
+        float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (oy[mt][r] >= a.H || ox[mt][r] >= a.W) continue;
+                long long pix = (long long)oy[mt][r] * a.W + ox[mt][r];
+                float gi = tz_hard_sigmoid(acc[mt][0 % NT][r]);
+                float gf = tz_hard_sigmoid(acc[mt][1 % NT][r]);
+                float gg = tz_tanh(acc[mt][2 % NT][r]);
+                float go = tz_hard_sigmoid(acc[mt][3 % NT][r]);
+                float cp = a.aux ? a.aux[pix * R + ch] : 0.0f;
+                float t1 = gf * cp;
+                float t2 = gi * gg;
+                float c = t1 + t2;
+                float rr = go * tz_tanh(c);
+                o0[pix * R + ch] = rr;
+                if (o1) o1[pix * R + ch] = c;
+            }
+    } else if (EPI == EPI_LSTM_PACKED) {
+        // one 16-column tile holds [i(R) f(R) g(R) o(R)], R <= 4: gather the 4 gates by shuffle
+        const int R = a.R;
+        float* o0 = a.out0 + (long long)n * a.out0_nstride;
+        float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
+        const int lbase = lane & 48;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[mt][0][r];
+                float vi = __shfl(v, lbase + (j % 4), 64);
+                float vf = __shfl(v, lbase + ((j % 4) + R) % 16, 64);
+                float vg = __shfl(v, lbase + ((j % 4) + 2 * R) % 16, 64);
+                float vo = __shfl(v, lbase + ((j % 4) + 3 * R) % 16, 64);
+                if (j >= R || oy[mt][r] >= a.H || ox[mt][r] >= a.W) continue;
+                long long pix = (long long)oy[mt][r] * a.W + ox[mt][r];
+                float gi = tz_hard_sigmoid(vi), gf = tz_hard_sigmoid(vf), gg = tz_tanh(vg), go = tz_hard_sigmoid(vo);
+                float cp = a.aux ? a.aux[pix * R + j] : 0.0f;
+                float t1 = gf * cp;
+                float t2 = gi * gg;
+                float c = t1 + t2;
+                float rr = go * tz_tanh(c);
+                o0[pix * R + j] = rr;
+                if (o1) o1[pix * R + j] = c;
+            }
+    } else if (EPI == EPI_POOL_ERR) {
+        // prednet.py:289-291 then 274-277 of the next level: A = maxpool2x2(relu(conv));
+        // e = [relu(Ahat0 - A), relu(A - Ahat0)] written at the pooled resolution.
+        const int H2 = a.H >> 1, W2 = a.W >> 1, C = a.Cout;
+        float* o = a.out0 + (long long)n * a.out0_nstride;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            int yp = oy[mt][0] >> 1, xp = ox[mt][0] >> 1;
+            if (yp >= H2 || xp >= W2) continue;
+            long long pp = (long long)yp * W2 + xp;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                int ch = col0 + nt * 16;
+                if (ch >= C) continue;
+                float m = tz_relu(acc[mt][nt][0]);
+#pragma unroll
+                for (int r = 1; r < 4; ++r) {
+                    float t = tz_relu(acc[mt][nt][r]);
+                    if (t > m) m = t;
+                }
+                float h = a.aux[pp * C + ch];
+                float d1 = h - m, d2 = m - h;
+                o[pp * 2 * C + ch] = tz_relu(d1);
+                o[pp * 2 * C + C + ch] = tz_relu(d2);
+            }
+        }
+    }
+}
+
+// level-0 error unit (prednet.py:274-277 with a = input frame, Ahat = Ahat_0(t0)):
+// input is either a key frame (uint8, unpadded; x = float32(k)/255, compress.py:138) or a
+// padded float32 frame of the prediction stack (compress.py:222).
+__global__ __launch_bounds__(256) void k_err0(const uint8_t* __restrict__ frames_u8, int H, int W,
+                                              const float* __restrict__ in_stack, const int* __restrict__ is_key,
+                                              const int* __restrict__ in_idx, const float* __restrict__ ahat0, int Hp,
+                                              int Wp, int C, float* __restrict__ e0) {
+    int n = blockIdx.y;
+    long long npx = (long long)Hp * Wp;
+    const bool key = is_key[n] != 0;
+    const long long fi = in_idx[n];
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (long long)gridDim.x * blockDim.x) {
+        int y = (int)(p / Wp), x = (int)(p - (long long)y * Wp);
+        for (int c = 0; c < C; ++c) {
+            float av;
+            if (key) {
+                av = 0.0f;
+                if (y < H && x < W) av = (float)frames_u8[(fi * H * W + (long long)y * W + x) * C + c] / 255.0f;
+            } else {
+                av = in_stack[(fi * npx + p) * C + c];
+            }
+            float h = ahat0[p * C + c];
+            float d1 = h - av, d2 = av - h;
+            e0[((long long)n * npx + p) * 2 * C + c] = tz_relu(d1);
+            e0[((long long)n * npx + p) * 2 * C + C + c] = tz_relu(d2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- host side
+struct Seg {
+    int row_off, C;
+};
+struct PackedConv {
+    float* d_W = nullptr;
+    float* d_bias = nullptr;
+    int nchunks = 0, ncols = 0, NT = 1, ncb = 1;
+    std::vector<Seg> segs;
+};
+
+struct tz_model {
+    int L = 0;
+    int stack[TZ_MAX_LEVELS] = {0}, rstack[TZ_MAX_LEVELS] = {0};
+    std::vector<std::vector<float>> w;  // Keras list order
+    int Hp = 0, Wp = 0, maxB = 0;
+    bool prepared = false;
+    float *R0[TZ_MAX_LEVELS] = {0}, *C0[TZ_MAX_LEVELS] = {0}, *Ahat0[TZ_MAX_LEVELS] = {0}, *G0[TZ_MAX_LEVELS] = {0};
+    float *E[TZ_MAX_LEVELS] = {0}, *R1[TZ_MAX_LEVELS] = {0};
+    PackedConv a_conv[TZ_MAX_LEVELS], gate_t1[TZ_MAX_LEVELS], ahat0_t1;
+    int* d_idx = nullptr;  // 3*maxB ints: is_key, in_idx, out_idx
+    std::vector<void*> allocs;
+    // weight list accessors
+    const float* a_k(int l) const { return w[2 * l].data(); }
+    const float* a_b(int l) const { return w[2 * l + 1].data(); }
+    const float* ahat_k(int l) const { return w[2 * (L - 1) + 2 * l].data(); }
+    const float* ahat_b(int l) const { return w[2 * (L - 1) + 2 * l + 1].data(); }
+    // gate g in our order 0=i 1=f 2=c 3=o ; list order is c, f, i, o (prednet.py:212)
+    int gate_base(int g) const {
+        static const int pos[4] = {2, 1, 0, 3};
+        return 2 * (L - 1) + 2 * L + pos[g] * 2 * L;
+    }
+    const float* g_k(int g, int l) const { return w[gate_base(g) + 2 * l].data(); }
+    const float* g_b(int g, int l) const { return w[gate_base(g) + 2 * l + 1].data(); }
+    int gate_cin(int l) const { return rstack[l] + 2 * stack[l] + (l < L - 1 ? rstack[l + 1] : 0); }
+};
+
+static int dmalloc(tz_ctx* ctx, tz_model* m, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return tz_fail(ctx, TZ_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    m->allocs.push_back(*p);
+    return TZ_OK;
+}
+
+struct ColSrc {
+    const float* kernel;  // HWIO (3,3,Cin,Cout)
+    const float* bias;
+    int Cin, Cout, ch;    // ch < 0: zero padding column
+};
+
+// Pack weights into the chunk order walked by k_conv3x3: for seg, tap, 16-channel chunk.
+static int pack_conv(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, const std::vector<ColSrc>& cols, int NT,
+                     PackedConv* pc) {
+    int ncols = (int)cols.size();
+    int nchunks = 0;
+    for (auto& s : segs) nchunks += 9 * ((s.C + 15) / 16);
+    std::vector<float> W((size_t)std::max(nchunks, 1) * 16 * ncols, 0.0f), B(ncols, 0.0f);
+    int chunk = 0;
+    for (auto& s : segs)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int c0 = 0; c0 < s.C; c0 += 16, ++chunk)
+                for (int kc = 0; kc < 16 && c0 + kc < s.C; ++kc)
+                    for (int col = 0; col < ncols; ++col) {
+                        const ColSrc& cs = cols[col];
+                        if (cs.ch < 0) continue;
+                        W[((size_t)chunk * 16 + kc) * ncols + col] =
+                            cs.kernel[((size_t)tap * cs.Cin + s.row_off + c0 + kc) * cs.Cout + cs.ch];
+                    }
+    for (int col = 0; col < ncols; ++col)
+        if (cols[col].ch >= 0) B[col] = cols[col].bias[cols[col].ch];
+    pc->nchunks = nchunks;
+    pc->ncols = ncols;
+    pc->NT = NT;
+    pc->ncb = ncols / (16 * NT);
+    pc->segs = segs;
+    TZ_TRY(dmalloc(ctx, m, (void**)&pc->d_W, W.size() * 4));
+    TZ_TRY(dmalloc(ctx, m, (void**)&pc->d_bias, B.size() * 4));
+    TZ_HIP(ctx, hipMemcpy(pc->d_W, W.data(), W.size() * 4, hipMemcpyHostToDevice));
+    TZ_HIP(ctx, hipMemcpy(pc->d_bias, B.data(), B.size() * 4, hipMemcpyHostToDevice));
+    return TZ_OK;
+}
+
+static int plain_nt(int Cout) {
+    if (Cout % 64 == 0) return 4;
+    if (Cout % 48 == 0) return 3;
+    return 1;
+}
+
+static std::vector<ColSrc> plain_cols(const float* k, const float* b, int Cin, int Cout) {
+    int ncols = ((Cout + 15) / 16) * 16;
+    std::vector<ColSrc> cols(ncols);
+    for (int c = 0; c < ncols; ++c) cols[c] = ColSrc{k, b, Cin, Cout, c < Cout ? c : -1};
+    return cols;
+}
+
+// packed gate columns: R%16==0 -> [cg][gate][16]; R<=4 -> [gate][R] in one 16-wide tile
+static int gate_cols(tz_ctx* ctx, const tz_model* m, int l, std::vector<ColSrc>* cols, int* NT) {
+    int R = m->rstack[l], Cin = m->gate_cin(l);
+    if (R % 16 == 0) {
+        cols->resize((size_t)4 * R);
+        for (int cg = 0; cg < R / 16; ++cg)
+            for (int g = 0; g < 4; ++g)
+                for (int j = 0; j < 16; ++j)
+                    (*cols)[cg * 64 + g * 16 + j] = ColSrc{m->g_k(g, l), m->g_b(g, l), Cin, R, cg * 16 + j};
+        *NT = 4;
+        return TZ_OK;
+    }
+    if (R <= 4) {
+        cols->assign(16, ColSrc{nullptr, nullptr, 0, 0, -1});
+        for (int g = 0; g < 4; ++g)
+            for (int c = 0; c < R; ++c) (*cols)[g * R + c] = ColSrc{m->g_k(g, l), m->g_b(g, l), Cin, R, c};
+        *NT = 1;
+        return TZ_OK;
+    }
+    return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "R_stack_sizes[%d]=%d: need a multiple of 16 or <= 4", l, R);
+}
+
+template <int NT, int EPI>
+static void launch_conv_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
+    int blocks = a.ncb * a.tiles_x * a.tiles_y * nbatch;
+    hipLaunchKernelGGL((k_conv3x3<NT, EPI>), dim3(blocks), dim3(256), 0, ctx->stream, a);
+}
+
+static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbatch) {
+    tz_prof_scope ps(ctx, TZP_CONV);
+#define TZ_CASE(nt, e)                   \
+    if (NT == nt && epi == e) {          \
+        launch_conv_t<nt, e>(ctx, a, nbatch); \
+        TZ_HIP(ctx, hipGetLastError());  \
+        return TZ_OK;                    \
+    }
+    TZ_CASE(1, EPI_RAW) TZ_CASE(4, EPI_RAW)
+    TZ_CASE(1, EPI_RELU) TZ_CASE(3, EPI_RELU) TZ_CASE(4, EPI_RELU)
+    TZ_CASE(4, EPI_LSTM) TZ_CASE(1, EPI_LSTM_PACKED)
+    TZ_CASE(1, EPI_POOL_ERR) TZ_CASE(3, EPI_POOL_ERR) TZ_CASE(4, EPI_POOL_ERR)
+#undef TZ_CASE
+    return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "no conv kernel for NT=%d epilogue=%d", NT, epi);
+}
+
+static void fill_srcs(ConvArgs& a, const PackedConv& pc, const float* const* ptrs, const long long* nstrides,
+                      const int* ups) {
+    a.nsrc = (int)pc.segs.size();
+    int base = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+        a.src[s].p = ptrs[s];
+        a.src[s].nstride = nstrides[s];
+        a.src[s].C = pc.segs[s].C;
+        a.src[s].up = ups[s];
+        a.src[s].cpt = (pc.segs[s].C + 15) / 16;
+        a.src[s].chunk_base = base;
+        base += 9 * a.src[s].cpt;
+    }
+    a.nchunks = pc.nchunks;
+    a.Wp = pc.d_W;
+    a.bias = pc.d_bias;
+    a.ncols = pc.ncols;
+    a.ncb = pc.ncb;
+}
+
+static void set_geom(ConvArgs& a, int H, int W) {
+    a.H = H;
+    a.W = W;
+    a.tiles_x = (W + 15) / 16;
+    a.tiles_y = (H + 15) / 16;
+}
+
+void tz_model_free(tz_ctx* ctx) {
+    tz_model* m = ctx->model;
+    if (!m) return;
+    for (void* p : m->allocs) (void)hipFree(p);
+    delete m;
+    ctx->model = nullptr;
+}
+
+extern "C" int tz_model_load(tz_ctx* ctx, int nb_layers, const int* stack_sizes, const int* r_stack_sizes,
+                             const float* const* weights) {
+    if (!ctx) return TZ_ERR_INVALID;
+    if (nb_layers < 1 || nb_layers > TZ_MAX_LEVELS || !stack_sizes || !r_stack_sizes || !weights)
+        return tz_fail(ctx, TZ_ERR_INVALID, "bad model description");
+    if (stack_sizes[0] != 3) return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "stack_sizes[0] must be 3 (RGB frames, compress.py:114)");
+    tz_model_free(ctx);
+    tz_model* m = new tz_model();
+    ctx->model = m;
+    m->L = nb_layers;
+    for (int l = 0; l < nb_layers; ++l) {
+        m->stack[l] = stack_sizes[l];
+        m->rstack[l] = r_stack_sizes[l];
+        if (stack_sizes[l] < 1 || r_stack_sizes[l] < 1) return tz_fail(ctx, TZ_ERR_INVALID, "bad channel count");
+        if (l > 0 && stack_sizes[l] % 16) return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "stack_sizes[%d] must be a multiple of 16", l);
+        if (!(r_stack_sizes[l] % 16 == 0 || r_stack_sizes[l] <= 4))
+            return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "R_stack_sizes[%d] must be a multiple of 16 or <= 4", l);
+    }
+    const int L = nb_layers;
+    int k = 0;
+    auto take = [&](size_t count) {
+        m->w.emplace_back(weights[k], weights[k] + count);
+        ++k;
+    };
+    for (int l = 0; l < L - 1; ++l) {  // a
+        take((size_t)9 * 2 * m->stack[l] * m->stack[l + 1]);
+        take(m->stack[l + 1]);
+    }
+    for (int l = 0; l < L; ++l) {  // ahat
+        take((size_t)9 * m->rstack[l] * m->stack[l]);
+        take(m->stack[l]);
+    }
+    for (int g = 0; g < 4; ++g)  // c, f, i, o
+        for (int l = 0; l < L; ++l) {
+            take((size_t)9 * m->gate_cin(l) * m->rstack[l]);
+            take(m->rstack[l]);
+        }
+    return TZ_OK;
+}
+
+extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
+    if (!ctx) return TZ_ERR_INVALID;
+    tz_model* m = ctx->model;
+    if (!m) return tz_fail(ctx, TZ_ERR_STATE, "tz_model_prepare before tz_model_load");
+    const int L = m->L;
+    if (Hp <= 0 || Wp <= 0 || max_batch < 1) return tz_fail(ctx, TZ_ERR_INVALID, "bad prepare arguments");
+    if ((Hp % (1 << (L - 1))) || (Wp % (1 << (L - 1))) || (Hp % 8) || (Wp % 8))
+        return tz_fail(ctx, TZ_ERR_INVALID,
+                       "Image size is out of scope for this model: padded size %dx%d must divide by 8 and 2^(levels-1)", Hp, Wp);
+    if (m->prepared && m->Hp == Hp && m->Wp == Wp && m->maxB >= max_batch) return TZ_OK;
+    // rebuild from the kept host weights
+    {
+        std::vector<std::vector<float>> w = std::move(m->w);
+        int st[TZ_MAX_LEVELS], rs[TZ_MAX_LEVELS];
+        for (int l = 0; l < L; ++l) { st[l] = m->stack[l]; rs[l] = m->rstack[l]; }
+        tz_model_free(ctx);
+        m = new tz_model();
+        ctx->model = m;
+        m->L = L;
+        for (int l = 0; l < L; ++l) { m->stack[l] = st[l]; m->rstack[l] = rs[l]; }
+        m->w = std::move(w);
+    }
+    m->Hp = Hp;
+    m->Wp = Wp;
+    m->maxB = max_batch;
+    auto hl = [&](int l) { return Hp >> l; };
+    auto wl = [&](int l) { return Wp >> l; };
+    for (int l = 0; l < L; ++l) {
+        size_t npx = (size_t)hl(l) * wl(l);
+        int R = m->rstack[l];
+        TZ_TRY(dmalloc(ctx, m, (void**)&m->R0[l], npx * R * 4));
+        TZ_TRY(dmalloc(ctx, m, (void**)&m->C0[l], npx * R * 4));
+        TZ_TRY(dmalloc(ctx, m, (void**)&m->Ahat0[l], npx * m->stack[l] * 4));
+        TZ_TRY(dmalloc(ctx, m, (void**)&m->E[l], (size_t)max_batch * npx * 2 * m->stack[l] * 4));
+        TZ_TRY(dmalloc(ctx, m, (void**)&m->R1[l], (size_t)max_batch * npx * R * 4));
+    }
+    TZ_TRY(dmalloc(ctx, m, (void**)&m->d_idx, sizeof(int) * 3 * max_batch));
+
+    // ---- t=0 top-down from zero state (prednet.py:143-190, 249-264): only r_up is non-zero
+    for (int l = L - 1; l >= 0; --l) {
+        std::vector<ColSrc> cols;
+        int NT;
+        TZ_TRY(gate_cols(ctx, m, l, &cols, &NT));
+        std::vector<Seg> segs;
+        if (l < L - 1) segs.push_back(Seg{m->rstack[l] + 2 * m->stack[l], m->rstack[l + 1]});
+        PackedConv pc;
+        TZ_TRY(pack_conv(ctx, m, segs, cols, NT, &pc));
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        const float* ptrs[2] = {l < L - 1 ? m->R0[l + 1] : nullptr, nullptr};
+        long long ns[2] = {0, 0};
+        int ups[2] = {1, 0};
+        fill_srcs(a, pc, ptrs, ns, ups);
+        set_geom(a, hl(l), wl(l));
+        a.Cout = m->rstack[l];
+        a.R = m->rstack[l];
+        a.out0 = m->R0[l];
+        a.out1 = m->C0[l];
+        TZ_TRY(launch_conv(ctx, NT, NT == 4 ? EPI_LSTM : EPI_LSTM_PACKED, a, 1));
+    }
+    // ---- Ahat_l at t=0 (prednet.py:268-271)
+    for (int l = 0; l < L; ++l) {
+        int Cout = m->stack[l], NT = plain_nt(Cout);
+        PackedConv pc;
+        TZ_TRY(pack_conv(ctx, m, {Seg{0, m->rstack[l]}}, plain_cols(m->ahat_k(l), m->ahat_b(l), m->rstack[l], Cout), NT, &pc));
+        if (l == 0) m->ahat0_t1 = pc;
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        const float* ptrs[2] = {m->R0[l], nullptr};
+        long long ns[2] = {0, 0};
+        int ups[2] = {0, 0};
+        fill_srcs(a, pc, ptrs, ns, ups);
+        set_geom(a, hl(l), wl(l));
+        a.Cout = Cout;
+        a.out0 = m->Ahat0[l];
+        a.clip1 = l == 0;
+        TZ_TRY(launch_conv(ctx, NT, EPI_RELU, a, 1));
+    }
+    // ---- G0_l = bias + conv over the r_tm1 rows of the t=1 gate convolution, and the t=1 packs
+    for (int l = 0; l < L; ++l) {
+        std::vector<ColSrc> cols;
+        int NT;
+        TZ_TRY(gate_cols(ctx, m, l, &cols, &NT));
+        PackedConv pg;
+        TZ_TRY(pack_conv(ctx, m, {Seg{0, m->rstack[l]}}, cols, NT, &pg));
+        size_t npx = (size_t)hl(l) * wl(l);
+        TZ_TRY(dmalloc(ctx, m, (void**)&m->G0[l], npx * pg.ncols * 4));
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        const float* ptrs[2] = {m->R0[l], nullptr};
+        long long ns[2] = {0, 0};
+        int ups[2] = {0, 0};
+        fill_srcs(a, pg, ptrs, ns, ups);
+        set_geom(a, hl(l), wl(l));
+        a.out0 = m->G0[l];
+        TZ_TRY(launch_conv(ctx, NT, EPI_RAW, a, 1));
+        std::vector<Seg> segs = {Seg{m->rstack[l], 2 * m->stack[l]}};
+        if (l < L - 1) segs.push_back(Seg{m->rstack[l] + 2 * m->stack[l], m->rstack[l + 1]});
+        TZ_TRY(pack_conv(ctx, m, segs, cols, NT, &m->gate_t1[l]));
+    }
+    // ---- A convs (prednet.py:290)
+    for (int l = 0; l < L - 1; ++l) {
+        int Cout = m->stack[l + 1], NT = plain_nt(Cout);
+        TZ_TRY(pack_conv(ctx, m, {Seg{0, 2 * m->stack[l]}}, plain_cols(m->a_k(l), m->a_b(l), 2 * m->stack[l], Cout), NT,
+                         &m->a_conv[l]));
+    }
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m->prepared = true;
+    return TZ_OK;
+}
+
+int tz_model_dims(tz_ctx* ctx, int* Hp, int* Wp, int* max_batch) {
+    tz_model* m = ctx->model;
+    if (!m || !m->prepared) return tz_fail(ctx, TZ_ERR_STATE, "model not prepared");
+    *Hp = m->Hp;
+    *Wp = m->Wp;
+    *max_batch = m->maxB;
+    return TZ_OK;
+}
+
+int tz_model_c0_dev(tz_ctx* ctx, const float** c0) {
+    tz_model* m = ctx->model;
+    if (!m || !m->prepared) return tz_fail(ctx, TZ_ERR_STATE, "model not prepared");
+    *c0 = m->Ahat0[0];
+    return TZ_OK;
+}
+
+// One predictor step for n <= maxB independent frames (the `predict` seam, compress.py:227).
+// Input n: key frame h_in_idx[n] of d_frames_u8 (h_in_is_key) or padded f32 frame
+// h_in_idx[n] of d_in_stack; output goes to frame slot h_out_idx[n] of d_out_stack.
+int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int* h_in_idx, const int* h_out_idx,
+                           const uint8_t* d_frames_u8, int H, int W, const float* d_in_stack, float* d_out_stack) {
+    tz_model* m = ctx->model;
+    if (!m || !m->prepared) return tz_fail(ctx, TZ_ERR_STATE, "model not prepared");
+    if (n < 1 || n > m->maxB) return tz_fail(ctx, TZ_ERR_INVALID, "batch %d outside 1..%d", n, m->maxB);
+    const int L = m->L, Hp = m->Hp, Wp = m->Wp;
+    std::vector<int> idx(3 * (size_t)m->maxB, 0);
+    for (int i = 0; i < n; ++i) {
+        idx[i] = h_in_is_key[i];
+        idx[m->maxB + i] = h_in_idx[i];
+        idx[2 * m->maxB + i] = h_out_idx[i];
+    }
+    TZ_HIP(ctx, hipMemcpyAsync(m->d_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice, ctx->stream));
+    auto hl = [&](int l) { return Hp >> l; };
+    auto wl = [&](int l) { return Wp >> l; };
+    auto npx = [&](int l) { return (long long)hl(l) * wl(l); };
+    {
+        tz_prof_scope ps(ctx, TZP_ERR0);
+        int gx = (int)std::min<long long>((npx(0) + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_err0, dim3(gx, n), dim3(256), 0, ctx->stream, d_frames_u8, H, W, d_in_stack, m->d_idx,
+                           m->d_idx + m->maxB, m->Ahat0[0], Hp, Wp, m->stack[0], m->E[0]);
+        TZ_HIP(ctx, hipGetLastError());
+    }
+    for (int l = 0; l < L - 1; ++l) {  // t0 bottom-up
+        const PackedConv& pc = m->a_conv[l];
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        const float* ptrs[2] = {m->E[l], nullptr};
+        long long ns[2] = {npx(l) * 2 * m->stack[l], 0};
+        int ups[2] = {0, 0};
+        fill_srcs(a, pc, ptrs, ns, ups);
+        set_geom(a, hl(l), wl(l));
+        a.Cout = m->stack[l + 1];
+        a.aux = m->Ahat0[l + 1];
+        a.out0 = m->E[l + 1];
+        a.out0_nstride = npx(l + 1) * 2 * m->stack[l + 1];
+        TZ_TRY(launch_conv(ctx, pc.NT, EPI_POOL_ERR, a, n));
+    }
+    for (int l = L - 1; l >= 0; --l) {  // t1 top-down
+        const PackedConv& pc = m->gate_t1[l];
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        const float* ptrs[2] = {m->E[l], l < L - 1 ? m->R1[l + 1] : nullptr};
+        long long ns[2] = {npx(l) * 2 * m->stack[l], l < L - 1 ? npx(l + 1) * m->rstack[l + 1] : 0};
+        int ups[2] = {0, 1};
+        fill_srcs(a, pc, ptrs, ns, ups);
+        set_geom(a, hl(l), wl(l));
+        a.init = m->G0[l];
+        a.Cout = m->rstack[l];
+        a.R = m->rstack[l];
+        a.aux = m->C0[l];
+        a.out0 = m->R1[l];
+        a.out0_nstride = npx(l) * m->rstack[l];
+        TZ_TRY(launch_conv(ctx, pc.NT, pc.NT == 4 ? EPI_LSTM : EPI_LSTM_PACKED, a, n));
+    }
+    {  // Ahat_0 at t1 = the prediction (prednet.py:268-271, 293-295)
+        const PackedConv& pc = m->ahat0_t1;
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        const float* ptrs[2] = {m->R1[0], nullptr};
+        long long ns[2] = {npx(0) * m->rstack[0], 0};
+        int ups[2] = {0, 0};
+        fill_srcs(a, pc, ptrs, ns, ups);
+        set_geom(a, Hp, Wp);
+        a.Cout = m->stack[0];
+        a.out0 = d_out_stack;
+        a.out0_nstride = npx(0) * m->stack[0];
+        a.out_idx = m->d_idx + 2 * m->maxB;
+        a.clip1 = 1;
+        TZ_TRY(launch_conv(ctx, pc.NT, EPI_RELU, a, n));
+    }
+    return TZ_OK;
+}
+
+extern "C" int tz_predict_c0(tz_ctx* ctx, float* out) {
+    if (!ctx || !out) return TZ_ERR_INVALID;
+    const float* c0;
+    TZ_TRY(tz_model_c0_dev(ctx, &c0));
+    tz_model* m = ctx->model;
+    size_t bytes = (size_t)m->Hp * m->Wp * m->stack[0] * 4;
+    TZ_HIP(ctx, hipMemcpyAsync(out, c0, bytes, hipMemcpyDefault, ctx->stream));
+    if (!tz_is_device_ptr(out)) TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TZ_OK;
+}
+
+extern "C" int tz_predict_next(tz_ctx* ctx, const float* frames, int n, float* out) {
+    if (!ctx || !frames || !out || n < 0) return TZ_ERR_INVALID;
+    tz_model* m = ctx->model;
+    if (!m || !m->prepared) return tz_fail(ctx, TZ_ERR_STATE, "model not prepared");
+    size_t fe = (size_t)m->Hp * m->Wp * m->stack[0];
+    const void* din;
+    tz_out o;
+    std::vector<tz_out> outs;
+    int rc = tz_dev_in(ctx, frames, fe * n * 4, &din);
+    if (rc == TZ_OK) rc = tz_dev_out(ctx, out, fe * n * 4, &o);
+    if (rc == TZ_OK) {
+        outs.push_back(o);
+        for (int b0 = 0; b0 < n && rc == TZ_OK; b0 += m->maxB) {
+            int nb = std::min(m->maxB, n - b0);
+            std::vector<int> isk(nb, 0), ii(nb), oi(nb);
+            for (int i = 0; i < nb; ++i) ii[i] = oi[i] = b0 + i;
+            rc = tz_model_predict_batch(ctx, nb, isk.data(), ii.data(), oi.data(), nullptr, 0, 0, (const float*)din,
+                                        (float*)o.dev);
+        }
+    }
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+extern "C" int tz_predict_tap(tz_ctx* ctx, int kind, int level, float* out) {
+    if (!ctx || !out) return TZ_ERR_INVALID;
+    tz_model* m = ctx->model;
+    if (!m || !m->prepared) return tz_fail(ctx, TZ_ERR_STATE, "model not prepared");
+    if (level < 0 || level >= m->L || kind < 0 || kind > 1) return tz_fail(ctx, TZ_ERR_INVALID, "bad tap");
+    size_t npx = (size_t)(m->Hp >> level) * (m->Wp >> level);
+    const float* src = kind == 0 ? m->E[level] : m->R1[level];
+    size_t bytes = npx * (kind == 0 ? 2 * m->stack[level] : m->rstack[level]) * 4;
+    TZ_HIP(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDefault, ctx->stream));
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TZ_OK;
+}
