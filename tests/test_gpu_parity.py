@@ -56,13 +56,13 @@ def test_delta_encode(ctx, h, w):
                                         ("pwrel", [1.0])])
 def test_error_bound(ctx, mode, bound):
     rng = np.random.default_rng(2)
-    n, h, w = 4, 37, 53  # chains longer than one staged chunk (1024 px) and one fill block (2048 px)
+    n, h, w = 4, 45, 61  # chains longer than one staged chunk (1024 px) and one fill block (2048 px)
     orig = _frames(rng, n, h, w)
     noise = rng.integers(-255, 256, (n, h, w, 3))
     smooth = np.clip(np.round(np.cumsum(rng.normal(0, 0.7, (n, h * w, 3)), axis=1)), -255, 255).reshape(n, h, w, 3)
     diff = np.where(np.arange(n)[:, None, None, None] % 2 == 0, noise, smooth).astype(np.int16)
     diff[3] = 0
-    diff[3, 10, 5:9] = [3, -7, 9, 1]
+    diff[3, 10, 5:9, 1] = [3, -7, 9, 1]
     skip = np.array([0, 0, 1, 0], np.uint8)
     got = ctx.error_bound(orig, diff.copy(), mode, bound, skip)
     for i in range(n):
