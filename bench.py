@@ -205,10 +205,24 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(cfg, frames8):
     """The oracle (a C/OpenMP port of the same path; the reference's Keras predictor cannot
     run here) on a bounded sample: one 512x512 window of 1 key + k predicted frames,
     predict + delta, sized to ~15-25 s of CPU work."""
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # read by libgomp when the oracle library loads
     from oracle import coracle
     coracle.build()
     net = coracle.CPredNet(cfg.init_weights(seed=123), cfg.stack_sizes, cfg.R_stack_sizes, H, W)
@@ -224,9 +238,9 @@ def cpu_baseline(cfg, frames8):
         coracle.delta_frame(cur, frames8[2 + i])
     total = time.perf_counter() - t0
     n = 1 + k
-    return {"value": n / total, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": n / total, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d predicted 512x512x3 frames of the same stack (PredNet live work + delta), "
-                      "C oracle with OpenMP on all host cores" % n}
+                      "C oracle with OpenMP on the %d host cores of this job" % (n, cores)}
 
 
 if __name__ == "__main__":

@@ -81,11 +81,9 @@ int tzk_delta(tz_ctx* ctx, const float* pred, const uint8_t* orig, const uint8_t
 // compress.py:23-70, one chain per (frame, channel) over H*W elements, row-major.
 // Stage 1 (k_q_bound): per-chain tolerance E for rel / absrel from max-min of the ORIGINAL
 //                      slab (compress.py:31-33,36-43).
-// Stage 2 (k_q_heads): the greedy interval-intersection segmentation is inherently serial
-//                      per chain: one wave per chain, the wave stages 1024-pixel chunks of
-//                      the interleaved HWC data in LDS with coalesced loads and lane 0 walks
-//                      them, storing the truncated median at each run HEAD into `tmp`
-//                      (pre-filled with a sentinel).
+// Stage 2 (k_q_heads): exact wave-parallel form of the greedy interval-intersection
+//                      segmentation (see the kernel); stores the truncated median of every
+//                      run at its HEAD position of `tmp` (pre-filled with a sentinel).
 // Stage 3 (k_q_last / k_q_carry / k_q_fill): forward-fill the run values (a scan with
 //                      op(a,b) = b unless b is the sentinel) and write them back in place.
 struct QParams {
@@ -141,52 +139,118 @@ __global__ __launch_bounds__(256) void k_q_init(int16_t* __restrict__ tmp, const
         if (!skip[i / frame_elems]) tmp[i] = TZ_SENTINEL;
 }
 
-static constexpr int QCH = 1024;  // pixels per staged chunk
+// Wave-parallel exact greedy segmentation.  One wave per (frame, channel) chain; the chain is
+// walked in chunks of 64 elements (lane i <-> element).  A run started at s breaks at the
+// first i with min(Du[s..i]) < max(Dl[s..i]) (compress.py:60 -- a-b<0 <=> a<b in IEEE), which
+// is monotone in i, so per chunk:
+//   1. range tables T_k[i] = (min Du, max Dl) over [i, i+2^k) by shuffles (k = 0..5),
+//   2. nxt[s] = first break after s for EVERY s (fresh start) by binary lifting over T_k,
+//      together with the run's (u, l) up to the break,
+//   3. inclusive prefix (min Du, max Dl) from the chunk start; the run carried in from earlier
+//      chunks breaks at the first i with min(u, P_u[i]) < max(l, P_l[i])  (ballot),
+//   4. the true heads are the nxt-chain from that break (scalar readlane chase),
+//   5. every head whose run closes inside the chunk stores trunc((u+l)/2) (compress.py:61,
+//      truncation by the int64 store) at the head position of `tmp`; the last head carries on.
+// Nothing here depends on run lengths; elements past the chain end are (+inf, -inf) and can
+// neither break nor tighten a run.
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
 __global__ __launch_bounds__(192) void k_q_heads(const uint8_t* __restrict__ orig, const int16_t* __restrict__ diff,
                                                  const uint8_t* __restrict__ skip, int HW, QParams qp,
                                                  const double* __restrict__ Echain, int16_t* __restrict__ tmp) {
     int f = blockIdx.x;
     if (skip[f]) return;
-    __shared__ int16_t sd[QCH * 3];
-    __shared__ uint8_t so[QCH * 3];
     const int16_t* d = diff + (size_t)f * HW * 3;
     const uint8_t* o = orig + (size_t)f * HW * 3;
     int16_t* t = tmp + (size_t)f * HW * 3;
-    int c = threadIdx.x >> 6;  // wave == channel
-    int lane = threadIdx.x & 63;
+    const int c = threadIdx.x >> 6;  // wave == channel
+    const int lane = threadIdx.x & 63;
     double E = 0.0;
     if (qp.mode == TZ_MODE_ABS) E = fabs(qp.b0);
     else if (qp.mode != TZ_MODE_PWREL) E = Echain[f * 3 + c];
     const double inf = __builtin_huge_val();
-    double u = inf, l = -inf;
-    int head = 0;
-    for (int p0 = 0; p0 < HW; p0 += QCH) {
-        int np = min(QCH, HW - p0);
-        __syncthreads();
-        for (int k = threadIdx.x; k < np * 3; k += 192) {
-            sd[k] = d[(size_t)p0 * 3 + k];
-            so[k] = o[(size_t)p0 * 3 + k];
+    double u = inf, l = -inf;  // state of the run that is open at the chunk boundary
+    int chead = 0;             // its head (chain index)
+    const int nch = (HW + 63) >> 6;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int idx = ch * 64 + lane;
+        double du = inf, dl = -inf;
+        if (idx < HW) {
+            double e = qp.mode == TZ_MODE_PWREL ? (double)o[(size_t)idx * 3 + c] * qp.b0 : E;
+            double df = (double)d[(size_t)idx * 3 + c];
+            du = df + e;
+            dl = df - e;
         }
-        __syncthreads();
-        if (lane == 0) {
-            for (int k = 0; k < np; ++k) {
-                double e = qp.mode == TZ_MODE_PWREL ? (double)so[k * 3 + c] * qp.b0 : E;
-                double df = (double)sd[k * 3 + c];
-                double du = df + e, dl = df - e;
-                double tu = u < du ? u : du, tl = l > dl ? l : dl;
-                if (tu - tl < 0.0) {
-                    t[(size_t)head * 3 + c] = (int16_t)(long long)((u + l) / 2);
-                    u = inf;
-                    l = -inf;
-                    head = p0 + k;
-                }
-                if (du < u) u = du;
-                if (l < dl) l = dl;
+        // 1. range tables (level 0 is the element itself); shfl_down past lane 63 returns the
+        //    caller's own value, which clamps the range at the chunk end
+        double tu[6], tl[6];
+        tu[0] = du;
+        tl[0] = dl;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) {
+            double a = __shfl_down(tu[k - 1], 1 << (k - 1), 64), b = __shfl_down(tl[k - 1], 1 << (k - 1), 64);
+            tu[k] = tu[k - 1] < a ? tu[k - 1] : a;
+            tl[k] = tl[k - 1] > b ? tl[k - 1] : b;
+        }
+        // 3a. inclusive prefix from the chunk start
+        double pu = du, pl = dl;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            double a = __shfl_up(pu, sft, 64), b = __shfl_up(pl, sft, 64);
+            if (lane >= sft) {
+                pu = pu < a ? pu : a;
+                pl = pl > b ? pl : b;
             }
         }
+        // 2. binary lifting: longest break-free extension of a run that starts at this lane
+        double cu = du, cl = dl;
+        int pos = lane + 1;
+#pragma unroll
+        for (int k = 5; k >= 0; --k) {
+            const int step = 1 << k;
+            int src = pos < 63 ? pos : 63;
+            double xu = shfl_d(tu[k], src), xl = shfl_d(tl[k], src);
+            double nu = cu < xu ? cu : xu, nl = cl > xl ? cl : xl;
+            bool ok = (pos + step <= 64) && !(nu - nl < 0.0);
+            if (ok) {
+                cu = nu;
+                cl = nl;
+                pos += step;
+            }
+        }
+        const int nxt = pos;  // in [lane+1, 64]; 64 = the run leaves the chunk
+        // 3b. where does the carried run break?
+        double eu = u < pu ? u : pu, el = l > pl ? l : pl;
+        unsigned long long brk = __ballot(eu - el < 0.0);
+        if (brk == 0ull) {
+            u = shfl_d(eu, 63);
+            l = shfl_d(el, 63);
+            continue;
+        }
+        const int j0 = __ffsll((long long)brk) - 1;
+        {
+            double uc = u, lc = l;
+            if (j0 > 0) {
+                uc = shfl_d(eu, j0 - 1);
+                lc = shfl_d(el, j0 - 1);
+            }
+            if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
+        }
+        // 4. heads of this chunk
+        unsigned long long heads = 0ull;
+        int h = j0, last = j0;
+        while (h < 64) {
+            heads |= 1ull << h;
+            last = h;
+            h = __builtin_amdgcn_readlane(nxt, h);
+        }
+        // 5. closed runs store their value at their head; the last head carries on
+        if (((heads >> lane) & 1ull) && nxt < 64) t[(size_t)idx * 3 + c] = (int16_t)(long long)((cu + cl) / 2);
+        u = shfl_d(cu, last);
+        l = shfl_d(cl, last);
+        chead = ch * 64 + last;
     }
-    if (lane == 0 && HW > 0) t[(size_t)head * 3 + c] = (int16_t)(long long)((u + l) / 2);
+    if (lane == 0 && HW > 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((u + l) / 2);
 }
 
 static constexpr int QFB = 2048;  // pixels per fill block
