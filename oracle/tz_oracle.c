@@ -5,7 +5,8 @@
  *     uses Python loops where the reference does): error_bound, delta, spatial delta,
  *     histogram, remap, inverse scan, reconstruct.  Citations are into /root/reference/src.
  *  2. The PredNet forward pass (prednet.py:143-308) in the canonical arithmetic "TZ-PA1":
- *       conv[y,x,co] = b[co]; for source s in concat order, ky, kx, ci:
+ *       conv[y,x,co] = b[co]; for source s in concat order, for each block of 16 channels of
+ *                      s, for ky, kx, for ci in the block:
  *                         acc = fmaf(in_s[y+ky-1][x+kx-1][ci], W[ky][kx][coff_s+ci][co], acc)
  *     ('same' zero padding; upsampled sources read in[(y')>>1][(x')>>1]); activations from
  *     tz_math.h.  The reference's predictor arithmetic lives in keras==2.2.4 /
@@ -211,21 +212,23 @@ static void conv3x3(const tzo_src* src, int nsrc, int H, int W, const float* Wt,
             for (int s = 0; s < nsrc; ++s) {
                 int C = src[s].C;
                 if (src[s].p) { /* an all-zero source leaves every chain unchanged */
-                    for (int ky = 0; ky < 3; ++ky)
-                        for (int kx = 0; kx < 3; ++kx) {
-                            int yy = y + ky - 1, xx = x + kx - 1;
-                            int inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
-                            const float* ip = NULL;
-                            if (inside)
-                                ip = src[s].up ? src[s].p + ((size_t)(yy >> 1) * (W >> 1) + (xx >> 1)) * C
-                                               : src[s].p + ((size_t)yy * W + xx) * C;
-                            const float* wp = Wt + ((size_t)(ky * 3 + kx) * Cin + coff) * Cout;
-                            for (int ci = 0; ci < C; ++ci) {
-                                float xv = inside ? ip[ci] : 0.0f;
-                                const float* wr = wp + (size_t)ci * Cout;
-                                for (int co = 0; co < Cout; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+                    for (int c0 = 0; c0 < C; c0 += 16) /* blocks of 16 input channels */
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int kx = 0; kx < 3; ++kx) {
+                                int yy = y + ky - 1, xx = x + kx - 1;
+                                int inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                                const float* ip = NULL;
+                                if (inside)
+                                    ip = src[s].up ? src[s].p + ((size_t)(yy >> 1) * (W >> 1) + (xx >> 1)) * C
+                                                   : src[s].p + ((size_t)yy * W + xx) * C;
+                                const float* wp = Wt + ((size_t)(ky * 3 + kx) * Cin + coff) * Cout;
+                                int c1 = c0 + 16 < C ? c0 + 16 : C;
+                                for (int ci = c0; ci < c1; ++ci) {
+                                    float xv = inside ? ip[ci] : 0.0f;
+                                    const float* wr = wp + (size_t)ci * Cout;
+                                    for (int co = 0; co < Cout; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+                                }
                             }
-                        }
                 }
                 coff += C;
             }

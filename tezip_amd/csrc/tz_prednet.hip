@@ -12,18 +12,19 @@
 //     The t=1 bottom-up pass and the zero second input are dead.
 //
 // Arithmetic contract TZ-PA1 (bit-exact with oracle/tz_oracle.c): every convolution output is
-// ONE float32 fmaf chain: acc = bias; for source in concat order, ky, kx, ci:
-// acc = fmaf(x, w, acc).  The MFMA k-loop below walks exactly that order; out-of-image taps
-// and channel padding contribute fmaf(0, w, acc) = acc.  No split-K, no atomics: results do
-// not depend on batch size, grid shape or device.
+// ONE float32 fmaf chain: acc = bias; for source in concat order, for each block of 16 input
+// channels, for ky, kx, for ci in the block: acc = fmaf(x, w, acc).  The MFMA k-loop below walks
+// exactly that order; out-of-image taps and channel padding contribute fmaf(0, w, acc) = acc.
+// No split-K, no atomics: results do not depend on batch size, grid shape or device.
 //
-// Tiling: workgroup = 4 waves = 16x16 output pixels (256 GEMM rows) x NT*16 output columns;
-// each wave owns 64 rows x NT*16 columns = 4 x NT MFMA tiles (acc in registers).  K is
-// walked in chunks of 16 input channels of one (source, tap): A chunk 256x16 and B chunk
-// 16x(NT*16) are prefetched into registers while the previous chunk is multiplied out of LDS.
-// LDS row strides (18 / NT*16[+16] floats) make every ds_read_b32 of a fragment conflict free.
-// ~23.5 KB LDS and ~110 VGPRs per workgroup => 4 workgroups per CU hide the two barriers per
-// chunk behind each other's MFMAs.
+// Tiling: workgroup = 8 waves = 16x16 output pixels (256 GEMM rows) x NT*16 output columns;
+// each wave owns 32 rows x NT*16 columns = 2 x NT MFMA tiles (acc in registers).  For every
+// block of 16 input channels the 18x18 halo patch is staged in LDS ONCE and all 9 taps read
+// their shifted A fragments from it (the first version re-staged A per tap and was bound by
+// L2/Infinity-Cache traffic: 53 % L2 hit rate, profiles/r01); the per-tap 16 x (NT*16) weight
+// chunk is double-buffered in LDS, one barrier per tap.  The next patch is prefetched into
+// registers during the 9 taps.  LDS row strides (18 / NT*16[+16] floats) keep fragment reads
+// conflict free.  ~33 KB LDS, ~90 VGPRs, 512 threads => 2 workgroups (16 waves) per CU.
 #include <algorithm>
 
 #include "tz_internal.h"
@@ -61,67 +62,83 @@ struct ConvArgs {
     int R;              // EPI_LSTM_PACKED: channels per gate
 };
 
-static constexpr int SA = 18;  // LDS row stride of the A chunk (floats)
+static constexpr int SA = 18;    // LDS row stride of one halo-patch pixel (16 channels + 2 pad floats)
+static constexpr int PW = 18;    // halo patch is PW x PW pixels around the 16x16 output tile
+static constexpr int PPIX = PW * PW;
+static constexpr int A_ITEMS = PPIX * 4;                 // float4 items of one patch channel block
+static constexpr int NTHR = 512;                         // 8 waves: wave w owns tile rows 2w, 2w+1
+static constexpr int MT = 2;                             // 16-row MFMA tiles per wave
+static constexpr int A_PER_THREAD = (A_ITEMS + NTHR - 1) / NTHR;  // 3
 
 template <bool POOL>
 __device__ __forceinline__ void row_to_patch(int m, int& py, int& px) {
-    int w = m >> 6, mt = (m >> 4) & 3, r16 = m & 15;
+    int w = m >> 5, mt = (m >> 4) & 1, r16 = m & 15;
     if (POOL) {  // the 4 accumulator registers of a lane form one 2x2 pooling window
-        py = 4 * w + 2 * (mt >> 1) + ((r16 & 3) >> 1);
-        px = 8 * (mt & 1) + 2 * (r16 >> 2) + (r16 & 1);
+        py = 2 * w + ((r16 & 3) >> 1);
+        px = 8 * mt + 2 * (r16 >> 2) + (r16 & 1);
     } else {
-        py = 4 * w + mt;
+        py = 2 * w + mt;
         px = r16;
     }
 }
 
+// XCD-aware block order: blocks b and b+8 share an XCD (round-robin dispatch), so give every
+// XCD a contiguous range of logical ids: the column blocks of one pixel tile and neighbouring
+// tiles then share one L2.  Bijective for any grid size; only speed depends on it.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 template <int NT, int EPI>
-__global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvArgs a) {
+__global__ __launch_bounds__(NTHR, 4) void k_conv3x3(const ConvArgs a) {
     constexpr bool POOL = EPI == EPI_POOL_ERR;
     constexpr int NTC = NT * 16;
     constexpr int SB = NTC + ((NTC % 32) == 0 ? 16 : 0);
     constexpr int BVEC = 16 * NTC / 4;  // float4 loads for one B chunk
-    __shared__ float sA[256 * SA];
-    __shared__ float sB[16 * SB];
+    __shared__ float sA[PPIX * SA];
+    __shared__ float sB[2][16 * SB];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int cb = bid % a.ncb;
     bid /= a.ncb;
     const int ntiles = a.tiles_x * a.tiles_y;
     const int tile = bid % ntiles, n = bid / ntiles;
     const int ty0 = (tile / a.tiles_x) * 16, tx0 = (tile % a.tiles_x) * 16;
 
-    // ---- staging roles: A: 4 rows per thread (row = (tid>>2) + 64 j), channel quad tid&3
-    const int q = tid & 3;
-    int gy[4], gx[4];
+    // ---- staging roles
+    // A: the 18x18x16 halo patch = 1296 float4 items; item i -> patch pixel i>>2, channel quad i&3
+    int apix[A_PER_THREAD];  // (yy << 16) | xx of the item's global pixel, or -1 outside the image
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int py, px;
-        row_to_patch<POOL>((tid >> 2) + 64 * j, py, px);
-        gy[j] = ty0 + py;
-        gx[j] = tx0 + px;
+    for (int j = 0; j < A_PER_THREAD; ++j) {
+        int i = tid + NTHR * j;
+        int pp = i >> 2;
+        int yy = ty0 - 1 + pp / PW, xx = tx0 - 1 + pp % PW;
+        apix[j] = (i < A_ITEMS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? ((yy << 16) | xx) : -1;
     }
+    const int aq = tid & 3;
     const int b_row = NT == 4 ? (tid >> 4) : (NT == 3 ? tid / 12 : (tid >> 2));
     const int b_quad = NT == 4 ? (tid & 15) : (NT == 3 ? tid % 12 : (tid & 3));
     const bool b_active = tid < BVEC;
 
-    float4 ra[4];
+    float4 ra[A_PER_THREAD];
     float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    auto load_chunk = [&](int chunk) {
-        const ConvSrc& s = (a.nsrc > 1 && chunk >= a.src[1].chunk_base) ? a.src[1] : a.src[0];
-        int local = chunk - s.chunk_base;
-        int tap = local / s.cpt, c0 = (local - tap * s.cpt) * 16 + 4 * q;
-        int ky = tap / 3 - 1, kx = tap % 3 - 1;
+    const int nb0 = a.nsrc > 0 ? a.src[0].cpt : 0;
+    const int nblk = nb0 + (a.nsrc > 1 ? a.src[1].cpt : 0);
+
+    auto load_patch = [&](int blk) {
+        const ConvSrc& s = blk >= nb0 ? a.src[1] : a.src[0];
+        const int c0 = (blk >= nb0 ? blk - nb0 : blk) * 16 + 4 * aq;
         const float* base = s.p + (long long)n * s.nstride;
         const int Ws = a.W >> s.up;
         const bool vec = (s.C & 3) == 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int yy = gy[j] + ky, xx = gx[j] + kx;
+        for (int j = 0; j < A_PER_THREAD; ++j) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && c0 < s.C) {
+            if (apix[j] >= 0 && c0 < s.C) {
+                int yy = apix[j] >> 16, xx = apix[j] & 0xffff;
                 const float* ptr = base + ((long long)(yy >> s.up) * Ws + (xx >> s.up)) * s.C + c0;
                 if (vec) {
                     v = *(const float4*)ptr;
@@ -134,41 +151,44 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvArgs a) {
             }
             ra[j] = v;
         }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_PER_THREAD; ++j) {
+            int i = tid + NTHR * j;
+            if (i < A_ITEMS) {
+                float* d = sA + (i >> 2) * SA + 4 * aq;
+                *(float2*)d = make_float2(ra[j].x, ra[j].y);
+                *(float2*)(d + 2) = make_float2(ra[j].z, ra[j].w);
+            }
+        }
+    };
+    auto load_b = [&](int chunk) {
         if (b_active) rb = *(const float4*)(a.Wp + ((long long)chunk * 16 + b_row) * a.ncols + cb * NTC + 4 * b_quad);
     };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float* d = sA + ((tid >> 2) + 64 * j) * SA + 4 * q;
-            *(float2*)d = make_float2(ra[j].x, ra[j].y);
-            *(float2*)(d + 2) = make_float2(ra[j].z, ra[j].w);
-        }
-        if (b_active) *(float4*)(sB + b_row * SB + 4 * b_quad) = rb;
+    auto store_b = [&](int buf) {
+        if (b_active) *(float4*)(sB[buf] + b_row * SB + 4 * b_quad) = rb;
     };
 
     // ---- accumulators: acc[mt][nt], element r <-> GEMM row (lane>>4)*4 + r, column lane&15
-    f32x4 acc[4][NT];
+    f32x4 acc[MT][NT];
     const int col0 = cb * NTC + (lane & 15);
-    int oy[4][4], ox[4][4];  // pixel of (mt, r) for this lane
+    auto out_pix = [&](int mt, int r, int& y, int& x) {
+        int py, px;
+        row_to_patch<POOL>(wv * 32 + mt * 16 + (lane >> 4) * 4 + r, py, px);
+        y = ty0 + py;
+        x = tx0 + px;
+    };
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int py, px;
-            row_to_patch<POOL>(wv * 64 + mt * 16 + (lane >> 4) * 4 + r, py, px);
-            oy[mt][r] = ty0 + py;
-            ox[mt][r] = tx0 + px;
-        }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (a.init) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    bool ok = oy[mt][r] < a.H && ox[mt][r] < a.W;
-                    acc[mt][nt][r] =
-                        ok ? a.init[((long long)oy[mt][r] * a.W + ox[mt][r]) * a.ncols + col0 + nt * 16] : 0.0f;
+                    int y, x;
+                    out_pix(mt, r, y, x);
+                    acc[mt][nt][r] = (y < a.H && x < a.W) ? a.init[((long long)y * a.W + x) * a.ncols + col0 + nt * 16] : 0.0f;
                 }
             } else {
                 float b = a.bias[col0 + nt * 16];
@@ -176,32 +196,51 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvArgs a) {
             }
         }
 
-    // ---- K loop
-    if (a.nchunks > 0) {
-        load_chunk(0);
-        store_chunk();
+    // ---- K loop: channel blocks of 16 (patch staged once), 9 taps each (weights double-buffered)
+    if (nblk > 0) {
+        // LDS offsets of this lane's A rows inside the patch (tap 0,0 = patch origin)
+        int arow[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int py, px;
+            row_to_patch<POOL>(wv * 32 + mt * 16 + (lane & 15), py, px);
+            arow[mt] = (py * PW + px) * SA + (lane >> 4);
+        }
+        const float* pb0 = sB[0] + (lane >> 4) * SB + (lane & 15);
+        load_patch(0);
+        load_b(0);
+        store_patch();
+        store_b(0);
         __syncthreads();
-        const float* pa = sA + (wv * 64 + (lane & 15)) * SA + (lane >> 4);
-        const float* pb = sB + (lane >> 4) * SB + (lane & 15);
-        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-            const bool more = chunk + 1 < a.nchunks;
-            if (more) load_chunk(chunk + 1);
+        int cur = 0;
+        for (int blk = 0; blk < nblk; ++blk) {
+            const bool more_blk = blk + 1 < nblk;
+            if (more_blk) load_patch(blk + 1);
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const bool more = more_blk || tap < 8;
+                if (more) load_b(blk * 9 + tap + 1);
+                const int toff = ((tap / 3) * PW + (tap % 3)) * SA;
+                const float* pb = pb0 + cur * (16 * SB);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                float fa[4], fb[NT];
+                for (int kk = 0; kk < 4; ++kk) {
+                    float fa[MT], fb[NT];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) fa[mt] = pa[mt * 16 * SA + 4 * kk];
+                    for (int mt = 0; mt < MT; ++mt) fa[mt] = sA[arow[mt] + toff + 4 * kk];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) fb[nt] = pb[4 * kk * SB + nt * 16];
+                    for (int nt = 0; nt < NT; ++nt) fb[nt] = pb[4 * kk * SB + nt * 16];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+                }
+                if (more) store_b(cur ^ 1);
+                __syncthreads();
+                cur ^= 1;
             }
-            __syncthreads();
-            if (more) {
-                store_chunk();
+            if (more_blk) {
+                store_patch();
                 __syncthreads();
             }
         }
@@ -211,22 +250,26 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvArgs a) {
     const int j = lane & 15;
     if (EPI == EPI_RAW) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (oy[mt][r] >= a.H || ox[mt][r] >= a.W) continue;
-                long long pix = (long long)oy[mt][r] * a.W + ox[mt][r];
+                int y, x;
+                out_pix(mt, r, y, x);
+                if (y >= a.H || x >= a.W) continue;
+                long long pix = (long long)y * a.W + x;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) a.out0[pix * a.ncols + col0 + nt * 16] = acc[mt][nt][r];
             }
     } else if (EPI == EPI_RELU) {
         float* o = a.out0 + (long long)(a.out_idx ? a.out_idx[n] : n) * a.out0_nstride;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (oy[mt][r] >= a.H || ox[mt][r] >= a.W) continue;
-                long long pix = (long long)oy[mt][r] * a.W + ox[mt][r];
+                int y, x;
+                out_pix(mt, r, y, x);
+                if (y >= a.H || x >= a.W) continue;
+                long long pix = (long long)y * a.W + x;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     int ch = col0 + nt * 16;
@@ -244,11 +287,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvArgs a) {
         float* o0 = a.out0 + (long long)n * a.out0_nstride;
         float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (oy[mt][r] >= a.H || ox[mt][r] >= a.W) continue;
-                long long pix = (long long)oy[mt][r] * a.W + ox[mt][r];
+                int y, x;
+                out_pix(mt, r, y, x);
+                if (y >= a.H || x >= a.W) continue;
+                long long pix = (long long)y * a.W + x;
                 float gi = tz_hard_sigmoid(acc[mt][0 % NT][r]);
                 float gf = tz_hard_sigmoid(acc[mt][1 % NT][r]);
                 float gg = tz_tanh(acc[mt][2 % NT][r]);
@@ -268,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvArgs a) {
         float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
         const int lbase = lane & 48;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[mt][0][r];
@@ -276,8 +321,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvArgs a) {
                 float vf = __shfl(v, lbase + ((j % 4) + R) % 16, 64);
                 float vg = __shfl(v, lbase + ((j % 4) + 2 * R) % 16, 64);
                 float vo = __shfl(v, lbase + ((j % 4) + 3 * R) % 16, 64);
-                if (j >= R || oy[mt][r] >= a.H || ox[mt][r] >= a.W) continue;
-                long long pix = (long long)oy[mt][r] * a.W + ox[mt][r];
+                int y, x;
+                out_pix(mt, r, y, x);
+                if (j >= R || y >= a.H || x >= a.W) continue;
+                long long pix = (long long)y * a.W + x;
                 float gi = tz_hard_sigmoid(vi), gf = tz_hard_sigmoid(vf), gg = tz_tanh(vg), go = tz_hard_sigmoid(vo);
                 float cp = a.aux ? a.aux[pix * R + j] : 0.0f;
                 float t1 = gf * cp;
@@ -293,8 +340,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const ConvArgs a) {
         const int H2 = a.H >> 1, W2 = a.W >> 1, C = a.Cout;
         float* o = a.out0 + (long long)n * a.out0_nstride;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            int yp = oy[mt][0] >> 1, xp = ox[mt][0] >> 1;
+        for (int mt = 0; mt < MT; ++mt) {
+            int y, x;
+            out_pix(mt, 0, y, x);
+            int yp = y >> 1, xp = x >> 1;
             if (yp >= H2 || xp >= W2) continue;
             long long pp = (long long)yp * W2 + xp;
 #pragma unroll
@@ -396,7 +445,7 @@ struct ColSrc {
     int Cin, Cout, ch;    // ch < 0: zero padding column
 };
 
-// Pack weights into the chunk order walked by k_conv3x3: for seg, tap, 16-channel chunk.
+// Pack weights into the chunk order walked by k_conv3x3: for seg, 16-channel block, tap.
 static int pack_conv(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, const std::vector<ColSrc>& cols, int NT,
                      PackedConv* pc) {
     int ncols = (int)cols.size();
@@ -405,8 +454,8 @@ static int pack_conv(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, con
     std::vector<float> W((size_t)std::max(nchunks, 1) * 16 * ncols, 0.0f), B(ncols, 0.0f);
     int chunk = 0;
     for (auto& s : segs)
-        for (int tap = 0; tap < 9; ++tap)
-            for (int c0 = 0; c0 < s.C; c0 += 16, ++chunk)
+        for (int c0 = 0; c0 < s.C; c0 += 16)
+            for (int tap = 0; tap < 9; ++tap, ++chunk)
                 for (int kc = 0; kc < 16 && c0 + kc < s.C; ++kc)
                     for (int col = 0; col < ncols; ++col) {
                         const ColSrc& cs = cols[col];
@@ -466,7 +515,7 @@ static int gate_cols(tz_ctx* ctx, const tz_model* m, int l, std::vector<ColSrc>*
 template <int NT, int EPI>
 static void launch_conv_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
     int blocks = a.ncb * a.tiles_x * a.tiles_y * nbatch;
-    hipLaunchKernelGGL((k_conv3x3<NT, EPI>), dim3(blocks), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k_conv3x3<NT, EPI>), dim3(blocks), dim3(NTHR), 0, ctx->stream, a);
 }
 
 static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbatch) {
