@@ -1,0 +1,83 @@
+"""End-to-end through the reference-shaped entry points on a MI355X: PNG directory ->
+compress.run -> {filename.txt, key_frame.dat, entropy.dat} -> decompress.run -> PNGs, and the
+files are decoded by the ORACLE's decoder too (the restatement of the reference's decompressor,
+pinned to it by tests/test_oracle_golden.py), i.e. the on-disk format is the reference's."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import coracle
+from oracle import oracle as O
+from tezip_amd import compress, decompress, synth, weights, zstd
+from tezip_amd.prednet import PredNetConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def _write(tmp, frames, gray):
+    from PIL import Image
+    d = tmp / "data"
+    d.mkdir()
+    for t in range(frames.shape[0]):
+        img = frames[t, :, :, 0] if gray else frames[t]
+        Image.fromarray(img, mode="L" if gray else "RGB").save(d / ("frame_%03d.png" % t))
+    return str(d)
+
+
+@pytest.mark.parametrize("gray,p,window,thr,mode,bound,entropy", [
+    (False, 0, 5, None, "abs", [0.0], True),
+    (True, 2, 4, None, "abs", [3.0], True),
+    (False, 0, None, 0.02, "rel", [0.01], False),
+])
+def test_cli_roundtrip_and_reference_format(tmp_path, gray, p, window, thr, mode, bound, entropy):
+    from PIL import Image
+    cfg = PredNetConfig(stack_sizes=(3, 16, 32))
+    nt, h, w = 13, 29, 43
+    frames = synth.translating_scene(nt, h, w, seed=5)
+    if gray:
+        frames = np.repeat(frames[..., :1], 3, axis=-1)
+    hp, wp = 32, 48
+    wts = cfg.init_weights(seed=4, bias_scale=0.1)
+    mdir = str(tmp_path / "model")
+    weights.save_model(mdir, cfg, wts, hp, wp)
+    ddir = _write(tmp_path, frames, gray)
+    cdir, udir = str(tmp_path / "comp"), str(tmp_path / "out")
+    compress.run(mdir, ddir, cdir, p, window, thr, mode, bound, True, True, entropy)
+    assert sorted(os.listdir(cdir)) == ["entropy.dat", "filename.txt", "key_frame.dat"]
+    names = ["frame_%03d.png" % t for t in range(nt)]
+    assert open(os.path.join(cdir, "filename.txt")).read() == O.filename_txt(names, not gray)
+    key_bytes = np.frombuffer(zstd.decompress(open(os.path.join(cdir, "key_frame.dat"), "rb").read()), np.uint8)
+    stream = np.frombuffer(zstd.decompress(open(os.path.join(cdir, "entropy.dat"), "rb").read()), "<i2")
+
+    class P:
+        net = coracle.CPredNet(wts, cfg.stack_sizes, cfg.R_stack_sizes, hp, wp)
+
+        def c0(self, a, b):
+            return self.net.c0()
+
+        def next(self, f):
+            return self.net.next(np.asarray(f, np.float32))
+
+    ref = O.compress_oracle(frames, p, window, thr, mode, bound, P(), entropy)
+    np.testing.assert_array_equal(key_bytes, ref["key_frame"])
+    np.testing.assert_array_equal(stream, ref["stream"])       # pre-zstd bytes identical to the oracle's
+    oracle_dec = O.decode_stream(stream, key_bytes, P())         # the reference's decoder (restated) reads our files
+    decompress.run(mdir, cdir, udir, True, False)
+    got = np.stack([np.array(Image.open(os.path.join(udir, n))) for n in names])
+    assert got.shape == (nt, h, w, 3)                            # decompress.py:278 always saves RGB
+    np.testing.assert_array_equal(got, oracle_dec)
+    if bound[0] == 0:
+        np.testing.assert_array_equal(got, frames)
+    else:
+        assert np.abs(got.astype(int) - frames.astype(int)).max() <= (int(bound[0]) + 1 if mode == "abs" else 4)
+
+
+def test_wrong_model_size_is_reported_like_the_reference(tmp_path, capsys):
+    cfg = PredNetConfig(stack_sizes=(3, 16, 32))
+    mdir = str(tmp_path / "model")
+    weights.save_model(mdir, cfg, cfg.init_weights(seed=1), 64, 64)
+    ddir = _write(tmp_path, synth.translating_scene(4, 16, 16, seed=1), False)
+    with pytest.raises(SystemExit):
+        compress.run(mdir, ddir, str(tmp_path / "c"), 0, 2, None, "abs", [0.0], True, False, True)
+    assert "ERROR:Image size is out of scope for this model." in capsys.readouterr().out

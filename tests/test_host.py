@@ -1,0 +1,117 @@
+"""Host-side mirror of the reference interface (no GPU needed): CLI validation cascade
+(tezip.py:28-84), model directory parsing, trailer/stream layout (compress.py:381-394,
+decompress.py:105-113) against the goldens, zstd frames, padding helpers."""
+import io
+import os
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle as O
+from tezip_amd import compress, data_utils, decompress, tezip, weights, zstd
+from tezip_amd.prednet import PredNetConfig
+
+R = np.load(os.path.join(GOLDEN, "ref_runs.npz"))
+H = np.load(os.path.join(GOLDEN, "ref_helpers.npz"))
+
+
+def _cli(argv):
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        args = tezip.build_parser().parse_args(argv + ["-f"])  # -f: no device probe, 'CPU MODE'
+        try:
+            tezip.main(args)
+        except SystemExit:
+            pass
+    return buf.getvalue().splitlines()
+
+
+def test_cli_validation_cascade_messages():
+    assert _cli([])[1:] == ['ERROR', 'Please mode select!', 'learn or compress or uncompress.',
+                            'Command to check the options is -h or --help']
+    assert _cli(["-c", "m", "d", "o"])[1:] == ['compress mode', 'ERROR', 'Please specify the -p or --preprocess option!',
+                                               'warm up num.']
+    out = _cli(["-c", "m", "d", "o", "-p", "0"])
+    assert out[2:4] == ['ERROR', 'Please specify the window size(-w or --window) or MSE threshold(-t or --threshold) option!']
+    out = _cli(["-c", "m", "d", "o", "-p", "0", "-w", "5", "-t", "0.1", "-m", "abs", "-b", "0"])
+    assert out[3] == 'Please select only one of window size(-w or --window) or MSE threshold(-t or --threshold)!'
+    out = _cli(["-c", "m", "d", "o", "-p", "0", "-w", "5", "-m", "xyz", "-b", "0"])
+    assert out[2:5] == ['xyz', 'ERROR', 'Please specify the -m or --mode correctly!']
+    out = _cli(["-c", "m", "d", "o", "-p", "0", "-w", "5", "-m", "abs"])
+    assert out[3:5] == ['ERROR', 'Please specify the -b or --bound option!']
+    out = _cli(["-c", "m", "d", "o", "-p", "0", "-w", "5", "-m", "absrel", "-b", "1"])
+    assert out[3] == 'ERROR' and out[5].startswith("If the -m or --mode is 'absrel'")
+    out = _cli(["-c", "m", "d", "o", "-u", "m", "f", "d"])
+    assert out[1:3] == ['ERROR', 'Please select only one of learn or compress or uncompress.']
+    assert _cli([])[0] == 'CPU MODE'
+    # flags: -n is store_false (default True), as tezip.py:99
+    a = tezip.build_parser().parse_args(["-n"])
+    assert a.no_entropy is False and tezip.build_parser().parse_args([]).no_entropy is True
+
+
+def test_force_cpu_is_refused_not_emulated(tmp_path):
+    out = _cli(["-c", str(tmp_path), str(tmp_path), str(tmp_path / "o"), "-p", "0", "-w", "5", "-m", "abs", "-b", "0"])
+    assert any("MI355X only" in l for l in out)
+
+
+def test_padding_helpers_match_reference():
+    assert [data_utils.padding_size(int(v)) for v in H["pad_sizes_in"]] == H["pad_sizes_out"].tolist()
+    assert data_utils.padding_shape(375, 1242) == (376, 1248)
+
+
+def test_model_dir_roundtrip_and_keras_style_json(tmp_path):
+    cfg = PredNetConfig()
+    w = cfg.init_weights(seed=2, bias_scale=0.1)
+    weights.save_model(str(tmp_path), cfg, w, 128, 160)
+    cfg2, w2, shape = weights.load_model(str(tmp_path))
+    assert cfg2.stack_sizes == (3, 48, 96, 192) and shape == (128, 160)
+    assert all((a == b).all() for a, b in zip(w, w2))
+    # a json shaped like Keras 2.2.4's model.to_json() with extra layers (train.py:63-70)
+    js = ('{"class_name":"Model","config":{"layers":[{"class_name":"InputLayer","config":{"batch_input_shape":'
+          '[null,2,64,64,3]}},{"class_name":"PredNet","config":{"stack_sizes":[3,48,96,192],"R_stack_sizes":[3,48,96,192],'
+          '"A_filt_sizes":[3,3,3],"Ahat_filt_sizes":[3,3,3,3],"R_filt_sizes":[3,3,3,3],"pixel_max":1.0,'
+          '"data_format":"channels_last","output_mode":"error"}},{"class_name":"TimeDistributed","config":{}}]}}')
+    c3, s3 = weights.parse_model_json(js)
+    assert c3.nb_layers == 4 and s3 == (64, 64)
+    with pytest.raises(FileNotFoundError):
+        weights.load_model(str(tmp_path / "missing"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in R["run_names"]])
+def test_stream_layout_matches_reference_files(name):
+    pre = "run_%s_" % name
+    ref = R[pre + "entropy"]
+    payload, table, shape, warm = decompress.parse_stream(ref.astype('<i2').tobytes())
+    p2, t2, s2, w2 = O.parse_stream(ref)
+    assert shape == s2 and warm == w2 and (payload == p2).all()
+    assert (table is None) == (t2 is None) and (table is None or (table == t2).all())
+    rebuilt = compress.build_stream(payload, table, shape, warm)
+    np.testing.assert_array_equal(rebuilt, ref)
+    nt, h, w = shape[1:4]
+    assert payload.size == nt * h * w * 3
+
+
+def test_zstd_frames_are_standard_and_carry_content_size():
+    data = np.arange(10000, dtype=np.int16)
+    blob = zstd.compress_array(data, 9)
+    assert blob[:4] == b"\x28\xb5\x2f\xfd"  # zstd magic
+    assert zstd.decompress(blob) == data.tobytes()
+    assert zstd.decompress(zstd.compress(b"", 9)) == b""
+
+
+def test_load_images_rules(tmp_path):
+    from PIL import Image
+    d = tmp_path / "imgs"
+    d.mkdir()
+    rng = np.random.default_rng(0)
+    for i in (2, 0, 1):
+        Image.fromarray(rng.integers(0, 256, (9, 7), dtype=np.uint8), mode="L").save(d / ("f%d.png" % i))
+    stack, files, is_rgb = compress.load_images(str(d))
+    assert files == ["f0.png", "f1.png", "f2.png"] and not is_rgb
+    assert stack.shape == (3, 9, 7, 3) and (stack[..., 0] == stack[..., 2]).all()  # compress.py:114
+    buf = io.StringIO()
+    with redirect_stdout(buf), pytest.raises(SystemExit):
+        compress.load_images(str(tmp_path / "nothing"))
+    assert "is an empty or non-existent directory" in buf.getvalue()

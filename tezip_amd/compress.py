@@ -1,0 +1,138 @@
+"""compress.run -- same signature, files and messages as the reference's
+/root/reference/src/compress.py:93 `run(...)`; everything between "uint8 frame stack" and
+"int16 payload + table" runs in libtezip_hip.so on the MI355X (no CPU fallback).
+
+Output directory:
+  filename.txt   line 1 "1"|"0" (RGB|L source), then one basename per line  (compress.py:133-136)
+  key_frame.dat  zstd-9 of uint8[nt*H*W*3], zero except key frames           (compress.py:271-278)
+  entropy.dat    zstd-9 of int16: payload | table | T  (or | -1) | 1,nt,H,W,3 | warm_up
+                                                                              (compress.py:381-400)
+"""
+import glob
+import os
+import time
+
+import numpy as np
+
+from . import _lib, weights, zstd
+from .data_utils import padding_shape
+
+
+def load_images(data_dir):
+    """compress.py:97-131: sorted(glob), RGB or L only (L is expanded to RGB), all one size."""
+    from PIL import Image, UnidentifiedImageError
+    file_paths = sorted(glob.glob(os.path.join(data_dir, '*')))
+    if len(file_paths) == 0:
+        print("ERROR:", data_dir, "is an empty or non-existent directory")
+        exit()
+    try:
+        first = Image.open(file_paths[0])
+        image_mode = first.mode
+        if all([image_mode != 'RGB', image_mode != 'L']):
+            print("ERROR: input image is {0}. Only RGB and grayscale are supported.".format(image_mode))
+            exit()
+        is_rgb = image_mode == 'RGB'
+        frames, files = [], []
+        for path in file_paths:
+            img = Image.open(path)
+            arr = np.array(img if is_rgb else img.convert('RGB'))
+            if arr.ndim != 3 or arr.shape[2] != 3:
+                raise IndexError(path)
+            frames.append(arr)
+            files.append(os.path.basename(path))
+        stack = np.ascontiguousarray(np.stack(frames), dtype=np.uint8)
+    except (PermissionError, IndexError, UnidentifiedImageError, IsADirectoryError, ValueError):
+        print(data_dir, "contains files or folders that are not images.")
+        exit()
+    return stack, files, is_rgb
+
+
+def open_model(weights_dir):
+    """compress.py:143-160: same error messages."""
+    json_file = os.path.join(weights_dir, weights.JSON_NAME)
+    try:
+        return weights.load_model(weights_dir)
+    except FileNotFoundError:
+        print("ERROR: No such file or directory:", json_file)
+        exit()
+    except OSError as e:
+        print("ERROR: No such file or directory:", os.path.join(weights_dir, weights.H5_NAME))
+        print(e)
+        exit()
+
+
+def make_context(cfg, wts, hp, wp, max_batch, device=0):
+    ctx = _lib.Context(device)
+    ctx.load_model(cfg, wts)
+    ctx.prepare(hp, wp, max_batch)
+    return ctx
+
+
+def build_stream(payload, table, shape5, warm_up):
+    """compress.py:381-394: payload | table | len(table)  (or | -1) | shape | PREPROCESS, int16."""
+    if table is not None:
+        tail = np.concatenate([table.astype(np.int64), [len(table)]])
+    else:
+        tail = np.array([-1], dtype=np.int64)
+    trailer = np.concatenate([tail, list(shape5), [warm_up]]).astype(np.int16)
+    return np.concatenate([np.asarray(payload, dtype=np.int16).reshape(-1), trailer])
+
+
+def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, MODE, BOUND_VALUE, GPU_FLAG, VERBOSE,
+        ENTROPY_RUN, device=0):
+    if not GPU_FLAG:
+        print("ERROR: this build runs the compression path on an AMD MI355X only (no CPU path).")
+        exit()
+    if not os.path.exists(OUTPUT_DIR):
+        os.mkdir(OUTPUT_DIR)
+    origine_img, files, isRGB = load_images(DATA_DIR)
+
+    with open(os.path.join(OUTPUT_DIR, 'filename.txt'), 'w', encoding='UTF-8') as f:
+        f.write(f"{int(isRGB)}\n")
+        for file_name in files:
+            f.write("%s\n" % file_name)
+
+    nt, H, W = origine_img.shape[:3]
+    cfg, wts, model_shape = open_model(WEIGHTS_DIR)
+    hp, wp = padding_shape(H, W)
+    if model_shape is not None and (model_shape[0] != hp or model_shape[1] != wp):
+        print("ERROR:Image size is out of scope for this model.")
+        print("Compatible sizes for this model are height", model_shape[0] - 7, "to", model_shape[0], "and width",
+              model_shape[1] - 7, "to", model_shape[1])
+        exit()
+    if nt < PREPROCESS + 2:
+        print("ERROR: need at least warm_up+2 images (%d given, warm_up %d)." % (nt, PREPROCESS))
+        exit()
+
+    nwin = 1 if WINDOW_SIZE is None else max(1, (nt - PREPROCESS + WINDOW_SIZE - 1) // WINDOW_SIZE)
+    ctx = make_context(cfg, wts, hp, wp, min(nwin, 64), device)
+    try:
+        if VERBOSE:
+            ctx.prof_enable(True)
+        t0 = time.time()
+        key, mse = ctx.rollout(origine_img, PREPROCESS, WINDOW_SIZE, THRESHOLD, want_mse=bool(VERBOSE))
+        if VERBOSE:
+            for i in range(PREPROCESS + 1, nt):
+                print("MSE:", mse[i])
+                if key[i] and i > PREPROCESS:
+                    print("move key point")
+            print("predict:{0}".format(time.time() - t0) + "[sec]")
+
+        # key frames (compress.py:271-278)
+        key_frame = np.zeros_like(origine_img)
+        key_frame[key] = origine_img[key]
+        with open(os.path.join(OUTPUT_DIR, "key_frame.dat"), mode='wb') as f:
+            f.write(zstd.compress_array(key_frame, 9))
+
+        payload, table, _ = ctx.encode(MODE, BOUND_VALUE, ENTROPY_RUN)
+        if VERBOSE:
+            prof = ctx.prof_get()
+            print("error_bound:{0}".format(prof["quant"][0] / 1e3) + "[sec]")
+            print("finding_difference:{0}".format(prof["spatial_delta_hist"][0] / 1e3) + "[sec]")
+            if ENTROPY_RUN:
+                print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
+        stream = build_stream(payload, table if ENTROPY_RUN else None, (1, nt, H, W, 3), PREPROCESS)
+        with open(os.path.join(OUTPUT_DIR, "entropy.dat"), mode='wb') as f:
+            f.write(zstd.compress_array(stream, 9))
+    finally:
+        ctx.close()

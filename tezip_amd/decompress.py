@@ -1,0 +1,96 @@
+"""decompress.run -- same signature, inputs and outputs as the reference's
+/root/reference/src/decompress.py:39 `run(...)`; the rollout replay, inverse remap, inverse
+spatial delta (a prefix scan on the GPU instead of the reference's Python loop) and the
+reconstruction run in libtezip_hip.so."""
+import os
+import time
+
+import numpy as np
+
+from . import _lib, zstd
+from .compress import make_context, open_model
+from .data_utils import padding_shape
+
+
+def parse_stream(data):
+    """decompress.py:105-113, 203-221: -> (payload, table|None, shape5, warm_up)."""
+    s = np.frombuffer(data, dtype='<i2')
+    if s.size < 8:
+        raise ValueError("entropy.dat is too short")
+    warm_up = int(s[-1])
+    shape = tuple(int(v) for v in s[-6:-1])
+    tlen = int(s[-7])
+    if tlen == -1:
+        return s[:-7], None, shape, warm_up
+    if tlen < 0 or tlen > s.size - 7:
+        raise ValueError("corrupt table length %d" % tlen)
+    return s[: -7 - tlen], s[-7 - tlen: -7], shape, warm_up
+
+
+def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
+    if not GPU_FLAG:
+        print("ERROR: this build runs the decompression path on an AMD MI355X only (no CPU path).")
+        exit()
+    if not os.path.exists(OUTPUT_DIR):
+        os.mkdir(OUTPUT_DIR)
+    isRGB = True
+    try:
+        with open(os.path.join(DATA_DIR, 'filename.txt'), 'r', encoding='UTF-8') as f:
+            file_names = [s.strip() for s in f.readlines()]
+    except FileNotFoundError:
+        print("ERROR:No such file or directory:", os.path.join(DATA_DIR, 'filename.txt'))
+        exit()
+    # decompress.py:55: `isdigit` is not called there, so any 1-character first line is the flag
+    if file_names and len(file_names[0]) == 1:
+        isRGB = bool(int(file_names.pop(0)))
+
+    cfg, wts, model_shape = open_model(WEIGHTS_DIR)
+
+    def read(name):
+        try:
+            with open(os.path.join(DATA_DIR, name), mode='rb') as f:
+                return zstd.decompress(f.read())
+        except FileNotFoundError:
+            print("ERROR: No such file or directory:", os.path.join(DATA_DIR, name))
+            exit()
+
+    key_bytes = read("key_frame.dat")
+    payload, table, shape, warm_up = parse_stream(read("entropy.dat"))
+    _, nt, H, W, C = shape
+    key_frames = np.frombuffer(key_bytes, dtype=np.uint8).reshape(nt, H, W, C)
+    hp, wp = padding_shape(H, W)
+    if model_shape is not None and (model_shape[0] != hp or model_shape[1] != wp):
+        print("ERROR:keyframe size and model size do not match.")
+        print("model size: height ", model_shape[0] - 7, "～", model_shape[0], " width ", model_shape[1] - 7, "～", model_shape[1])
+        print("key frame size: height ", H, " width ", W)
+        exit()
+    if len(file_names) != nt:
+        print("ERROR：The lengths of filename.txt and images do not match.")
+        print("filename.txt：", len(file_names))
+        print("number of images", nt)
+        exit()
+
+    ctx = make_context(cfg, wts, hp, wp, 64 if nt > 64 else max(1, nt), device)
+    try:
+        if VERBOSE:
+            ctx.prof_enable(True)
+        t0 = time.time()
+        ctx.rollout_decode(np.ascontiguousarray(key_frames), warm_up)
+        if VERBOSE:
+            print("predict:{0}".format(time.time() - t0) + "[sec]")
+        frames = ctx.decode(np.ascontiguousarray(payload), None if table is None else np.ascontiguousarray(table))
+        if VERBOSE:
+            prof = ctx.prof_get()
+            if table is not None:
+                print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
+            print("finding_difference:{0}".format(prof["undelta_scan"][0] / 1e3) + "[sec]")
+    finally:
+        ctx.close()
+
+    from PIL import Image
+    for j in range(nt):
+        img = Image.fromarray(frames[j])
+        if j == 0:
+            print("save as RGB" if isRGB else "save as gray")
+        # decompress.py:272-278: the grayscale save is overwritten by an unconditional RGB save
+        img.save(os.path.join(OUTPUT_DIR, file_names[j]))
