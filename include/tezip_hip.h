@@ -98,10 +98,18 @@ int tz_get_predictions(tz_ctx* ctx, float* out);
  * delta_out (may be NULL): the int16 delta stack after quantisation, before the spatial delta. */
 int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t* payload,
               int16_t* table, int* table_len, int16_t* delta_out);
+/* First stage of tz_encode only (compress.py:292-319): delta + error-bound quantisation of the
+ * context-resident rollout -> int16 delta stack nt*H*W*3.  Used when frame windows are sharded
+ * over GPUs: the spatial delta and the histogram then need a carry / a sum across shards
+ * (tz_spatial_delta with has_carry, tz_build_table, tz_remap). */
+int tz_encode_delta(tz_ctx* ctx, int mode, double b0, double b1, int16_t* delta_out);
 /* ---- decoder back half (decompress.py:203-256): payload (+table) -> nt*H*W*3 uint8 frames,
  * using the prediction stack of the last tz_rollout_decode. */
 int tz_decode(tz_ctx* ctx, const int16_t* payload, const int16_t* table, int table_len,
               uint8_t* frames_out);
+/* Last stage of tz_decode only (decompress.py:252-256): reconstruct from an already decoded
+ * int16 delta stack (sharded decoding: the inverse scan carry comes from the previous shard). */
+int tz_decode_delta(tz_ctx* ctx, const int16_t* delta, uint8_t* frames_out);
 
 /* ---- operator seams, usable stand-alone (each mirrors one reference helper) -----------------
  * tz_delta_encode: compress.py:292-314.  pred: nframes padded f32 frames; orig: nframes

@@ -1,0 +1,134 @@
+"""The N>1 path on CPU: world_size-2 (and 3) gloo process groups run the window-sharding
+protocol of tezip_amd/dist.py with the oracle plugged in as the per-rank engine, and must
+produce exactly the bytes of the single-process run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from tezip_amd import dist as tzdist
+
+
+def test_plan_shards_cuts_at_window_starts():
+    assert tzdist.plan_shards(80, 0, 20, 4) == [(0, 20), (20, 40), (40, 60), (60, 80)]
+    assert tzdist.plan_shards(80, 0, 20, 8) == [(0, 20), (20, 40), (40, 60), (60, 80)] + [(80, 80)] * 4
+    assert tzdist.plan_shards(14, 2, 4, 2) == [(0, 6), (6, 14)]
+    assert tzdist.plan_shards(9, 0, 4, 3) == [(0, 4), (4, 9), (9, 9)]  # trailing 1-frame group is merged
+    for nt, p, w, n in [(37, 3, 5, 4), (12, 0, 5, 2), (10, 1, 1, 3)]:
+        sh = tzdist.plan_shards(nt, p, w, n)
+        assert sh[0][0] == 0 and max(b for _, b in sh) == nt
+        for (a, b), (c, _) in zip(sh, sh[1:]):
+            assert b == c or (a == b == nt)
+        for a, b in sh:
+            assert b == a or (b - a >= 2 and (a == 0 or (a - p) % w == 0))
+    with pytest.raises(ValueError):
+        tzdist.plan_shards(10, 0, None, 2)
+
+
+class OracleEngine:
+    """Per-rank compute done by the CPU oracle (test double for dist.HipEngine)."""
+
+    def __init__(self, pred):
+        from oracle import coracle, oracle
+        self.O, self.C, self.pred = oracle, coracle, pred
+
+    def encode_delta(self, frames, warm_up, window, mode, bound):
+        ro = self.O.rollout(frames, warm_up, window, None, self.pred)
+        enc = self.O.encode_stream(frames, ro, warm_up, mode, bound, entropy=False)
+        return ro["key"], enc["delta"].reshape(-1)
+
+    def spatial_delta(self, d, carry, offset):
+        if carry is None:
+            y = self.C.spatial_delta(d, offset)
+        else:
+            y = self.C.spatial_delta(np.concatenate([[carry], d]).astype(np.int16), offset)[1:]
+        return y, (self.C.histogram(y).astype(np.uint64) if offset else None)
+
+    def build_table(self, hist):
+        syms = [int(s) for s in np.nonzero(hist)[0]]
+        syms.sort(key=lambda s: int(hist[s]), reverse=True)
+        return np.array(syms, np.int16)
+
+    def remap(self, y, table):
+        return self.O.remap_enc(y, table)
+
+    def decode_prepare(self, key_frames, warm_up):
+        self.key_frames = key_frames
+        self.x_hat, _ = self.O.decoder_rollout(key_frames, warm_up, self.pred)
+
+    def unmap(self, payload, table):
+        return (1600 - self.O.remap_dec(payload, table).astype(np.int64)).astype(np.int16)
+
+    def undelta(self, sd, carry):
+        if carry is None:
+            return self.O.finding_difference_dec(sd)
+        return self.O.finding_difference_dec(np.concatenate([[carry], sd]).astype(np.int16))[1:]
+
+    def reconstruct(self, delta):
+        h, w = delta.shape[1:3]
+        return self.O.reconstruct(self.x_hat[:, :h, :w], delta)
+
+
+def _case():
+    import fake_predictor
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    nt, h, w = 14, 13, 19
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    frames = np.stack([np.clip(np.stack([120 + 60 * np.sin((xx + 2 * t) / 5.0), 90 + 40 * np.cos((yy - t) / 4.0),
+                                         128 + 0.0 * xx], -1) + rng.normal(0, 3, (h, w, 3)), 0, 255).astype(np.uint8)
+                       for t in range(nt)])
+    pred = O.FnPredictor(fake_predictor.c0_image, fake_predictor.g_next)
+    return frames, pred
+
+
+def _worker(rank, world, port, p, window, mode, bound, entropy):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), os.path.join(here, "golden")]
+    import torch.distributed as dist
+    from oracle import oracle as O
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        frames, pred = _case()
+        eng = OracleEngine(pred)
+        res = tzdist.compress_sharded(eng, frames, p, window, mode, bound, entropy)
+        ref = O.compress_oracle(frames, p, window, None, mode, bound, pred, entropy)
+        ref_payload, ref_table, _, _ = O.parse_stream(ref["stream"])
+        if rank == 0:
+            payload, table, key = res
+            assert (key == ref["key"]).all()
+            assert payload.shape == ref_payload.shape and (payload == ref_payload).all()
+            assert (table is None) == (ref_table is None) and (table is None or (table == ref_table).all())
+        else:
+            assert res is None
+        key_stack = ref["key_frame"].reshape(frames.shape)
+        dec = tzdist.decompress_sharded(eng, key_stack, ref_payload, ref_table, p)
+        if rank == 0:
+            assert (dec == O.decode_stream(ref["stream"], ref["key_frame"], pred)).all()
+            if bound[0] == 0:
+                assert (dec == frames).all()
+        else:
+            assert dec is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("world,p,window,mode,bound,entropy", [
+    (2, 0, 4, "abs", [0.0], True),
+    (2, 2, 3, "abs", [3.0], True),
+    (3, 0, 5, "rel", [0.02], False),
+    (3, 1, 2, "pwrel", [0.05], True),
+])
+def test_sharded_equals_single_process(world, p, window, mode, bound, entropy):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, _free_port(), p, window, mode, bound, entropy), nprocs=world, join=True)

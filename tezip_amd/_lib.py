@@ -37,6 +37,8 @@ _SIGS = {
     "tz_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                             C.POINTER(C.c_int), C.c_void_p]),
     "tz_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "tz_encode_delta": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]),
+    "tz_decode_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "tz_delta_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "tz_error_bound": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_double, C.c_double]),
@@ -202,6 +204,21 @@ class Context:
                                     C.byref(tlen), _ptr(delta)))
         t = table[: tlen.value].copy() if tlen.value >= 0 else None
         return payload, t, delta
+
+    def encode_delta(self, mode, bound, out=None):
+        nt, h, w = self._shape
+        if out is None:
+            out = np.empty((nt, h, w, 3), np.int16)
+        b1 = float(bound[1]) if len(bound) > 1 else 0.0
+        self._ck(self.lib.tz_encode_delta(self.h, MODES[mode], float(bound[0]), b1, _ptr(out)))
+        return out
+
+    def decode_delta(self, delta, out=None):
+        nt, h, w = self._shape
+        if out is None:
+            out = np.empty((nt, h, w, 3), np.uint8)
+        self._ck(self.lib.tz_decode_delta(self.h, _ptr(delta), _ptr(out)))
+        return out
 
     def decode(self, payload, table, out=None):
         nt, h, w = self._shape

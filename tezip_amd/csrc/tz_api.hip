@@ -625,6 +625,53 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
     return rc;
 }
 
+extern "C" int tz_encode_delta(tz_ctx* ctx, int mode, double b0, double b1, int16_t* delta_out) {
+    if (!ctx || !delta_out) return TZ_ERR_INVALID;
+    if (!ctx->have_rollout || ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode_delta needs a tz_rollout first");
+    const int nt = ctx->nt, H = ctx->H, W = ctx->W;
+    const size_t N = (size_t)nt * H * W * 3;
+    std::vector<tz_out> outs;
+    tz_out o;
+    void* d_mask = nullptr;
+    int rc = tz_dev_out(ctx, delta_out, N * 2, &o);
+    if (rc == TZ_OK) outs.push_back(o);
+    if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_mask);
+    if (rc == TZ_OK) {
+        hipError_t e = hipMemcpyAsync(d_mask, ctx->group_first.data(), nt, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
+    }
+    if (rc == TZ_OK) rc = tzk_delta(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt, H, W, ctx->Hp, ctx->Wp, (int16_t*)o.dev);
+    if (rc == TZ_OK) rc = tzk_error_bound(ctx, ctx->d_frames, (int16_t*)o.dev, ctx->quant_skip.data(), nt, H, W, mode, b0, b1);
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+extern "C" int tz_decode_delta(tz_ctx* ctx, const int16_t* delta, uint8_t* frames_out) {
+    if (!ctx || !delta || !frames_out) return TZ_ERR_INVALID;
+    if (!ctx->have_rollout || !ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_decode_delta needs a tz_rollout_decode first");
+    const int nt = ctx->nt, H = ctx->H, W = ctx->W;
+    const size_t N = (size_t)nt * H * W * 3;
+    std::vector<tz_out> outs;
+    tz_out o;
+    const void* d_diff = nullptr;
+    void* d_mask = nullptr;
+    int rc = tz_dev_in(ctx, delta, N * 2, &d_diff);
+    if (rc == TZ_OK) rc = tz_dev_out(ctx, frames_out, N, &o);
+    if (rc == TZ_OK) outs.push_back(o);
+    if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_mask);
+    if (rc == TZ_OK) {
+        hipError_t e = hipMemcpyAsync(d_mask, ctx->key_mask.data(), nt, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
+    }
+    if (rc == TZ_OK)
+        rc = tzk_reconstruct(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, (const int16_t*)d_diff, nt, H, W,
+                             ctx->Hp, ctx->Wp, (uint8_t*)o.dev);
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
 extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, const int16_t* table, int table_len, uint8_t* frames_out) {
     if (!ctx || !payload || !frames_out) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || !ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_decode needs a tz_rollout_decode first");
