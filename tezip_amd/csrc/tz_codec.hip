@@ -139,118 +139,160 @@ __global__ __launch_bounds__(256) void k_q_init(int16_t* __restrict__ tmp, const
         if (!skip[i / frame_elems]) tmp[i] = TZ_SENTINEL;
 }
 
-// Wave-parallel exact greedy segmentation.  One wave per (frame, channel) chain; the chain is
-// walked in chunks of 64 elements (lane i <-> element).  A run started at s breaks at the
-// first i with min(Du[s..i]) < max(Dl[s..i]) (compress.py:60 -- a-b<0 <=> a<b in IEEE), which
-// is monotone in i, so per chunk:
+// Wave-parallel exact greedy segmentation.  One workgroup (8 waves) per (frame, channel)
+// chain; the chain is walked in chunks of 64 elements (lane i <-> element).  A run started at s
+// breaks at the first i with min(Du[s..i]) < max(Dl[s..i]) (compress.py:60 -- a-b<0 <=> a<b in
+// IEEE), which is monotone in i, so per chunk:
+//   WORKER waves 1..7 (carry independent, one chunk each per round):
 //   1. range tables T_k[i] = (min Du, max Dl) over [i, i+2^k) by shuffles (k = 0..5),
 //   2. nxt[s] = first break after s for EVERY s (fresh start) by binary lifting over T_k,
 //      together with the run's (u, l) up to the break,
-//   3. inclusive prefix (min Du, max Dl) from the chunk start; the run carried in from earlier
-//      chunks breaks at the first i with min(u, P_u[i]) < max(l, P_l[i])  (ballot),
-//   4. the true heads are the nxt-chain from that break (scalar readlane chase),
+//   3. inclusive prefix (min Du, max Dl) from the chunk start; all of it goes to an LDS slot.
+//   RESOLVER wave 0 (sequential over chunks, one round behind the workers):
+//   4. the run carried in from earlier chunks breaks at the first i with
+//      min(u, P_u[i]) < max(l, P_l[i])  (ballot); the true heads are the nxt-chain from that
+//      break, which the workers have already expanded into a bit mask per start (pointer
+//      doubling), so this is one LDS lookup,
 //   5. every head whose run closes inside the chunk stores trunc((u+l)/2) (compress.py:61,
 //      truncation by the int64 store) at the head position of `tmp`; the last head carries on.
-// Nothing here depends on run lengths; elements past the chain end are (+inf, -inf) and can
-// neither break nor tighten a run.
+// Rounds are double-buffered in LDS with one barrier per round.  Nothing depends on run
+// lengths; elements past the chain end are (+inf, -inf) and can neither break nor tighten a run.
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
-__global__ __launch_bounds__(192) void k_q_heads(const uint8_t* __restrict__ orig, const int16_t* __restrict__ diff,
+static constexpr int QW = 7;  // worker waves per chain
+
+struct QSlot {
+    double cu[64], cl[64], pu[64], pl[64];
+    unsigned long long heads[64];  // heads[s]: bit mask of the nxt-chain that starts at s
+    int nxt[64];
+};
+
+__global__ __launch_bounds__(512) void k_q_heads(const uint8_t* __restrict__ orig, const int16_t* __restrict__ diff,
                                                  const uint8_t* __restrict__ skip, int HW, QParams qp,
                                                  const double* __restrict__ Echain, int16_t* __restrict__ tmp) {
-    int f = blockIdx.x;
+    const int f = blockIdx.x / 3, c = blockIdx.x % 3;
     if (skip[f]) return;
+    __shared__ QSlot slots[2][QW];
     const int16_t* d = diff + (size_t)f * HW * 3;
     const uint8_t* o = orig + (size_t)f * HW * 3;
     int16_t* t = tmp + (size_t)f * HW * 3;
-    const int c = threadIdx.x >> 6;  // wave == channel
-    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double E = 0.0;
     if (qp.mode == TZ_MODE_ABS) E = fabs(qp.b0);
     else if (qp.mode != TZ_MODE_PWREL) E = Echain[f * 3 + c];
     const double inf = __builtin_huge_val();
-    double u = inf, l = -inf;  // state of the run that is open at the chunk boundary
-    int chead = 0;             // its head (chain index)
     const int nch = (HW + 63) >> 6;
-    for (int ch = 0; ch < nch; ++ch) {
-        const int idx = ch * 64 + lane;
-        double du = inf, dl = -inf;
-        if (idx < HW) {
-            double e = qp.mode == TZ_MODE_PWREL ? (double)o[(size_t)idx * 3 + c] * qp.b0 : E;
-            double df = (double)d[(size_t)idx * 3 + c];
-            du = df + e;
-            dl = df - e;
-        }
-        // 1. range tables (level 0 is the element itself); shfl_down past lane 63 returns the
-        //    caller's own value, which clamps the range at the chunk end
-        double tu[6], tl[6];
-        tu[0] = du;
-        tl[0] = dl;
+    const int nrounds = (nch + QW - 1) / QW;
+    double u = inf, l = -inf;  // resolver: state of the run that is open at the chunk boundary
+    int chead = 0;             // resolver: its head (chain index)
+    for (int r = 0; r <= nrounds; ++r) {
+        if (wv > 0 && r < nrounds) {
+            const int ch = r * QW + (wv - 1);
+            if (ch < nch) {
+                const int idx = ch * 64 + lane;
+                double du = inf, dl = -inf;
+                if (idx < HW) {
+                    double e = qp.mode == TZ_MODE_PWREL ? (double)o[(size_t)idx * 3 + c] * qp.b0 : E;
+                    double df = (double)d[(size_t)idx * 3 + c];
+                    du = df + e;
+                    dl = df - e;
+                }
+                // 1. range tables (level 0 is the element itself); shfl_down past lane 63 returns
+                //    the caller's own value, which clamps the range at the chunk end
+                double tu[6], tl[6];
+                tu[0] = du;
+                tl[0] = dl;
 #pragma unroll
-        for (int k = 1; k < 6; ++k) {
-            double a = __shfl_down(tu[k - 1], 1 << (k - 1), 64), b = __shfl_down(tl[k - 1], 1 << (k - 1), 64);
-            tu[k] = tu[k - 1] < a ? tu[k - 1] : a;
-            tl[k] = tl[k - 1] > b ? tl[k - 1] : b;
-        }
-        // 3a. inclusive prefix from the chunk start
-        double pu = du, pl = dl;
+                for (int k = 1; k < 6; ++k) {
+                    double a = __shfl_down(tu[k - 1], 1 << (k - 1), 64), b = __shfl_down(tl[k - 1], 1 << (k - 1), 64);
+                    tu[k] = tu[k - 1] < a ? tu[k - 1] : a;
+                    tl[k] = tl[k - 1] > b ? tl[k - 1] : b;
+                }
+                // 3. inclusive prefix from the chunk start
+                double pu = du, pl = dl;
 #pragma unroll
-        for (int sft = 1; sft < 64; sft <<= 1) {
-            double a = __shfl_up(pu, sft, 64), b = __shfl_up(pl, sft, 64);
-            if (lane >= sft) {
-                pu = pu < a ? pu : a;
-                pl = pl > b ? pl : b;
+                for (int sft = 1; sft < 64; sft <<= 1) {
+                    double a = __shfl_up(pu, sft, 64), b = __shfl_up(pl, sft, 64);
+                    if (lane >= sft) {
+                        pu = pu < a ? pu : a;
+                        pl = pl > b ? pl : b;
+                    }
+                }
+                // 2. binary lifting: longest break-free extension of a run that starts at this lane
+                double cu = du, cl = dl;
+                int pos = lane + 1;
+#pragma unroll
+                for (int k = 5; k >= 0; --k) {
+                    const int step = 1 << k;
+                    int src = pos < 63 ? pos : 63;
+                    double xu = shfl_d(tu[k], src), xl = shfl_d(tl[k], src);
+                    double nu = cu < xu ? cu : xu, nl = cl > xl ? cl : xl;
+                    bool ok = (pos + step <= 64) && !(nu - nl < 0.0);
+                    if (ok) {
+                        cu = nu;
+                        cl = nl;
+                        pos += step;
+                    }
+                }
+                QSlot& sl = slots[r & 1][wv - 1];
+                sl.cu[lane] = cu;
+                sl.cl[lane] = cl;
+                sl.pu[lane] = pu;
+                sl.pl[lane] = pl;
+                sl.nxt[lane] = pos;  // in [lane+1, 64]; 64 = the run leaves the chunk
+                // 2b. pointer doubling: the set of run heads reached from a start at this lane
+                unsigned long long M = 1ull << lane;
+                int J = pos;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    int src = J < 64 ? J : lane;
+                    unsigned long long Mj = __shfl(M, src, 64);
+                    int Jj = __shfl(J, src, 64);
+                    if (J < 64) {
+                        M |= Mj;
+                        J = Jj;
+                    }
+                }
+                sl.heads[lane] = M;
+            }
+        } else if (wv == 0 && r > 0) {
+            for (int w = 0; w < QW; ++w) {
+                const int ch = (r - 1) * QW + w;
+                if (ch >= nch) break;
+                const QSlot& sl = slots[(r - 1) & 1][w];
+                const double pu = sl.pu[lane], pl = sl.pl[lane];
+                // 4. where does the carried run break?
+                double eu = u < pu ? u : pu, el = l > pl ? l : pl;
+                unsigned long long brk = __ballot(eu - el < 0.0);
+                if (brk == 0ull) {
+                    u = shfl_d(eu, 63);
+                    l = shfl_d(el, 63);
+                    continue;
+                }
+                const int j0 = __ffsll((long long)brk) - 1;
+                {
+                    double uc = u, lc = l;
+                    if (j0 > 0) {
+                        uc = shfl_d(eu, j0 - 1);
+                        lc = shfl_d(el, j0 - 1);
+                    }
+                    if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
+                }
+                const int nxt = sl.nxt[lane];
+                const unsigned long long heads = sl.heads[j0];
+                const int last = 63 - __clzll((long long)heads);
+                // 5. closed runs store their value at their head; the last head carries on
+                const double cu = sl.cu[lane], cl = sl.cl[lane];
+                if (((heads >> lane) & 1ull) && nxt < 64)
+                    t[(size_t)(ch * 64 + lane) * 3 + c] = (int16_t)(long long)((cu + cl) / 2);
+                u = shfl_d(cu, last);
+                l = shfl_d(cl, last);
+                chead = ch * 64 + last;
             }
         }
-        // 2. binary lifting: longest break-free extension of a run that starts at this lane
-        double cu = du, cl = dl;
-        int pos = lane + 1;
-#pragma unroll
-        for (int k = 5; k >= 0; --k) {
-            const int step = 1 << k;
-            int src = pos < 63 ? pos : 63;
-            double xu = shfl_d(tu[k], src), xl = shfl_d(tl[k], src);
-            double nu = cu < xu ? cu : xu, nl = cl > xl ? cl : xl;
-            bool ok = (pos + step <= 64) && !(nu - nl < 0.0);
-            if (ok) {
-                cu = nu;
-                cl = nl;
-                pos += step;
-            }
-        }
-        const int nxt = pos;  // in [lane+1, 64]; 64 = the run leaves the chunk
-        // 3b. where does the carried run break?
-        double eu = u < pu ? u : pu, el = l > pl ? l : pl;
-        unsigned long long brk = __ballot(eu - el < 0.0);
-        if (brk == 0ull) {
-            u = shfl_d(eu, 63);
-            l = shfl_d(el, 63);
-            continue;
-        }
-        const int j0 = __ffsll((long long)brk) - 1;
-        {
-            double uc = u, lc = l;
-            if (j0 > 0) {
-                uc = shfl_d(eu, j0 - 1);
-                lc = shfl_d(el, j0 - 1);
-            }
-            if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
-        }
-        // 4. heads of this chunk
-        unsigned long long heads = 0ull;
-        int h = j0, last = j0;
-        while (h < 64) {
-            heads |= 1ull << h;
-            last = h;
-            h = __builtin_amdgcn_readlane(nxt, h);
-        }
-        // 5. closed runs store their value at their head; the last head carries on
-        if (((heads >> lane) & 1ull) && nxt < 64) t[(size_t)idx * 3 + c] = (int16_t)(long long)((cu + cl) / 2);
-        u = shfl_d(cu, last);
-        l = shfl_d(cl, last);
-        chead = ch * 64 + last;
+        __syncthreads();
     }
-    if (lane == 0 && HW > 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((u + l) / 2);
+    if (wv == 0 && lane == 0 && HW > 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((u + l) / 2);
 }
 
 static constexpr int QFB = 2048;  // pixels per fill block
@@ -357,7 +399,7 @@ int tzk_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8
                            (double*)d_E);
     hipLaunchKernelGGL(k_q_init, dim3(grid_for(fe * nframes, 256)), dim3(256), 0, ctx->stream, (int16_t*)d_tmp,
                        (const uint8_t*)d_skip, fe, nframes);
-    hipLaunchKernelGGL(k_q_heads, dim3(nframes), dim3(192), 0, ctx->stream, orig, (const int16_t*)diff,
+    hipLaunchKernelGGL(k_q_heads, dim3(nframes * 3), dim3(512), 0, ctx->stream, orig, (const int16_t*)diff,
                        (const uint8_t*)d_skip, HW, qp, (const double*)d_E, (int16_t*)d_tmp);
     hipLaunchKernelGGL(k_q_last, dim3(nblk, nframes), dim3(256), 0, ctx->stream, (const int16_t*)d_tmp,
                        (const uint8_t*)d_skip, HW, nblk, (int16_t*)d_carry);
