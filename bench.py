@@ -58,6 +58,24 @@ def turbulence_cuda(nt, h, w, seed, device):
     return out.round().clamp(0, 255).to(torch.uint8).contiguous()
 
 
+def measured_traffic(prefix):
+    """Per-launch HBM bytes of the kernels whose name starts with `prefix`, from the committed
+    rocprofv3 PMC summary of this same bench command (profiles/CURRENT -> traffic.json, made by
+    profiles/collect.sh + profiles/summarize.py; FETCH_SIZE/WRITE_SIZE corrected per
+    MI355X_MICROARCH.md).  None when no profile is committed."""
+    try:
+        cur = open(os.path.join(ROOT, "profiles", "CURRENT")).read().strip()
+        t = json.load(open(os.path.join(ROOT, "profiles", cur, "traffic.json")))
+        num = den = 0.0
+        for k, v in t.items():
+            if k.startswith(prefix) and "hbm_bytes_per_launch" in v:
+                num += v["hbm_bytes_per_launch"] * v.get("launches", 1)
+                den += v.get("launches", 1)
+        return num / den if den else None
+    except Exception:
+        return None
+
+
 def live_flops_per_px0(cfg):
     """MACs*2 per level-0 pixel that the per-frame path executes (SURVEY.md §8d 'live work',
     minus the r_{t-1} part of the gate convolutions, which is constant per model and folded
@@ -190,11 +208,11 @@ def main():
             "compression_ratio": ratio,
             "roofline": {"kernel": "k_conv3x3 (fp32 MFMA implicit GEMM, all PredNet convolutions)", "bound": "mfma",
                          "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic("k_conv3x3"),
                          "launches_per_step": conv_n, "ms_per_step": conv_ms,
                          "algorithmic_flops_per_step": flops_step},
             "roofline_delta": {"kernel": "k_delta_flat", "bound": "hbm", "achieved": delta_gbs, "peak": PEAK_HBM_GBS,
-                               "unit": "GB/s", "frac": delta_gbs / PEAK_HBM_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": delta_gbs / PEAK_HBM_GBS, "traffic": measured_traffic("k_delta_flat"),
                                "bytes_per_launch": delta_bytes, "ms_per_launch": delta_ms / max(delta_n, 1)},
             "kernel_ms_per_step": {k: v[0] for k, v in prof.items()},
             "cpu_baseline": cpu,
