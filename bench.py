@@ -165,6 +165,14 @@ def main():
     delta_bytes = 7.0 * NT * H * W * 3  # f32 pred + u8 orig in, i16 out
     delta_gbs = delta_bytes / (delta_ms * 1e-3) / 1e9 if delta_ms > 0 else 0.0
 
+    # ---- host-buffer (PCIe-inclusive) rate of the same step: informational, never `value`
+    host_frames = frames.cpu().numpy()
+    host_payload = np.empty(NT * H * W * 3, np.int16)
+    t1 = time.perf_counter()
+    ctx.rollout(host_frames, WARM_UP, WINDOW)
+    ctx.encode(MODE, BOUND, True, payload=host_payload)
+    pcie_fps = NT / (time.perf_counter() - t1)
+
     # ---- compression ratio (untimed; same libzstd for both files, level 9 as the reference)
     ratio = None
     if rank == 0:
@@ -206,6 +214,7 @@ def main():
                                    "lossy rel 1e-3, entropy remap on; PredNet (3,48,96,192) glorot seed 123",
                        "frames_per_step": NT, "predicted_frames_per_step": n_pred, "sharding": "one sequence per GPU"},
             "compression_ratio": ratio,
+            "pcie_inclusive_frames_per_s_rank0": pcie_fps,
             "roofline": {"kernel": "k_conv3x3 (fp32 MFMA implicit GEMM, all PredNet convolutions)", "bound": "mfma",
                          "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic("k_conv3x3"),
