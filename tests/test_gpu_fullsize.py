@@ -1,0 +1,93 @@
+"""BASELINE.json frame sizes on the GPU, checked through size-independent properties (the oracle
+would take minutes here): compress -> decompress round trips, the error bound as the reference
+defines it (|err| <= E, +1 for the truncated median, compress.py:61), encoder and decoder
+regenerating identical predictions, batch invariance, and a spot check of a few windows of the
+quantiser and one prediction against the C oracle."""
+import numpy as np
+import pytest
+
+from tezip_amd import synth
+from tezip_amd.prednet import PredNetConfig
+
+pytestmark = pytest.mark.gpu
+
+CFG = PredNetConfig()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tezip_amd import _lib
+    c = _lib.Context(0)
+    c.load_model(CFG, CFG.init_weights(seed=123))
+    yield c
+    c.close()
+
+
+def _roundtrip(ctx, frames, p, window, thr, mode, bound, entropy=True):
+    key, _ = ctx.rollout(frames, p, window, thr)
+    enc_pred = ctx.get_predictions()
+    payload, table, delta = ctx.encode(mode, bound, entropy, want_delta=True)
+    key_stack = np.zeros_like(frames)
+    key_stack[key] = frames[key]
+    kd = ctx.rollout_decode(key_stack, p)
+    dec_pred = ctx.get_predictions()
+    dec = ctx.decode(payload, table)
+    return key, kd, enc_pred, dec_pred, payload, table, delta, dec
+
+
+@pytest.mark.parametrize("mode,bound,tol", [("abs", [0.0], 0), ("rel", [1e-3], 0), ("abs", [2.0], 3), ("pwrel", [0.02], 7)])
+def test_cfg3_512_roundtrip(ctx, mode, bound, tol):
+    frames = synth.turbulence(24, 512, 512, seed=3)
+    ctx.prepare(512, 512, max_batch=4)
+    key, kd, ep, dp, payload, table, delta, dec = _roundtrip(ctx, frames, 0, 6, None, mode, bound)
+    assert key.tolist() == [i % 6 == 0 for i in range(24)] and (kd == key).all()
+    # the decoder regenerates the encoder's predictions bit for bit (every non-key slot)
+    assert np.array_equal(ep[~key], dp[~key])
+    assert payload.shape == (24 * 512 * 512 * 3,) and 0 < len(table) <= 1021
+    assert int(payload.min()) >= 0 and int(payload.max()) < len(table)
+    err = np.abs(dec.astype(np.int16) - frames.astype(np.int16))
+    assert int(err.max()) <= tol
+    if tol == 0:
+        assert np.array_equal(dec, frames)
+    assert (delta[key] == 0).all()
+
+
+def test_cfg3_quantiser_and_prediction_spot_check_vs_oracle(ctx):
+    from oracle import coracle
+    frames = synth.turbulence(8, 512, 512, seed=4)
+    ctx.prepare(512, 512, max_batch=2)
+    key, _ = ctx.rollout(frames, 0, 4)
+    pred = ctx.get_predictions()
+    raw = ctx.delta_encode(pred, frames, key.astype(np.uint8))
+    _, _, delta = ctx.encode("abs", [2.0], True, want_delta=True)
+    for f in (1, 6):  # whole-frame chains of 262,144 elements
+        np.testing.assert_array_equal(delta[f], coracle.error_bound_frame(frames[f], raw[f], "abs", [2.0]))
+    net = coracle.CPredNet(CFG.init_weights(seed=123), CFG.stack_sizes, CFG.R_stack_sizes, 512, 512)
+    np.testing.assert_array_equal(pred[1], net.next(coracle.u8_to_f32_frame(frames[0], 512, 512)))
+    np.testing.assert_array_equal(pred[0], net.c0())
+
+
+def test_cfg4_1024_lossy_and_dwp(ctx):
+    frames = synth.detector(10, 1024, 1024, seed=4)
+    ctx.prepare(1024, 1024, max_batch=2)
+    key, kd, ep, dp, payload, table, delta, dec = _roundtrip(ctx, frames, 0, 5, None, "abs", [2.0])
+    assert key.tolist() == [True, False, False, False, False] * 2
+    assert np.array_equal(ep[~key], dp[~key])
+    assert int(np.abs(dec.astype(np.int16) - frames.astype(np.int16)).max()) <= 3
+    # DWP on the same data: windows come from the MSE threshold; still a lossless round trip
+    ctx.prepare(1024, 1024, max_batch=2)
+    k1, mse = ctx.rollout(frames, 1, None, 1e9, want_mse=True)
+    assert k1.tolist() == [True, True] + [False] * 8 and (np.diff(mse[2:]) != 0).any()
+    thr = float(np.sort(mse[2:])[len(mse[2:]) // 2])
+    key, kd, ep, dp, payload, table, delta, dec = _roundtrip(ctx, frames, 1, None, thr, "abs", [0.0])
+    assert 2 < key.sum() < 10 and np.array_equal(dec, frames)
+
+
+def test_batch_invariance_of_the_rollout(ctx):
+    frames = synth.turbulence(16, 512, 512, seed=5)
+    ctx.prepare(512, 512, max_batch=4)
+    ctx.rollout(frames, 0, 4)
+    a = ctx.get_predictions()
+    ctx.prepare(512, 512, max_batch=1)  # same windows, one at a time
+    ctx.rollout(frames, 0, 4)
+    assert np.array_equal(a, ctx.get_predictions())

@@ -410,6 +410,7 @@ struct tz_model {
     int stack[TZ_MAX_LEVELS] = {0}, rstack[TZ_MAX_LEVELS] = {0};
     std::vector<std::vector<float>> w;  // Keras list order
     int Hp = 0, Wp = 0, maxB = 0;
+    int cap = 0;  // windows advanced together (<= maxB, the allocated batch)
     bool prepared = false;
     float *R0[TZ_MAX_LEVELS] = {0}, *C0[TZ_MAX_LEVELS] = {0}, *Ahat0[TZ_MAX_LEVELS] = {0}, *G0[TZ_MAX_LEVELS] = {0};
     float *E[TZ_MAX_LEVELS] = {0}, *R1[TZ_MAX_LEVELS] = {0};
@@ -618,7 +619,10 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
     if ((Hp % (1 << (L - 1))) || (Wp % (1 << (L - 1))) || (Hp % 8) || (Wp % 8))
         return tz_fail(ctx, TZ_ERR_INVALID,
                        "Image size is out of scope for this model: padded size %dx%d must divide by 8 and 2^(levels-1)", Hp, Wp);
-    if (m->prepared && m->Hp == Hp && m->Wp == Wp && m->maxB >= max_batch) return TZ_OK;
+    if (m->prepared && m->Hp == Hp && m->Wp == Wp && m->maxB >= max_batch) {
+        m->cap = max_batch;
+        return TZ_OK;
+    }
     // rebuild from the kept host weights
     {
         std::vector<std::vector<float>> w = std::move(m->w);
@@ -634,6 +638,7 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
     m->Hp = Hp;
     m->Wp = Wp;
     m->maxB = max_batch;
+    m->cap = max_batch;
     auto hl = [&](int l) { return Hp >> l; };
     auto wl = [&](int l) { return Wp >> l; };
     for (int l = 0; l < L; ++l) {
@@ -725,7 +730,7 @@ int tz_model_dims(tz_ctx* ctx, int* Hp, int* Wp, int* max_batch) {
     if (!m || !m->prepared) return tz_fail(ctx, TZ_ERR_STATE, "model not prepared");
     *Hp = m->Hp;
     *Wp = m->Wp;
-    *max_batch = m->maxB;
+    *max_batch = m->cap;
     return TZ_OK;
 }
 
