@@ -56,6 +56,11 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
     }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
+    ctx->ring_size = 1 << 20;
+    if (hipHostMalloc((void**)&ctx->ring, ctx->ring_size, hipHostMallocDefault) != hipSuccess) {
+        ctx->ring = nullptr;
+        ctx->ring_size = 0;
+    }
     *out = ctx;
     return TZ_OK;
 }
@@ -74,6 +79,7 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
         }
+    if (ctx->ring) (void)hipHostFree(ctx->ring);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -142,6 +148,25 @@ int tz_ensure(tz_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
     return TZ_OK;
 }
 
+int tz_upload(tz_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return TZ_OK;
+    size_t need = (bytes + 63) & ~(size_t)63;
+    if (!ctx->ring || need > ctx->ring_size / 4) {  // large or no ring: blocking copy
+        TZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return TZ_OK;
+    }
+    if (ctx->ring_pos + need > ctx->ring_size) {  // wrap: everything queued so far must have left the ring
+        TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->ring_pos = 0;
+    }
+    uint8_t* slot = ctx->ring + ctx->ring_pos;
+    ctx->ring_pos += need;
+    memcpy(slot, src, bytes);
+    TZ_HIP(ctx, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return TZ_OK;
+}
+
 int tz_dev_in(tz_ctx* ctx, const void* p, size_t bytes, const void** dev) {
     if (bytes == 0 || tz_is_device_ptr(p)) {
         *dev = p;
@@ -150,6 +175,7 @@ int tz_dev_in(tz_ctx* ctx, const void* p, size_t bytes, const void** dev) {
     void* d;
     TZ_TRY(tz_pool_alloc(ctx, bytes, &d));
     TZ_HIP(ctx, hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's host buffer is free again on return
     *dev = d;
     return TZ_OK;
 }
@@ -303,7 +329,7 @@ static int fill_c0(tz_ctx* ctx, const std::vector<int>& slots) {
     size_t fe = (size_t)ctx->Hp * ctx->Wp * 3;
     void* d_slots;
     TZ_TRY(tz_pool_alloc(ctx, slots.size() * sizeof(int), &d_slots));
-    TZ_HIP(ctx, hipMemcpyAsync(d_slots, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    TZ_TRY(tz_upload(ctx, d_slots, slots.data(), slots.size() * sizeof(int)));
     int gx = (int)std::min<size_t>((fe + 255) / 256, 1024);
     hipLaunchKernelGGL(k_bcast_frame, dim3(gx, (unsigned)slots.size()), dim3(256), 0, ctx->stream, c0, fe,
                        (const int*)d_slots, (int)slots.size(), ctx->d_pred);
@@ -588,10 +614,7 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
         rc = tz_pool_alloc(ctx, N * 2, &d_delta);
     }
     if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_mask);
-    if (rc == TZ_OK) {
-        hipError_t e = hipMemcpyAsync(d_mask, ctx->group_first.data(), nt, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
-    }
+    if (rc == TZ_OK) rc = tz_upload(ctx, d_mask, ctx->group_first.data(), nt);
     // compress.py:292-314
     if (rc == TZ_OK) rc = tzk_delta(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt, H, W, ctx->Hp, ctx->Wp, (int16_t*)d_delta);
     // compress.py:315-319
@@ -636,10 +659,7 @@ extern "C" int tz_encode_delta(tz_ctx* ctx, int mode, double b0, double b1, int1
     int rc = tz_dev_out(ctx, delta_out, N * 2, &o);
     if (rc == TZ_OK) outs.push_back(o);
     if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_mask);
-    if (rc == TZ_OK) {
-        hipError_t e = hipMemcpyAsync(d_mask, ctx->group_first.data(), nt, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
-    }
+    if (rc == TZ_OK) rc = tz_upload(ctx, d_mask, ctx->group_first.data(), nt);
     if (rc == TZ_OK) rc = tzk_delta(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt, H, W, ctx->Hp, ctx->Wp, (int16_t*)o.dev);
     if (rc == TZ_OK) rc = tzk_error_bound(ctx, ctx->d_frames, (int16_t*)o.dev, ctx->quant_skip.data(), nt, H, W, mode, b0, b1);
     if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
@@ -660,10 +680,7 @@ extern "C" int tz_decode_delta(tz_ctx* ctx, const int16_t* delta, uint8_t* frame
     if (rc == TZ_OK) rc = tz_dev_out(ctx, frames_out, N, &o);
     if (rc == TZ_OK) outs.push_back(o);
     if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_mask);
-    if (rc == TZ_OK) {
-        hipError_t e = hipMemcpyAsync(d_mask, ctx->key_mask.data(), nt, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
-    }
+    if (rc == TZ_OK) rc = tz_upload(ctx, d_mask, ctx->key_mask.data(), nt);
     if (rc == TZ_OK)
         rc = tzk_reconstruct(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, (const int16_t*)d_diff, nt, H, W,
                              ctx->Hp, ctx->Wp, (uint8_t*)o.dev);
@@ -687,10 +704,7 @@ extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, const int16_t* tab
     if (rc == TZ_OK) outs.push_back(o);
     if (rc == TZ_OK) rc = tz_pool_alloc(ctx, N * 2, &d_diff);
     if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_mask);
-    if (rc == TZ_OK) {
-        hipError_t e = hipMemcpyAsync(d_mask, ctx->key_mask.data(), nt, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
-    }
+    if (rc == TZ_OK) rc = tz_upload(ctx, d_mask, ctx->key_mask.data(), nt);
     const int16_t* sd = (const int16_t*)d_pay;
     if (rc == TZ_OK && table_len >= 0) {  // decompress.py:203-236
         std::vector<int16_t> lut;
@@ -723,17 +737,13 @@ extern "C" int tz_delta_encode(tz_ctx* ctx, const float* pred, const uint8_t* or
     int rc = tz_dev_in(ctx, pred, (size_t)nframes * Hp * Wp * 3 * 4, &dp);
     if (rc == TZ_OK) rc = tz_dev_in(ctx, orig, N, &dor);
     if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nframes, &dm);
-    if (rc == TZ_OK && nframes) {
-        hipError_t e = hipMemcpyAsync(dm, zm.data(), nframes, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
-    }
+    if (rc == TZ_OK && nframes) rc = tz_upload(ctx, dm, zm.data(), nframes);
     if (rc == TZ_OK) rc = tz_dev_out(ctx, out, N * 2, &o);
     if (rc == TZ_OK) {
         outs.push_back(o);
         rc = tzk_delta(ctx, (const float*)dp, (const uint8_t*)dor, (const uint8_t*)dm, nframes, H, W, Hp, Wp, (int16_t*)o.dev);
     }
     if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
-    if (rc == TZ_OK && !outs.empty() && !outs[0].host) rc = tz_ctx_synchronize(ctx);  // zm is a stack-local upload
     tz_pool_release_all(ctx);
     return rc;
 }
@@ -758,7 +768,6 @@ extern "C" int tz_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, c
         rc = tzk_error_bound(ctx, (const uint8_t*)dor, (int16_t*)o.dev, sk.data(), nframes, H, W, mode, b0, b1);
     }
     if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
-    if (rc == TZ_OK && !outs.empty() && !outs[0].host) rc = tz_ctx_synchronize(ctx);
     tz_pool_release_all(ctx);
     return rc;
 }
@@ -801,7 +810,6 @@ static int lut_op(tz_ctx* ctx, const int16_t* in, size_t n, const std::vector<in
         rc = tzk_lut(ctx, (const int16_t*)din, n, lut.data(), 0, post, (int16_t*)o.dev);
     }
     if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
-    if (rc == TZ_OK && !o.host) rc = tz_ctx_synchronize(ctx);  // the LUT upload reads a local vector
     tz_pool_release_all(ctx);
     return rc;
 }
@@ -852,10 +860,7 @@ extern "C" int tz_reconstruct(tz_ctx* ctx, const float* pred, const uint8_t* key
     if (rc == TZ_OK && key_frames) rc = tz_dev_in(ctx, key_frames, N, &dk);
     if (rc == TZ_OK) rc = tz_dev_in(ctx, diff, N * 2, &dd);
     if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nframes, &dm);
-    if (rc == TZ_OK && nframes) {
-        hipError_t e = hipMemcpyAsync(dm, km.data(), nframes, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
-    }
+    if (rc == TZ_OK && nframes) rc = tz_upload(ctx, dm, km.data(), nframes);
     if (rc == TZ_OK) rc = tz_dev_out(ctx, out, N, &o);
     if (rc == TZ_OK) {
         outs.push_back(o);
@@ -863,7 +868,6 @@ extern "C" int tz_reconstruct(tz_ctx* ctx, const float* pred, const uint8_t* key
                              W, Hp, Wp, (uint8_t*)o.dev);
     }
     if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
-    if (rc == TZ_OK && !o.host) rc = tz_ctx_synchronize(ctx);
     tz_pool_release_all(ctx);
     return rc;
 }

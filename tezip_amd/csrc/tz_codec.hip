@@ -391,7 +391,7 @@ int tzk_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8
     TZ_TRY(tz_pool_alloc(ctx, sizeof(double) * 3 * nframes, &d_E));
     TZ_TRY(tz_pool_alloc(ctx, fe * nframes * 2, &d_tmp));
     TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * nblk * 3 * 2, &d_carry));
-    TZ_HIP(ctx, hipMemcpyAsync(d_skip, h_skip, nframes, hipMemcpyHostToDevice, ctx->stream));
+    TZ_TRY(tz_upload(ctx, d_skip, h_skip, nframes));
     QParams qp{mode, b0, b1};
     tz_prof_scope ps(ctx, TZP_QUANT);
     if (mode == TZ_MODE_REL || mode == TZ_MODE_ABSREL)
@@ -519,7 +519,7 @@ int tzk_lut(tz_ctx* ctx, const int16_t* in, size_t n, const int16_t* h_lut2112, 
         return tz_fail(ctx, TZ_ERR_INVALID, "remap buffers must be 16-byte aligned");
     void* d_lut;
     TZ_TRY(tz_pool_alloc(ctx, (TZ_NBINS + 1) * 2, &d_lut));
-    TZ_HIP(ctx, hipMemcpyAsync(d_lut, h_lut2112, (TZ_NBINS + 1) * 2, hipMemcpyHostToDevice, ctx->stream));
+    TZ_TRY(tz_upload(ctx, d_lut, h_lut2112, (TZ_NBINS + 1) * 2));
     tz_prof_scope ps(ctx, TZP_LUT);
     hipLaunchKernelGGL(k_lut, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, ctx->stream, in, n, (const int16_t*)d_lut,
                        post_offset, out);

@@ -53,6 +53,10 @@ struct tz_ctx {
     std::vector<uint8_t> group_first; // nt: 1 where a group starts (delta slot 0 -> 0)
     std::vector<uint8_t> quant_skip;  // nt: 1 where error_bound is not applied
     bool have_rollout = false, rollout_is_decode = false;
+    // pinned staging ring for small host->device uploads (index arrays, masks, LUTs): the copy
+    // out of it is truly asynchronous and the memory outlives the caller's locals
+    uint8_t* ring = nullptr;
+    size_t ring_size = 0, ring_pos = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool prof_on = false;
@@ -80,6 +84,8 @@ bool tz_is_device_ptr(const void* p);
 int tz_pool_alloc(tz_ctx* ctx, size_t bytes, void** out);   // freed by tz_pool_release_all
 void tz_pool_release_all(tz_ctx* ctx);
 int tz_ensure(tz_ctx* ctx, void** buf, size_t* cap, size_t bytes);  // persistent buffer growth
+// Stream-ordered upload of a small host block to `dst` (device) through the pinned ring.
+int tz_upload(tz_ctx* ctx, void* dst, const void* src, size_t bytes);
 
 // Input argument: returns a device pointer holding `bytes` of *p (staging if host).
 int tz_dev_in(tz_ctx* ctx, const void* p, size_t bytes, const void** dev);

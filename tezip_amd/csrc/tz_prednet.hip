@@ -756,7 +756,7 @@ int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int
         idx[m->maxB + i] = h_in_idx[i];
         idx[2 * m->maxB + i] = h_out_idx[i];
     }
-    TZ_HIP(ctx, hipMemcpyAsync(m->d_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice, ctx->stream));
+    TZ_TRY(tz_upload(ctx, m->d_idx, idx.data(), sizeof(int) * idx.size()));
     auto hl = [&](int l) { return Hp >> l; };
     auto wl = [&](int l) { return Wp >> l; };
     auto npx = [&](int l) { return (long long)hl(l) * wl(l); };
