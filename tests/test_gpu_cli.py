@@ -81,3 +81,18 @@ def test_wrong_model_size_is_reported_like_the_reference(tmp_path, capsys):
     with pytest.raises(SystemExit):
         compress.run(mdir, ddir, str(tmp_path / "c"), 0, 2, None, "abs", [0.0], True, False, True)
     assert "ERROR:Image size is out of scope for this model." in capsys.readouterr().out
+
+
+def test_cli_with_the_reference_model_files(tmp_path):
+    """Model directory exactly as the reference leaves it: prednet_model.json + Keras
+    prednet_weights.hdf5 (fixture written by real h5py, read by the built-in reader)."""
+    from PIL import Image
+    from conftest import GOLDEN
+    mdir = os.path.join(GOLDEN, "keras_style_model")
+    frames = synth.translating_scene(9, 16, 24, seed=12)
+    ddir = _write(tmp_path, frames, False)
+    cdir, udir = str(tmp_path / "comp"), str(tmp_path / "out")
+    compress.run(mdir, ddir, cdir, 0, 3, None, "abs", [0.0], True, False, True)
+    decompress.run(mdir, cdir, udir, True, False)
+    got = np.stack([np.array(Image.open(os.path.join(udir, "frame_%03d.png" % t))) for t in range(9)])
+    np.testing.assert_array_equal(got, frames)

@@ -115,3 +115,20 @@ def test_load_images_rules(tmp_path):
     with redirect_stdout(buf), pytest.raises(SystemExit):
         compress.load_images(str(tmp_path / "nothing"))
     assert "is an empty or non-existent directory" in buf.getvalue()
+
+
+def test_reads_the_reference_hdf5_checkpoint_without_h5py():
+    """tests/golden/keras_style_model was written by real h5py in the layout of Keras 2.2.4's
+    ModelCheckpoint (train.py:109); the built-in reader must return exactly those arrays."""
+    mdir = os.path.join(GOLDEN, "keras_style_model")
+    cfg, w, shape = weights.load_model(mdir)
+    assert cfg.stack_sizes == (3, 16) and shape == (16, 24)
+    ref = PredNetConfig(stack_sizes=(3, 16)).init_weights(seed=77, bias_scale=0.1)
+    assert len(w) == len(ref) == 22
+    for a, b in zip(w, ref):
+        assert a.dtype == np.float32 and a.shape == b.shape and (a == b).all()
+    from tezip_amd import h5lite
+    every = h5lite.H5File(os.path.join(mdir, weights.H5_NAME)).walk()
+    assert "/model_weights/time_distributed_1/time_distributed_1/kernel:0" in every
+    with pytest.raises(ValueError):
+        h5lite.H5File(os.path.join(GOLDEN, "ref_runs.npz"))

@@ -6,9 +6,9 @@ PredNet layer from them (compress.py:143-173).  Here:
   * prednet_model.json is read the same way (the PredNet layer's config gives the channel
     stacks, the InputLayer's batch_input_shape the padded frame size);
   * weights are read from `prednet_weights.npz` (this build's native format: arrays
-    w000..wNNN in the Keras weight-list order of prednet.py:210-227), or from
-    `prednet_weights.hdf5` when an h5py module is importable (it is not part of the image this
-    was built in; `python -m tezip_amd.weights convert <model_dir>` converts wherever it is).
+    w000..wNNN in the Keras weight-list order of prednet.py:210-227), or from the reference's
+    `prednet_weights.hdf5` -- with h5py when it is importable, otherwise with the built-in
+    minimal reader tezip_amd/h5lite.py (h5py is not part of the image this was built in).
 """
 import json
 import os
@@ -113,9 +113,9 @@ def load_model(model_dir):
     elif os.path.exists(h5):
         try:
             weights = _load_h5(h5, cfg)
-        except ImportError:
-            raise OSError("%s needs h5py, which is not installed: convert it once with "
-                          "`python -m tezip_amd.weights convert %s` on a machine that has h5py" % (h5, model_dir))
+        except ImportError:  # no h5py in this image: the built-in reader covers Keras' files
+            from . import h5lite
+            weights = h5lite.load_prednet_weights(h5, [n for n, _ in cfg.weight_shapes()])
     else:
         raise OSError("No such file or directory: %s" % h5)
     shapes = cfg.weight_shapes()
