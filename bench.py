@@ -79,12 +79,13 @@ def measured_traffic(prefix):
 def live_flops_per_px0(cfg):
     """MACs*2 per level-0 pixel that the per-frame path executes (SURVEY.md §8d 'live work',
     minus the r_{t-1} part of the gate convolutions, which is constant per model and folded
-    into G0 at prepare time)."""
+    into G0 at prepare time, and with the upsampled source up(r_{l+1}) evaluated through 4
+    collapsed taps instead of 9: DESIGN.md §3)."""
     st, rs, L = cfg.stack_sizes, cfg.R_stack_sizes, cfg.nb_layers
     mac = 0.0
     for l in range(L):
-        cin = 2 * st[l] + (rs[l + 1] if l < L - 1 else 0)
-        mac += 9 * cin * 4 * rs[l] / 4 ** l          # t1 gates over [e_l, up(r_{l+1})]
+        taps_ch = 9 * 2 * st[l] + (4 * rs[l + 1] if l < L - 1 else 0)
+        mac += taps_ch * 4 * rs[l] / 4 ** l          # t1 gates over [e_l (9 taps), up(r_{l+1}) (4 taps)]
         if l < L - 1:
             mac += 9 * 2 * st[l] * st[l + 1] / 4 ** l  # t0 A conv
     mac += 9 * rs[0] * st[0]                          # Ahat_0 at t1

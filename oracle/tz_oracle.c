@@ -6,9 +6,11 @@
  *     histogram, remap, inverse scan, reconstruct.  Citations are into /root/reference/src.
  *  2. The PredNet forward pass (prednet.py:143-308) in the canonical arithmetic "TZ-PA1":
  *       conv[y,x,co] = b[co]; for source s in concat order, for each block of 16 channels of
- *                      s, for ky, kx, for ci in the block:
- *                         acc = fmaf(in_s[y+ky-1][x+kx-1][ci], W[ky][kx][coff_s+ci][co], acc)
- *     ('same' zero padding; upsampled sources read in[(y')>>1][(x')>>1]); activations from
+ *                      s, for each tap, for ci in the block: acc = fmaf(x, w, acc)
+ *     ('same' zero padding; same-resolution sources use the 9 taps (ky,kx); the upsampled
+ *     source up(r_{l+1}) is read at half resolution with 4 collapsed taps whose weights are
+ *     float32 sums of the 3x3 taps hitting the same half-resolution pixel: see conv3x3);
+ *     activations from
  *     tz_math.h.  The reference's predictor arithmetic lives in keras==2.2.4 /
  *     tensorflow-gpu==1.15 (docs/index.rst:263-264), which are not under /root/reference and
  *     not installable here: PARITY UNPINNED for the predictor.  TZ-PA1 is this build's own
@@ -197,12 +199,56 @@ typedef struct {
     int up; /* 1: stored at half resolution, nearest-upsampled x2 on read (prednet.py:264) */
 } tzo_src;
 
-/* Canonical conv: out[y][x][co] = chain(bias; sources in order; ky; kx; ci). W is HWIO with
- * I = sum of source channels. */
+/* 3x3 taps of an upsampled source that read the same half-resolution pixel, for output parity
+ * a (0 even / 1 odd coordinate) and collapsed tap d: a=0: {0},{1,2}; a=1: {0,1},{2}. */
+static int collapse_set(int a, int d, int out[2]) {
+    if (a == 0) {
+        if (d == 0) { out[0] = 0; return 1; }
+        out[0] = 1; out[1] = 2; return 2;
+    }
+    if (d == 0) { out[0] = 0; out[1] = 1; return 2; }
+    out[0] = 2; return 1;
+}
+
+/* Canonical conv (TZ-PA1): out[y][x][co] = chain(bias; sources in concat order; blocks of 16
+ * channels; taps; ci).  Same-resolution source: the 9 taps (ky, kx).  Upsampled source
+ * (prednet.py:264 followed by the 3x3 conv): read at half resolution with 4 collapsed taps
+ * (dy, dx); their weights are the float32 sums (ascending ky, kx) of the 3x3 taps that land on
+ * the same half-resolution pixel for the parity of (y, x).  Mathematically the same convolution.
+ * W is HWIO with I = sum of source channels. */
 static void conv3x3(const tzo_src* src, int nsrc, int H, int W, const float* Wt, const float* bias, int Cout,
                     float* out) {
     int Cin = 0;
     for (int s = 0; s < nsrc; ++s) Cin += src[s].C;
+    /* collapsed weights of upsampled sources: Wc[s][cls][tp][ci][co] */
+    float* Wc[4] = {0, 0, 0, 0};
+    {
+        int coff = 0;
+        for (int s = 0; s < nsrc; ++s) {
+            int C = src[s].C;
+            if (src[s].p && src[s].up) {
+                Wc[s] = (float*)malloc(sizeof(float) * 16 * (size_t)C * Cout);
+                for (int cls = 0; cls < 4; ++cls)
+                    for (int tp = 0; tp < 4; ++tp) {
+                        int kys[2], kxs[2];
+                        int nky = collapse_set(cls >> 1, tp >> 1, kys), nkx = collapse_set(cls & 1, tp & 1, kxs);
+                        for (int ci = 0; ci < C; ++ci)
+                            for (int co = 0; co < Cout; ++co) {
+                                float v = 0.0f;
+                                int first = 1;
+                                for (int iy = 0; iy < nky; ++iy)
+                                    for (int ix = 0; ix < nkx; ++ix) {
+                                        float w = Wt[((size_t)(kys[iy] * 3 + kxs[ix]) * Cin + coff + ci) * Cout + co];
+                                        v = first ? w : v + w;
+                                        first = 0;
+                                    }
+                                Wc[s][(((size_t)cls * 4 + tp) * C + ci) * Cout + co] = v;
+                            }
+                    }
+            }
+            coff += C;
+        }
+    }
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < H; ++y) {
         float* acc = (float*)malloc(sizeof(float) * (size_t)Cout);
@@ -211,16 +257,13 @@ static void conv3x3(const tzo_src* src, int nsrc, int H, int W, const float* Wt,
             int coff = 0;
             for (int s = 0; s < nsrc; ++s) {
                 int C = src[s].C;
-                if (src[s].p) { /* an all-zero source leaves every chain unchanged */
+                if (src[s].p && !src[s].up) { /* an all-zero source leaves every chain unchanged */
                     for (int c0 = 0; c0 < C; c0 += 16) /* blocks of 16 input channels */
                         for (int ky = 0; ky < 3; ++ky)
                             for (int kx = 0; kx < 3; ++kx) {
                                 int yy = y + ky - 1, xx = x + kx - 1;
                                 int inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
-                                const float* ip = NULL;
-                                if (inside)
-                                    ip = src[s].up ? src[s].p + ((size_t)(yy >> 1) * (W >> 1) + (xx >> 1)) * C
-                                                   : src[s].p + ((size_t)yy * W + xx) * C;
+                                const float* ip = inside ? src[s].p + ((size_t)yy * W + xx) * C : NULL;
                                 const float* wp = Wt + ((size_t)(ky * 3 + kx) * Cin + coff) * Cout;
                                 int c1 = c0 + 16 < C ? c0 + 16 : C;
                                 for (int ci = c0; ci < c1; ++ci) {
@@ -229,6 +272,21 @@ static void conv3x3(const tzo_src* src, int nsrc, int H, int W, const float* Wt,
                                     for (int co = 0; co < Cout; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
                                 }
                             }
+                } else if (src[s].p) {
+                    int H2 = H >> 1, W2 = W >> 1, cls = ((y & 1) << 1) | (x & 1);
+                    for (int c0 = 0; c0 < C; c0 += 16)
+                        for (int tp = 0; tp < 4; ++tp) {
+                            int ly = (y >> 1) - 1 + (y & 1) + (tp >> 1), lx = (x >> 1) - 1 + (x & 1) + (tp & 1);
+                            int inside = ly >= 0 && ly < H2 && lx >= 0 && lx < W2;
+                            const float* ip = inside ? src[s].p + ((size_t)ly * W2 + lx) * C : NULL;
+                            const float* wp = Wc[s] + ((size_t)cls * 4 + tp) * C * Cout;
+                            int c1 = c0 + 16 < C ? c0 + 16 : C;
+                            for (int ci = c0; ci < c1; ++ci) {
+                                float xv = inside ? ip[ci] : 0.0f;
+                                const float* wr = wp + (size_t)ci * Cout;
+                                for (int co = 0; co < Cout; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+                            }
+                        }
                 }
                 coff += C;
             }
@@ -236,6 +294,7 @@ static void conv3x3(const tzo_src* src, int nsrc, int H, int W, const float* Wt,
         }
         free(acc);
     }
+    for (int s = 0; s < 4; ++s) free(Wc[s]);
 }
 
 tzo_model* tzo_model_create(int L, const int* stack, const int* rstack, int Hp, int Wp, const float* const* w) {

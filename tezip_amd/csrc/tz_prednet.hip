@@ -13,9 +13,13 @@
 //
 // Arithmetic contract TZ-PA1 (bit-exact with oracle/tz_oracle.c): every convolution output is
 // ONE float32 fmaf chain: acc = bias; for source in concat order, for each block of 16 input
-// channels, for ky, kx, for ci in the block: acc = fmaf(x, w, acc).  The MFMA k-loop below walks
-// exactly that order; out-of-image taps and channel padding contribute fmaf(0, w, acc) = acc.
-// No split-K, no atomics: results do not depend on batch size, grid shape or device.
+// channels, for each tap, for ci in the block: acc = fmaf(x, w, acc).  Taps of a same-resolution
+// source are the 9 (ky, kx); an upsampled source up(r_{l+1}) is read at HALF resolution with 4
+// collapsed taps (dy, dx) whose weights are the float32 sums of the 3x3 taps that land on the
+// same half-resolution pixel for the output pixel's parity (2.25x fewer MACs for that source).
+// The MFMA k-loop below walks exactly that order; out-of-image taps and channel padding
+// contribute fmaf(0, w, acc) = acc.  No split-K, no atomics: results do not depend on batch
+// size, grid shape or device.
 //
 // Tiling: workgroup = 8 waves = 16x16 output pixels (256 GEMM rows) x NT*16 output columns;
 // each wave owns 32 rows x NT*16 columns = 2 x NT MFMA tiles (acc in registers).  For every
@@ -24,7 +28,7 @@
 // L2/Infinity-Cache traffic: 53 % L2 hit rate, profiles/r01); the per-tap 16 x (NT*16) weight
 // chunk is double-buffered in LDS, one barrier per tap.  The next patch is prefetched into
 // registers during the 9 taps.  LDS row strides (18 / NT*16[+16] floats) keep fragment reads
-// conflict free.  ~33 KB LDS, ~90 VGPRs, 512 threads => 2 workgroups (16 waves) per CU.
+// conflict free.  33-44 KB LDS, <=100 VGPRs, 512 threads => 3 workgroups (24 waves) per CU.
 #include <algorithm>
 
 #include "tz_internal.h"
@@ -62,20 +66,33 @@ struct ConvArgs {
     int R;              // EPI_LSTM_PACKED: channels per gate
 };
 
-static constexpr int SA = 18;    // LDS row stride of one halo-patch pixel (16 channels + 2 pad floats)
-static constexpr int PW = 18;    // halo patch is PW x PW pixels around the 16x16 output tile
+static constexpr int SA = 18;    // LDS row stride of one patch pixel (16 channels + 2 pad floats)
+static constexpr int PW = 18;    // same-resolution halo patch: PW x PW pixels around the 16x16 tile
 static constexpr int PPIX = PW * PW;
+static constexpr int LW = 10;    // half-resolution patch of an upsampled source: LW x LW pixels
+static constexpr int LPIX = LW * LW;
+static constexpr int NTHR = 512;                         // 8 waves, each owns two 16-row MFMA tiles
+static constexpr int MT = 2;
 static constexpr int A_ITEMS = PPIX * 4;                 // float4 items of one patch channel block
-static constexpr int NTHR = 512;                         // 8 waves: wave w owns tile rows 2w, 2w+1
-static constexpr int MT = 2;                             // 16-row MFMA tiles per wave
 static constexpr int A_PER_THREAD = (A_ITEMS + NTHR - 1) / NTHR;  // 3
 
-template <bool POOL>
+enum { MAP_LINEAR = 0, MAP_POOL = 1, MAP_PARITY = 2 };
+
+// GEMM row m (0..255) of the workgroup -> pixel (py, px) of its 16x16 output tile.
+//  LINEAR: wave w = rows 2w, 2w+1 of the tile.
+//  POOL:   the 4 accumulator registers of a lane form one 2x2 pooling window.
+//  PARITY: every 16-row MFMA tile holds pixels of ONE parity class (py&1, px&1), so that the
+//          parity-specific collapsed weights of an upsampled source can be its B operand.
+template <int MAP>
 __device__ __forceinline__ void row_to_patch(int m, int& py, int& px) {
     int w = m >> 5, mt = (m >> 4) & 1, r16 = m & 15;
-    if (POOL) {  // the 4 accumulator registers of a lane form one 2x2 pooling window
+    if (MAP == MAP_POOL) {
         py = 2 * w + ((r16 & 3) >> 1);
         px = 8 * mt + 2 * (r16 >> 2) + (r16 & 1);
+    } else if (MAP == MAP_PARITY) {
+        int T = 2 * w + mt, pc = T >> 2, sub = T & 3;
+        py = 2 * (2 * sub + (r16 >> 3)) + (pc >> 1);
+        px = 2 * (r16 & 7) + (pc & 1);
     } else {
         py = 2 * w + mt;
         px = r16;
@@ -90,14 +107,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int NT, int EPI>
-__global__ __launch_bounds__(NTHR, 4) void k_conv3x3(const ConvArgs a) {
-    constexpr bool POOL = EPI == EPI_POOL_ERR;
+template <int NT, int EPI, bool UPS>
+__global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
+    constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : ((EPI == EPI_LSTM || EPI == EPI_LSTM_PACKED) ? MAP_PARITY : MAP_LINEAR);
     constexpr int NTC = NT * 16;
     constexpr int SB = NTC + ((NTC % 32) == 0 ? 16 : 0);
-    constexpr int BVEC = 16 * NTC / 4;  // float4 loads for one B chunk
+    constexpr int QPR = NTC / 4;                     // float4 items per weight row
+    constexpr int BVEC = 16 * QPR;                   // items of a same-resolution chunk (16 k-rows)
+    constexpr int UPH = NT == 4 ? 8 : 16;            // k-rows of an upsampled-source step (per class)
+    constexpr int UPN = 16 / UPH;                    // steps per collapsed tap
+    constexpr int BUF = (UPS ? 4 * UPH : 16) * SB;   // floats per weight buffer (up: 4 classes x UPH rows)
+    static_assert((!UPS || 4 * UPH * QPR <= NTHR) && BVEC <= NTHR, "one weight item per thread");
     __shared__ float sA[PPIX * SA];
-    __shared__ float sB[2][16 * SB];
+    __shared__ float sB[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -107,20 +129,10 @@ __global__ __launch_bounds__(NTHR, 4) void k_conv3x3(const ConvArgs a) {
     const int tile = bid % ntiles, n = bid / ntiles;
     const int ty0 = (tile / a.tiles_x) * 16, tx0 = (tile % a.tiles_x) * 16;
 
-    // ---- staging roles
-    // A: the 18x18x16 halo patch = 1296 float4 items; item i -> patch pixel i>>2, channel quad i&3
-    int apix[A_PER_THREAD];  // (yy << 16) | xx of the item's global pixel, or -1 outside the image
-#pragma unroll
-    for (int j = 0; j < A_PER_THREAD; ++j) {
-        int i = tid + NTHR * j;
-        int pp = i >> 2;
-        int yy = ty0 - 1 + pp / PW, xx = tx0 - 1 + pp % PW;
-        apix[j] = (i < A_ITEMS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? ((yy << 16) | xx) : -1;
-    }
+    // ---- A staging roles.  Same-resolution source: 18x18x16 halo patch = 1296 float4 items,
+    // item i -> patch pixel i>>2, channel quad i&3.  Upsampled source: 10x10x16 = 400 items of
+    // the half-resolution map (item i = tid).
     const int aq = tid & 3;
-    const int b_row = NT == 4 ? (tid >> 4) : (NT == 3 ? tid / 12 : (tid >> 2));
-    const int b_quad = NT == 4 ? (tid & 15) : (NT == 3 ? tid % 12 : (tid & 3));
-    const bool b_active = tid < BVEC;
 
     float4 ra[A_PER_THREAD];
     float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -128,46 +140,71 @@ __global__ __launch_bounds__(NTHR, 4) void k_conv3x3(const ConvArgs a) {
     const int nb0 = a.nsrc > 0 ? a.src[0].cpt : 0;
     const int nblk = nb0 + (a.nsrc > 1 ? a.src[1].cpt : 0);
 
+    auto load_quad = [&](const ConvSrc& s, const float* ptr, int c0) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((s.C & 3) == 0) {
+            v = *(const float4*)ptr;
+        } else {
+            v.x = ptr[0];
+            if (c0 + 1 < s.C) v.y = ptr[1];
+            if (c0 + 2 < s.C) v.z = ptr[2];
+            if (c0 + 3 < s.C) v.w = ptr[3];
+        }
+        return v;
+    };
     auto load_patch = [&](int blk) {
         const ConvSrc& s = blk >= nb0 ? a.src[1] : a.src[0];
         const int c0 = (blk >= nb0 ? blk - nb0 : blk) * 16 + 4 * aq;
         const float* base = s.p + (long long)n * s.nstride;
-        const int Ws = a.W >> s.up;
-        const bool vec = (s.C & 3) == 0;
-#pragma unroll
-        for (int j = 0; j < A_PER_THREAD; ++j) {
+        // (pixel coordinates are recomputed per block rather than kept in registers)
+        if (UPS && s.up) {
+            const int pp = tid >> 2;
+            const int ly = (ty0 >> 1) - 1 + pp / LW, lx = (tx0 >> 1) - 1 + pp % LW;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (apix[j] >= 0 && c0 < s.C) {
-                int yy = apix[j] >> 16, xx = apix[j] & 0xffff;
-                const float* ptr = base + ((long long)(yy >> s.up) * Ws + (xx >> s.up)) * s.C + c0;
-                if (vec) {
-                    v = *(const float4*)ptr;
-                } else {
-                    v.x = ptr[0];
-                    if (c0 + 1 < s.C) v.y = ptr[1];
-                    if (c0 + 2 < s.C) v.z = ptr[2];
-                    if (c0 + 3 < s.C) v.w = ptr[3];
-                }
+            if (pp < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1) && c0 < s.C)
+                v = load_quad(s, base + ((long long)ly * (a.W >> 1) + lx) * s.C + c0, c0);
+            ra[0] = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_PER_THREAD; ++j) {
+                const int i = tid + NTHR * j, pp = i >> 2;
+                const int yy = ty0 - 1 + pp / PW, xx = tx0 - 1 + pp % PW;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < A_ITEMS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && c0 < s.C)
+                    v = load_quad(s, base + ((long long)yy * a.W + xx) * s.C + c0, c0);
+                ra[j] = v;
             }
-            ra[j] = v;
         }
     };
-    auto store_patch = [&]() {
+    auto store_patch = [&](bool up) {
 #pragma unroll
         for (int j = 0; j < A_PER_THREAD; ++j) {
             int i = tid + NTHR * j;
-            if (i < A_ITEMS) {
+            if (up ? (j == 0 && i < LPIX * 4) : (i < A_ITEMS)) {
                 float* d = sA + (i >> 2) * SA + 4 * aq;
                 *(float2*)d = make_float2(ra[j].x, ra[j].y);
                 *(float2*)(d + 2) = make_float2(ra[j].z, ra[j].w);
             }
         }
     };
-    auto load_b = [&](int chunk) {
-        if (b_active) rb = *(const float4*)(a.Wp + ((long long)chunk * 16 + b_row) * a.ncols + cb * NTC + 4 * b_quad);
+    // Weight staging, one float4 per thread and step.  Same-resolution step: the 16 k-rows of
+    // one (block, tap).  Upsampled step: UPH k-rows (part `hf` of the block) of one collapsed tap
+    // for each of the 4 parity classes; the packed file keeps 16 rows per (tap, class) slot.
+    auto load_b = [&](int slot, bool up, int hf) {
+        if (UPS && up) {
+            int cls = tid / (UPH * QPR), r = tid - cls * (UPH * QPR);
+            if (tid < 4 * UPH * QPR)
+                rb = *(const float4*)(a.Wp + ((long long)(slot + cls) * 16 + UPH * hf + r / QPR) * a.ncols + cb * NTC + 4 * (r % QPR));
+        } else if (tid < BVEC) {
+            rb = *(const float4*)(a.Wp + ((long long)slot * 16 + tid / QPR) * a.ncols + cb * NTC + 4 * (tid % QPR));
+        }
     };
-    auto store_b = [&](int buf) {
-        if (b_active) *(float4*)(sB[buf] + b_row * SB + 4 * b_quad) = rb;
+    auto store_b = [&](int buf, bool up) {
+        if (UPS && up) {
+            if (tid < 4 * UPH * QPR) *(float4*)(sB + buf * BUF + (tid / QPR) * SB + 4 * (tid % QPR)) = rb;  // row = cls*UPH + r
+        } else if (tid < BVEC) {
+            *(float4*)(sB + buf * BUF + (tid / QPR) * SB + 4 * (tid % QPR)) = rb;
+        }
     };
 
     // ---- accumulators: acc[mt][nt], element r <-> GEMM row (lane>>4)*4 + r, column lane&15
@@ -175,7 +212,7 @@ __global__ __launch_bounds__(NTHR, 4) void k_conv3x3(const ConvArgs a) {
     const int col0 = cb * NTC + (lane & 15);
     auto out_pix = [&](int mt, int r, int& y, int& x) {
         int py, px;
-        row_to_patch<POOL>(wv * 32 + mt * 16 + (lane >> 4) * 4 + r, py, px);
+        row_to_patch<MAP>(wv * 32 + mt * 16 + (lane >> 4) * 4 + r, py, px);
         y = ty0 + py;
         x = tx0 + px;
     };
@@ -196,51 +233,81 @@ __global__ __launch_bounds__(NTHR, 4) void k_conv3x3(const ConvArgs a) {
             }
         }
 
-    // ---- K loop: channel blocks of 16 (patch staged once), 9 taps each (weights double-buffered)
+    // ---- K loop: blocks of 16 input channels (patch staged once per block).  A same-resolution
+    // source runs 9 steps per block (one tap each, 2 or 4 k-steps of 4 channels); an upsampled
+    // source runs 4*UPN steps (4 collapsed taps x UPN parts of UPH channels; the weights of the 3x3
+    // taps that hit the same half-resolution pixel were summed at pack time, per parity class).
+    // Every step: prefetch next weights -> MFMAs from LDS -> store next weights -> one barrier.
     if (nblk > 0) {
-        // LDS offsets of this lane's A rows inside the patch (tap 0,0 = patch origin)
-        int arow[MT];
+        int arow_hi[MT], arow_lo[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             int py, px;
-            row_to_patch<POOL>(wv * 32 + mt * 16 + (lane & 15), py, px);
-            arow[mt] = (py * PW + px) * SA + (lane >> 4);
+            row_to_patch<MAP>(wv * 32 + mt * 16 + (lane & 15), py, px);
+            arow_hi[mt] = (py * PW + px) * SA + (lane >> 4);
+            arow_lo[mt] = (((py >> 1) + (py & 1)) * LW + (px >> 1) + (px & 1)) * SA + (lane >> 4);
         }
-        const float* pb0 = sB[0] + (lane >> 4) * SB + (lane & 15);
+        const int wcls = MAP == MAP_PARITY ? (wv >> 1) : 0;  // parity class of this wave's rows
+        const int boff = (lane >> 4) * SB + (lane & 15);
+        bool up = UPS && a.src[nb0 > 0 ? 0 : 1].up != 0;
         load_patch(0);
-        load_b(0);
-        store_patch();
-        store_b(0);
+        load_b(0, up, 0);
+        store_patch(up);
+        store_b(0, up);
         __syncthreads();
-        int cur = 0;
+        int cur = 0, slot0 = 0;
         for (int blk = 0; blk < nblk; ++blk) {
+            const ConvSrc& s = blk >= nb0 ? a.src[1] : a.src[0];
+            up = UPS && s.up != 0;
+            const int nsteps = up ? 4 * UPN : 9;
+            const int cw = s.C - (blk >= nb0 ? blk - nb0 : blk) * 16;
             const bool more_blk = blk + 1 < nblk;
+            const bool up_next = UPS && more_blk && (blk + 1 >= nb0 ? a.src[1].up : a.src[0].up) != 0;
             if (more_blk) load_patch(blk + 1);
 #pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
-                const bool more = more_blk || tap < 8;
-                if (more) load_b(blk * 9 + tap + 1);
-                const int toff = ((tap / 3) * PW + (tap % 3)) * SA;
-                const float* pb = pb0 + cur * (16 * SB);
+            for (int st = 0; st < nsteps; ++st) {
+                const bool last = st == nsteps - 1;
+                if (!last) load_b(up ? slot0 + 4 * ((st + 1) / UPN) : slot0 + st + 1, up, (st + 1) % UPN);
+                else if (more_blk) load_b(slot0 + (up ? 16 : 9), up_next, 0);
+                // one compute body for both kinds of step: the first pair of k-steps always runs,
+                // the second pair only when the step holds more than 8 channels
+                const int tap = up ? st / UPN : st;
+                const int toff = (up ? ((tap >> 1) * LW + (tap & 1)) : ((tap / 3) * PW + (tap % 3))) * SA;
+                const bool second = up ? (UPH == 16) : (cw > 8);
+                const float* pa = sA + toff + (up ? UPH * (st % UPN) : 0);
+                const float* pb = sB + cur * BUF + boff + (up ? wcls * UPH * SB : 0);
+                int ar[MT];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    float fa[MT], fb[NT];
+                for (int mt = 0; mt < MT; ++mt) ar[mt] = up ? arow_lo[mt] : arow_hi[mt];
+                // (kept as ONE loop nest: duplicating the MFMA body per k-step count made hipcc
+                // spill accumulators inside the loop under the 80-VGPR budget, 4x slower)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) fa[mt] = sA[arow[mt] + toff + 4 * kk];
+                for (int pair = 0; pair < 2; ++pair) {
+                    if (pair == 0 || second) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) fb[nt] = pb[4 * kk * SB + nt * 16];
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            const int kk = 2 * pair + k2;
+                            float fa[MT], fb[NT];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+                            for (int mt = 0; mt < MT; ++mt) fa[mt] = pa[ar[mt] + 4 * kk];
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+                            for (int nt = 0; nt < NT; ++nt) fb[nt] = pb[4 * kk * SB + nt * 16];
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+                        }
+                    }
                 }
-                if (more) store_b(cur ^ 1);
+                if (!last) store_b(cur ^ 1, up);
+                else if (more_blk) store_b(cur ^ 1, up_next);
                 __syncthreads();
                 cur ^= 1;
             }
+            slot0 += up ? 16 : 9;
             if (more_blk) {
-                store_patch();
+                store_patch(up_next);
                 __syncthreads();
             }
         }
@@ -397,6 +464,7 @@ __global__ __launch_bounds__(256) void k_err0(const uint8_t* __restrict__ frames
 // ------------------------------------------------------------------------------- host side
 struct Seg {
     int row_off, C;
+    int up;  // 1: half-resolution source read through a x2 nearest upsample (collapsed taps)
 };
 struct PackedConv {
     float* d_W = nullptr;
@@ -447,26 +515,63 @@ struct ColSrc {
 };
 
 // Pack weights into the chunk order walked by k_conv3x3: for seg, 16-channel block, tap.
+// 3x3 taps of an upsampled source that read the same half-resolution pixel, for output parity
+// a (0 even / 1 odd coordinate) and collapsed tap d (0/1): a=0: {0},{1,2}; a=1: {0,1},{2}.
+static int collapse_set(int a, int d, int out[2]) {
+    if (a == 0) {
+        if (d == 0) { out[0] = 0; return 1; }
+        out[0] = 1; out[1] = 2; return 2;
+    }
+    if (d == 0) { out[0] = 0; out[1] = 1; return 2; }
+    out[0] = 2; return 1;
+}
+
+// Pack weights into the slot order walked by k_conv3x3: for seg, 16-channel block, then either
+// 9 taps (same-resolution source) or 4 collapsed taps x 4 parity classes (upsampled source,
+// weights summed in float32 in ascending (ky, kx) order: part of TZ-PA1).
 static int pack_conv(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, const std::vector<ColSrc>& cols, int NT,
                      PackedConv* pc) {
     int ncols = (int)cols.size();
-    int nchunks = 0;
-    for (auto& s : segs) nchunks += 9 * ((s.C + 15) / 16);
-    std::vector<float> W((size_t)std::max(nchunks, 1) * 16 * ncols, 0.0f), B(ncols, 0.0f);
-    int chunk = 0;
-    for (auto& s : segs)
-        for (int c0 = 0; c0 < s.C; c0 += 16)
-            for (int tap = 0; tap < 9; ++tap, ++chunk)
-                for (int kc = 0; kc < 16 && c0 + kc < s.C; ++kc)
-                    for (int col = 0; col < ncols; ++col) {
-                        const ColSrc& cs = cols[col];
-                        if (cs.ch < 0) continue;
-                        W[((size_t)chunk * 16 + kc) * ncols + col] =
-                            cs.kernel[((size_t)tap * cs.Cin + s.row_off + c0 + kc) * cs.Cout + cs.ch];
+    int nslots = 0;
+    for (auto& s : segs) nslots += (s.up ? 16 : 9) * ((s.C + 15) / 16);
+    std::vector<float> W((size_t)std::max(nslots, 1) * 16 * ncols, 0.0f), B(ncols, 0.0f);
+    int slot = 0;
+    auto put = [&](const Seg& s, int c0, const int* kys, int nky, const int* kxs, int nkx) {
+        for (int kc = 0; kc < 16 && c0 + kc < s.C; ++kc)
+            for (int col = 0; col < ncols; ++col) {
+                const ColSrc& cs = cols[col];
+                if (cs.ch < 0) continue;
+                float v = 0.0f;
+                bool first = true;
+                for (int iy = 0; iy < nky; ++iy)
+                    for (int ix = 0; ix < nkx; ++ix) {
+                        float w = cs.kernel[((size_t)(kys[iy] * 3 + kxs[ix]) * cs.Cin + s.row_off + c0 + kc) * cs.Cout + cs.ch];
+                        v = first ? w : v + w;
+                        first = false;
                     }
+                W[((size_t)slot * 16 + kc) * ncols + col] = v;
+            }
+        ++slot;
+    };
+    for (auto& s : segs)
+        for (int c0 = 0; c0 < s.C; c0 += 16) {
+            if (!s.up) {
+                for (int tap = 0; tap < 9; ++tap) {
+                    int ky = tap / 3, kx = tap % 3;
+                    put(s, c0, &ky, 1, &kx, 1);
+                }
+            } else {
+                for (int tp = 0; tp < 4; ++tp)
+                    for (int cls = 0; cls < 4; ++cls) {
+                        int kys[2], kxs[2];
+                        int nky = collapse_set(cls >> 1, tp >> 1, kys), nkx = collapse_set(cls & 1, tp & 1, kxs);
+                        put(s, c0, kys, nky, kxs, nkx);
+                    }
+            }
+        }
     for (int col = 0; col < ncols; ++col)
         if (cols[col].ch >= 0) B[col] = cols[col].bias[cols[col].ch];
-    pc->nchunks = nchunks;
+    pc->nchunks = nslots;
     pc->ncols = ncols;
     pc->NT = NT;
     pc->ncb = ncols / (16 * NT);
@@ -513,26 +618,29 @@ static int gate_cols(tz_ctx* ctx, const tz_model* m, int l, std::vector<ColSrc>*
     return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "R_stack_sizes[%d]=%d: need a multiple of 16 or <= 4", l, R);
 }
 
-template <int NT, int EPI>
+template <int NT, int EPI, bool UPS>
 static void launch_conv_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
     int blocks = a.ncb * a.tiles_x * a.tiles_y * nbatch;
-    hipLaunchKernelGGL((k_conv3x3<NT, EPI>), dim3(blocks), dim3(NTHR), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k_conv3x3<NT, EPI, UPS>), dim3(blocks), dim3(NTHR), 0, ctx->stream, a);
 }
 
 static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbatch) {
     tz_prof_scope ps(ctx, TZP_CONV);
-#define TZ_CASE(nt, e)                   \
-    if (NT == nt && epi == e) {          \
-        launch_conv_t<nt, e>(ctx, a, nbatch); \
-        TZ_HIP(ctx, hipGetLastError());  \
-        return TZ_OK;                    \
+    bool ups = false;
+    for (int s = 0; s < a.nsrc; ++s) ups = ups || a.src[s].up;
+#define TZ_CASE(nt, e, u)                      \
+    if (NT == nt && epi == e && ups == u) {    \
+        launch_conv_t<nt, e, u>(ctx, a, nbatch); \
+        TZ_HIP(ctx, hipGetLastError());        \
+        return TZ_OK;                          \
     }
-    TZ_CASE(1, EPI_RAW) TZ_CASE(4, EPI_RAW)
-    TZ_CASE(1, EPI_RELU) TZ_CASE(3, EPI_RELU) TZ_CASE(4, EPI_RELU)
-    TZ_CASE(4, EPI_LSTM) TZ_CASE(1, EPI_LSTM_PACKED)
-    TZ_CASE(1, EPI_POOL_ERR) TZ_CASE(3, EPI_POOL_ERR) TZ_CASE(4, EPI_POOL_ERR)
+    TZ_CASE(1, EPI_RAW, false) TZ_CASE(4, EPI_RAW, false)
+    TZ_CASE(1, EPI_RELU, false) TZ_CASE(3, EPI_RELU, false) TZ_CASE(4, EPI_RELU, false)
+    TZ_CASE(4, EPI_LSTM, false) TZ_CASE(4, EPI_LSTM, true)
+    TZ_CASE(1, EPI_LSTM_PACKED, false) TZ_CASE(1, EPI_LSTM_PACKED, true)
+    TZ_CASE(1, EPI_POOL_ERR, false) TZ_CASE(3, EPI_POOL_ERR, false) TZ_CASE(4, EPI_POOL_ERR, false)
 #undef TZ_CASE
-    return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "no conv kernel for NT=%d epilogue=%d", NT, epi);
+    return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "no conv kernel for NT=%d epilogue=%d upsampled=%d", NT, epi, (int)ups);
 }
 
 static void fill_srcs(ConvArgs& a, const PackedConv& pc, const float* const* ptrs, const long long* nstrides,
@@ -543,10 +651,11 @@ static void fill_srcs(ConvArgs& a, const PackedConv& pc, const float* const* ptr
         a.src[s].p = ptrs[s];
         a.src[s].nstride = nstrides[s];
         a.src[s].C = pc.segs[s].C;
-        a.src[s].up = ups[s];
+        a.src[s].up = pc.segs[s].up;
         a.src[s].cpt = (pc.segs[s].C + 15) / 16;
         a.src[s].chunk_base = base;
-        base += 9 * a.src[s].cpt;
+        base += (pc.segs[s].up ? 16 : 9) * a.src[s].cpt;
+        (void)ups;
     }
     a.nchunks = pc.nchunks;
     a.Wp = pc.d_W;
@@ -658,7 +767,7 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         int NT;
         TZ_TRY(gate_cols(ctx, m, l, &cols, &NT));
         std::vector<Seg> segs;
-        if (l < L - 1) segs.push_back(Seg{m->rstack[l] + 2 * m->stack[l], m->rstack[l + 1]});
+        if (l < L - 1) segs.push_back(Seg{m->rstack[l] + 2 * m->stack[l], m->rstack[l + 1], 1});
         PackedConv pc;
         TZ_TRY(pack_conv(ctx, m, segs, cols, NT, &pc));
         ConvArgs a;
@@ -678,7 +787,7 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
     for (int l = 0; l < L; ++l) {
         int Cout = m->stack[l], NT = plain_nt(Cout);
         PackedConv pc;
-        TZ_TRY(pack_conv(ctx, m, {Seg{0, m->rstack[l]}}, plain_cols(m->ahat_k(l), m->ahat_b(l), m->rstack[l], Cout), NT, &pc));
+        TZ_TRY(pack_conv(ctx, m, {Seg{0, m->rstack[l], 0}}, plain_cols(m->ahat_k(l), m->ahat_b(l), m->rstack[l], Cout), NT, &pc));
         if (l == 0) m->ahat0_t1 = pc;
         ConvArgs a;
         memset(&a, 0, sizeof(a));
@@ -698,7 +807,7 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         int NT;
         TZ_TRY(gate_cols(ctx, m, l, &cols, &NT));
         PackedConv pg;
-        TZ_TRY(pack_conv(ctx, m, {Seg{0, m->rstack[l]}}, cols, NT, &pg));
+        TZ_TRY(pack_conv(ctx, m, {Seg{0, m->rstack[l], 0}}, cols, NT, &pg));
         size_t npx = (size_t)hl(l) * wl(l);
         TZ_TRY(dmalloc(ctx, m, (void**)&m->G0[l], npx * pg.ncols * 4));
         ConvArgs a;
@@ -710,14 +819,14 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         set_geom(a, hl(l), wl(l));
         a.out0 = m->G0[l];
         TZ_TRY(launch_conv(ctx, NT, EPI_RAW, a, 1));
-        std::vector<Seg> segs = {Seg{m->rstack[l], 2 * m->stack[l]}};
-        if (l < L - 1) segs.push_back(Seg{m->rstack[l] + 2 * m->stack[l], m->rstack[l + 1]});
+        std::vector<Seg> segs = {Seg{m->rstack[l], 2 * m->stack[l], 0}};
+        if (l < L - 1) segs.push_back(Seg{m->rstack[l] + 2 * m->stack[l], m->rstack[l + 1], 1});
         TZ_TRY(pack_conv(ctx, m, segs, cols, NT, &m->gate_t1[l]));
     }
     // ---- A convs (prednet.py:290)
     for (int l = 0; l < L - 1; ++l) {
         int Cout = m->stack[l + 1], NT = plain_nt(Cout);
-        TZ_TRY(pack_conv(ctx, m, {Seg{0, 2 * m->stack[l]}}, plain_cols(m->a_k(l), m->a_b(l), 2 * m->stack[l], Cout), NT,
+        TZ_TRY(pack_conv(ctx, m, {Seg{0, 2 * m->stack[l], 0}}, plain_cols(m->a_k(l), m->a_b(l), 2 * m->stack[l], Cout), NT,
                          &m->a_conv[l]));
     }
     TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
