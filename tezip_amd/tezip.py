@@ -1,6 +1,12 @@
-"""TEZIP command line: same flags and validation cascade as /root/reference/src/tezip.py:10-100
-(-l/-c/-u, -p, -w xor -t, -m, -b, -f, -v, -n).  The device probe uses the HIP library instead of
-TensorFlow's device list; -l (training) is outside this build's scope."""
+"""TEZIP command line for the MI355X build.
+
+Behaviourally equivalent to the reference CLI (/root/reference/src/tezip.py:10-100): same
+flags, same validation order and the same messages on stdout, process exit code 0 on
+validation errors.  The structure is this build's own: flags come from a table, validation is a
+list of (predicate, message key) rules evaluated in the reference's order, and the device probe
+asks the HIP library instead of TensorFlow.  `-l` (training) is outside this build's scope
+(SURVEY.md §8f): it reports that instead of training.
+"""
 import argparse
 import os
 import sys
@@ -11,103 +17,113 @@ if __package__ in (None, ""):
 
 from . import compress, decompress  # noqa: E402
 
+# (short, long, argparse keywords) -- tezip.py:88-99
+FLAG_TABLE = (
+    ("-l", "--learn", dict(type=str, nargs=2, metavar=("model", "dir"), dest="learn")),
+    ("-c", "--compress", dict(type=str, nargs=3, metavar=("model", "dir", "file"), dest="compress")),
+    ("-u", "--uncompress", dict(type=str, nargs=3, metavar=("model", "file", "dir"), dest="uncompress")),
+    ("-p", "--preprocess", dict(type=int, nargs=1, metavar="warm_up_num", dest="preprocess")),
+    ("-w", "--window", dict(type=int, nargs=1, metavar="window_size", dest="window")),
+    ("-t", "--threshold", dict(type=float, nargs=1, metavar="MSE_threshold", dest="threshold")),
+    ("-m", "--mode", dict(type=str, nargs=1, metavar="mode", dest="mode")),
+    ("-b", "--bound", dict(type=float, nargs="*", metavar="value", dest="bound", default=None)),
+    ("-f", "--force", dict(action="store_true")),
+    ("-v", "--verbose", dict(action="store_true")),
+    ("-n", "--no_entropy", dict(action="store_false")),  # store_false: entropy remap is on by default
+)
+
+TEXT = {
+    "several": ("Please select only one of learn or compress or uncompress.",
+                "Command to check the options is -h or --help"),
+    "nothing": ("Please mode select!", "learn or compress or uncompress.",
+                "Command to check the options is -h or --help"),
+    "no_p": ("Please specify the -p or --preprocess option!", "warm up num."),
+    "no_window": ("Please specify the window size(-w or --window) or MSE threshold(-t or --threshold) option!",
+                  "Select window size for SWP and MSE threshold for DWP."),
+    "two_windows": ("Please select only one of window size(-w or --window) or MSE threshold(-t or --threshold)!",
+                    "Select window size for SWP and MSE threshold for DWP."),
+    "bad_mode": ("Please specify the -m or --mode correctly!", "'abs' or 'rel' or 'absrel' or 'pwrel'."),
+    "no_bound": ("Please specify the -b or --bound option!", "error bound value."),
+    "bound_count": ("If the -m or --mode is 'abs' or 'rel' or 'pwrel', enter one for -b or --bound. : value",
+                    "If the -m or --mode is 'absrel', enter two in -b or --bound. : abs_value rel_value"),
+    "no_training": ("Training (-l) is not part of the MI355X compression build: train with the reference and "
+                    "point -c/-u at its model directory (prednet_model.json + prednet_weights.hdf5).",),
+}
+BOUNDS_WANTED = {"abs": 1, "rel": 1, "pwrel": 1, "absrel": 2}
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(prog="TEZIP", formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    for short, long_, kw in FLAG_TABLE:
+        parser.add_argument(short, long_, **kw)
+    return parser
+
 
 def probe_gpu(force_cpu):
+    """tezip.py:12-21 asked TensorFlow for a GPU; here a context on device 0 must open."""
     if force_cpu:
         return False
     try:
         from . import _lib
-        c = _lib.Context(0)
-        c.close()
+        _lib.Context(0).close()
         return True
     except Exception:
         return False
 
 
+def complain(key):
+    print("ERROR")
+    for line in TEXT[key]:
+        print(line)
+
+
+def check_compress(arg):
+    """Reference order (tezip.py:40-84).  Returns None when the request is complete, else the key
+    of the message to print; prints the mode name where the reference does."""
+    if arg.preprocess is None:
+        return "no_p"
+    have_w, have_t = arg.window is not None, arg.threshold is not None
+    if not have_w and not have_t:
+        return "no_window"
+    if have_w and have_t:
+        return "two_windows"
+    if arg.mode is None:  # the reference raises a TypeError here; report it as a bad mode instead
+        return "bad_mode"
+    print(arg.mode[0])
+    if arg.mode[0] not in BOUNDS_WANTED:
+        return "bad_mode"
+    if not arg.bound:
+        return "no_bound"
+    if len(arg.bound) != BOUNDS_WANTED[arg.mode[0]]:
+        return "bound_count"
+    return None
+
+
 def main(arg):
-    GPU_flag = probe_gpu(arg.force)
-    print('GPU MODE' if GPU_flag else 'CPU MODE')
-
-    if (arg.learn != None and arg.compress != None) or (arg.compress != None and arg.uncompress != None) or \
-            (arg.learn != None and arg.uncompress != None):
-        print('ERROR')
-        print('Please select only one of learn or compress or uncompress.')
-        print('Command to check the options is -h or --help')
-    elif arg.learn != None:
-        print('train mode')
-        print('ERROR')
-        print('Training (-l) is not part of the MI355X compression build; train with the reference and convert the '
-              'weights (python -m tezip_amd.weights convert <model_dir>).')
-    elif arg.compress != None:
-        print('compress mode')
-        if arg.preprocess != None:
-            if arg.window == None and arg.threshold == None:
-                print('ERROR')
-                print('Please specify the window size(-w or --window) or MSE threshold(-t or --threshold) option!')
-                print('Select window size for SWP and MSE threshold for DWP.')
-            elif arg.window != None and arg.threshold != None:
-                print('ERROR')
-                print('Please select only one of window size(-w or --window) or MSE threshold(-t or --threshold)!')
-                print('Select window size for SWP and MSE threshold for DWP.')
-            elif arg.mode == None:
-                print('ERROR')
-                print('Please specify the -m or --mode correctly!')
-                print('\'abs\' or \'rel\' or \'absrel\' or \'pwrel\'.')
-            else:
-                print(arg.mode[0])
-                if arg.mode[0] in ('abs', 'rel', 'absrel', 'pwrel'):
-                    if arg.bound != None and len(arg.bound) != 0:
-                        if (arg.mode[0] in ('abs', 'rel', 'pwrel') and len(arg.bound) == 1) or \
-                                (arg.mode[0] == 'absrel' and len(arg.bound) == 2):
-                            if arg.window != None:
-                                compress.run(arg.compress[0], arg.compress[1], arg.compress[2], arg.preprocess[0],
-                                             arg.window[0], arg.threshold, arg.mode[0], arg.bound, GPU_flag, arg.verbose,
-                                             arg.no_entropy)
-                            else:
-                                compress.run(arg.compress[0], arg.compress[1], arg.compress[2], arg.preprocess[0],
-                                             arg.window, arg.threshold[0], arg.mode[0], arg.bound, GPU_flag, arg.verbose,
-                                             arg.no_entropy)
-                        else:
-                            print('ERROR')
-                            print('If the -m or --mode is \'abs\' or \'rel\' or \'pwrel\', enter one for -b or --bound. : value')
-                            print('If the -m or --mode is \'absrel\', enter two in -b or --bound. : abs_value rel_value')
-                    else:
-                        print('ERROR')
-                        print('Please specify the -b or --bound option!')
-                        print('error bound value.')
-                else:
-                    print('ERROR')
-                    print('Please specify the -m or --mode correctly!')
-                    print('\'abs\' or \'rel\' or \'absrel\' or \'pwrel\'.')
-        else:
-            print('ERROR')
-            print('Please specify the -p or --preprocess option!')
-            print('warm up num.')
-    elif arg.uncompress != None:
-        print('uncompress mode')
-        decompress.run(arg.uncompress[0], arg.uncompress[1], arg.uncompress[2], GPU_flag, arg.verbose)
-    else:
-        print('ERROR')
-        print('Please mode select!')
-        print('learn or compress or uncompress.')
-        print('Command to check the options is -h or --help')
+    gpu = probe_gpu(arg.force)
+    print("GPU MODE" if gpu else "CPU MODE")
+    chosen = [name for name in ("learn", "compress", "uncompress") if getattr(arg, name) is not None]
+    if len(chosen) > 1:
+        return complain("several")
+    if not chosen:
+        return complain("nothing")
+    if chosen[0] == "learn":
+        print("train mode")
+        return complain("no_training")
+    if chosen[0] == "uncompress":
+        print("uncompress mode")
+        model, src, dst = arg.uncompress
+        return decompress.run(model, src, dst, gpu, arg.verbose)
+    print("compress mode")
+    problem = check_compress(arg)
+    if problem:
+        return complain(problem)
+    model, src, dst = arg.compress
+    window = arg.window[0] if arg.window is not None else None
+    threshold = arg.threshold[0] if arg.threshold is not None else None
+    return compress.run(model, src, dst, arg.preprocess[0], window, threshold, arg.mode[0], arg.bound, gpu,
+                        arg.verbose, arg.no_entropy)
 
 
-def build_parser():
-    parser = argparse.ArgumentParser(prog='TEZIP', formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument('-l', '--learn', type=str, nargs=2, metavar=('model', 'dir'), dest='learn')
-    parser.add_argument('-c', '--compress', type=str, nargs=3, metavar=('model', 'dir', 'file'), dest='compress')
-    parser.add_argument('-u', '--uncompress', type=str, nargs=3, metavar=('model', 'file', 'dir'), dest='uncompress')
-    parser.add_argument('-p', '--preprocess', type=int, nargs=1, metavar=('warm_up_num'), dest='preprocess')
-    parser.add_argument('-w', '--window', type=int, nargs=1, metavar=('window_size'), dest='window')
-    parser.add_argument('-t', '--threshold', type=float, nargs=1, metavar=('MSE_threshold'), dest='threshold')
-    parser.add_argument('-m', '--mode', type=str, nargs=1, metavar=('mode'), dest='mode')
-    parser.add_argument('-b', '--bound', type=float, nargs='*', metavar=('value'), dest='bound', default=None)
-    parser.add_argument('-f', '--force', action='store_true')
-    parser.add_argument('-v', '--verbose', action='store_true')
-    parser.add_argument('-n', '--no_entropy', action='store_false')
-    return parser
-
-
-if __name__ == '__main__':
+if __name__ == "__main__":
     main(build_parser().parse_args())
