@@ -4,8 +4,8 @@ Behaviourally equivalent to the reference CLI (/root/reference/src/tezip.py:10-1
 flags, same validation order and the same messages on stdout, process exit code 0 on
 validation errors.  The structure is this build's own: flags come from a table, validation is a
 list of (predicate, message key) rules evaluated in the reference's order, and the device probe
-asks the HIP library instead of TensorFlow.  `-l` (training) is outside this build's scope
-(SURVEY.md §8f): it reports that instead of training.
+asks the HIP library instead of TensorFlow.  `-l` trains with tezip_amd/train.py (PyTorch
+autograd) on .npy stacks written by tezip_amd/train_data_create.py.
 """
 import argparse
 import os
@@ -15,7 +15,7 @@ if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     __package__ = "tezip_amd"
 
-from . import compress, decompress  # noqa: E402
+from . import compress, decompress, train  # noqa: E402
 
 # (short, long, argparse keywords) -- tezip.py:88-99
 FLAG_TABLE = (
@@ -46,8 +46,6 @@ TEXT = {
     "no_bound": ("Please specify the -b or --bound option!", "error bound value."),
     "bound_count": ("If the -m or --mode is 'abs' or 'rel' or 'pwrel', enter one for -b or --bound. : value",
                     "If the -m or --mode is 'absrel', enter two in -b or --bound. : abs_value rel_value"),
-    "no_training": ("Training (-l) is not part of the MI355X compression build: train with the reference and "
-                    "point -c/-u at its model directory (prednet_model.json + prednet_weights.hdf5).",),
 }
 BOUNDS_WANTED = {"abs": 1, "rel": 1, "pwrel": 1, "absrel": 2}
 
@@ -109,7 +107,7 @@ def main(arg):
         return complain("nothing")
     if chosen[0] == "learn":
         print("train mode")
-        return complain("no_training")
+        return train.run(arg.learn[0], arg.learn[1], arg.verbose)
     if chosen[0] == "uncompress":
         print("uncompress mode")
         model, src, dst = arg.uncompress
