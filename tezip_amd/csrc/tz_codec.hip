@@ -79,8 +79,8 @@ int tzk_delta(tz_ctx* ctx, const float* pred, const uint8_t* orig, const uint8_t
 
 // --------------------------------------------------------------------------- quantiser
 // compress.py:23-70, one chain per (frame, channel) over H*W elements, row-major.
-// Stage 1 (k_q_bound): per-chain tolerance E for rel / absrel from max-min of the ORIGINAL
-//                      slab (compress.py:31-33,36-43).
+// Stage 1 (k_q_minmax, k_q_bound): per-chain tolerance E for rel / absrel from max-min of the
+//                      ORIGINAL slab (compress.py:31-33,36-43).
 // Stage 2 (k_q_heads): exact wave-parallel form of the greedy interval-intersection
 //                      segmentation (see the kernel); stores the truncated median of every
 //                      run at its HEAD position of `tmp` (pre-filled with a sentinel).
@@ -91,44 +91,71 @@ struct QParams {
     double b0, b1;
 };
 
-__global__ __launch_bounds__(256) void k_q_bound(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ skip,
-                                                 int HW, QParams qp, double* __restrict__ E) {
-    int f = blockIdx.x;
+// min/max of the original slab per (frame, channel): 12 bytes (4 interleaved RGB pixels) per
+// lane and iteration, QBB blocks per frame combined with integer atomics (mm[f][c] = {min, max}).
+static constexpr int QBB = 16;
+__global__ __launch_bounds__(256) void k_q_minmax(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ skip,
+                                                  int HW, int* __restrict__ mm) {
+    const int f = blockIdx.y;
     if (skip[f]) return;
-    __shared__ int smn[3][256], smx[3][256];
-    int mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
     const uint8_t* o = orig + (size_t)f * HW * 3;
-    for (int p = threadIdx.x; p < HW; p += 256)
-        for (int c = 0; c < 3; ++c) {
-            int v = o[(size_t)p * 3 + c];
+    int mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
+    const int ngroups = HW / 4;  // 4 pixels = 12 bytes = 3 aligned dwords (frame base is 4-byte aligned when HW*3 % 4 == 0)
+    const bool aligned = (((size_t)f * HW * 3) & 3) == 0 && (((uintptr_t)orig) & 3) == 0;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ngroups; g += QBB * 256) {
+        unsigned w[3];
+        if (aligned) {
+            const unsigned* p = (const unsigned*)(o + (size_t)g * 12);
+            w[0] = p[0]; w[1] = p[1]; w[2] = p[2];
+        } else {
+            const uint8_t* p = o + (size_t)g * 12;
+            for (int k = 0; k < 3; ++k) w[k] = p[4 * k] | (p[4 * k + 1] << 8) | (p[4 * k + 2] << 16) | ((unsigned)p[4 * k + 3] << 24);
+        }
+#pragma unroll
+        for (int b = 0; b < 12; ++b) {
+            int v = (w[b >> 2] >> (8 * (b & 3))) & 0xff, c = b % 3;
             mn[c] = min(mn[c], v);
             mx[c] = max(mx[c], v);
         }
-    for (int c = 0; c < 3; ++c) {
-        smn[c][threadIdx.x] = mn[c];
-        smx[c][threadIdx.x] = mx[c];
     }
-    __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s)
+    if (blockIdx.x == 0)
+        for (int p = ngroups * 4 + threadIdx.x; p < HW; p += 256)
             for (int c = 0; c < 3; ++c) {
-                smn[c][threadIdx.x] = min(smn[c][threadIdx.x], smn[c][threadIdx.x + s]);
-                smx[c][threadIdx.x] = max(smx[c][threadIdx.x], smx[c][threadIdx.x + s]);
+                int v = o[(size_t)p * 3 + c];
+                mn[c] = min(mn[c], v);
+                mx[c] = max(mx[c], v);
             }
-        __syncthreads();
-    }
-    if (threadIdx.x < 3) {
-        int c = threadIdx.x;
-        double range = (double)(smx[c][0] - smn[c][0]);
-        double e;
-        if (qp.mode == TZ_MODE_REL) {
-            e = range * qp.b0;
-        } else {  // absrel
-            double a = fabs(qp.b0), r = range * qp.b1;
-            e = a < r ? a : r;
+    for (int c = 0; c < 3; ++c) {
+        for (int s = 32; s >= 1; s >>= 1) {
+            mn[c] = min(mn[c], __shfl_down(mn[c], s, 64));
+            mx[c] = max(mx[c], __shfl_down(mx[c], s, 64));
         }
-        E[f * 3 + c] = e;
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&mm[(f * 3 + c) * 2], mn[c]);
+            atomicMax(&mm[(f * 3 + c) * 2 + 1], mx[c]);
+        }
     }
+}
+
+__global__ void k_q_mm_init(int* __restrict__ mm, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mm[i] = (i & 1) ? 0 : 255;
+}
+
+// tolerance per chain from max-min of the ORIGINAL slab (compress.py:31-33, 36-43)
+__global__ void k_q_bound(const int* __restrict__ mm, const uint8_t* __restrict__ skip, QParams qp, int nframes,
+                          double* __restrict__ E) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nframes * 3 || skip[i / 3]) return;
+    double range = (double)(mm[2 * i + 1] - mm[2 * i]);
+    double e;
+    if (qp.mode == TZ_MODE_REL) {
+        e = range * qp.b0;
+    } else {  // absrel
+        double a = fabs(qp.b0), r = range * qp.b1;
+        e = a < r ? a : r;
+    }
+    E[i] = e;
 }
 
 __global__ __launch_bounds__(256) void k_q_init(int16_t* __restrict__ tmp, const uint8_t* __restrict__ skip,
@@ -386,17 +413,22 @@ int tzk_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8
     int HW = H * W;
     size_t fe = (size_t)HW * 3;
     int nblk = (HW + QFB - 1) / QFB;
-    void *d_skip, *d_E, *d_tmp, *d_carry;
+    void *d_skip, *d_E, *d_tmp, *d_carry, *d_mm;
     TZ_TRY(tz_pool_alloc(ctx, nframes, &d_skip));
     TZ_TRY(tz_pool_alloc(ctx, sizeof(double) * 3 * nframes, &d_E));
+    TZ_TRY(tz_pool_alloc(ctx, sizeof(int) * 6 * nframes, &d_mm));
     TZ_TRY(tz_pool_alloc(ctx, fe * nframes * 2, &d_tmp));
     TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * nblk * 3 * 2, &d_carry));
     TZ_TRY(tz_upload(ctx, d_skip, h_skip, nframes));
     QParams qp{mode, b0, b1};
     tz_prof_scope ps(ctx, TZP_QUANT);
-    if (mode == TZ_MODE_REL || mode == TZ_MODE_ABSREL)
-        hipLaunchKernelGGL(k_q_bound, dim3(nframes), dim3(256), 0, ctx->stream, orig, (const uint8_t*)d_skip, HW, qp,
-                           (double*)d_E);
+    if (mode == TZ_MODE_REL || mode == TZ_MODE_ABSREL) {
+        hipLaunchKernelGGL(k_q_mm_init, dim3((6 * nframes + 255) / 256), dim3(256), 0, ctx->stream, (int*)d_mm, 6 * nframes);
+        hipLaunchKernelGGL(k_q_minmax, dim3(QBB, nframes), dim3(256), 0, ctx->stream, orig, (const uint8_t*)d_skip, HW,
+                           (int*)d_mm);
+        hipLaunchKernelGGL(k_q_bound, dim3((3 * nframes + 63) / 64), dim3(64), 0, ctx->stream, (const int*)d_mm,
+                           (const uint8_t*)d_skip, qp, nframes, (double*)d_E);
+    }
     hipLaunchKernelGGL(k_q_init, dim3(grid_for(fe * nframes, 256)), dim3(256), 0, ctx->stream, (int16_t*)d_tmp,
                        (const uint8_t*)d_skip, fe, nframes);
     hipLaunchKernelGGL(k_q_heads, dim3(nframes * 3), dim3(512), 0, ctx->stream, orig, (const int16_t*)diff,

@@ -149,7 +149,7 @@ def run(WEIGHTS_DIR, DATA_DIR, VERBOSE, nb_epoch=100, samples_per_epoch=5, N_seq
             loss = l0_loss(model(batch(X, i)), nt)
             loss.backward()
             opt.step()
-            tl += float(loss)
+            tl += float(loss.detach())
         model.eval()
         with torch.no_grad():
             vl = float(np.mean([float(l0_loss(model(batch(Xv, int(i))), nt)) for i in vstarts]))
