@@ -231,6 +231,10 @@ def test_compress_decompress_matches_oracle(ctx, nt, h, w, p, window, thr, mode,
         np.testing.assert_allclose(got_mse, ref["mse"], rtol=1e-12)
     payload, table, delta = ctx.encode(mode, bound, entropy, want_delta=True)
     np.testing.assert_array_equal(delta, ref["delta"])
+    # without the delta tap the lossless case takes the fused delta+spatial-delta+histogram kernel
+    payload2, table2, _ = ctx.encode(mode, bound, entropy)
+    np.testing.assert_array_equal(payload2, payload)
+    assert (table2 is None) == (table is None) and (table is None or (table2 == table).all())
     stream_payload, ref_table, shape, warm = O.parse_stream(ref["stream"])
     np.testing.assert_array_equal(payload, stream_payload)
     if entropy:

@@ -597,6 +597,7 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
                          int* table_len, int16_t* delta_out) {
     if (!ctx || !payload || !table_len || (entropy && !table)) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode needs a tz_rollout first");
+    if (mode < 0 || mode > 3) return tz_fail(ctx, TZ_ERR_INVALID, "unknown error-bound mode %d", mode);
     const int nt = ctx->nt, H = ctx->H, W = ctx->W;
     const size_t N = (size_t)nt * H * W * 3;
     std::vector<tz_out> outs;
@@ -615,29 +616,39 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
     }
     if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_mask);
     if (rc == TZ_OK) rc = tz_upload(ctx, d_mask, ctx->group_first.data(), nt);
-    // compress.py:292-314
-    if (rc == TZ_OK) rc = tzk_delta(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt, H, W, ctx->Hp, ctx->Wp, (int16_t*)d_delta);
-    // compress.py:315-319
-    if (rc == TZ_OK) rc = tzk_error_bound(ctx, ctx->d_frames, (int16_t*)d_delta, ctx->quant_skip.data(), nt, H, W, mode, b0, b1);
-    if (rc == TZ_OK && !entropy) {
-        // compress.py:339-340 only
-        rc = tzk_spatial_delta(ctx, (const int16_t*)d_delta, N, 0, 0, 0, (int16_t*)o_pay.dev, nullptr);
-        *table_len = -1;
-    } else if (rc == TZ_OK) {
+    // error_bound returns its input untouched in these cases (compress.py:24,35)
+    const bool lossless = b0 == 0.0 || (mode == TZ_MODE_ABSREL && b1 == 0.0);
+    bool fused = false;
+    if (rc == TZ_OK && entropy) {
         rc = tz_pool_alloc(ctx, TZ_NBINS * sizeof(unsigned long long), &d_hist);
         if (rc == TZ_OK) rc = tz_pool_alloc(ctx, N * 2, &d_sd);
-        std::vector<unsigned long long> hist(TZ_NBINS, 0);
         if (rc == TZ_OK) {
             hipError_t e = hipMemsetAsync(d_hist, 0, TZ_NBINS * sizeof(unsigned long long), ctx->stream);
             if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "hist memset: %s", hipGetErrorString(e));
         }
+    }
+    // lossless and nobody asked for the delta stack: one fused pass (compress.py:292-355)
+    if (rc == TZ_OK && lossless && !delta_out)
+        rc = tzk_delta_sd_fused(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt, H, W, ctx->Hp, ctx->Wp,
+                                entropy ? 1 : 0, entropy ? (int16_t*)d_sd : (int16_t*)o_pay.dev,
+                                (unsigned long long*)d_hist, &fused);
+    if (rc == TZ_OK && !fused) {
+        // compress.py:292-314
+        rc = tzk_delta(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt, H, W, ctx->Hp, ctx->Wp, (int16_t*)d_delta);
+        // compress.py:315-319
+        if (rc == TZ_OK) rc = tzk_error_bound(ctx, ctx->d_frames, (int16_t*)d_delta, ctx->quant_skip.data(), nt, H, W, mode, b0, b1);
         // compress.py:339-355
-        if (rc == TZ_OK) rc = tzk_spatial_delta(ctx, (const int16_t*)d_delta, N, 0, 0, 1, (int16_t*)d_sd, (unsigned long long*)d_hist);
-        if (rc == TZ_OK) {
-            hipError_t e = hipMemcpyAsync(hist.data(), d_hist, TZ_NBINS * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "hist download: %s", hipGetErrorString(e));
-        }
+        if (rc == TZ_OK)
+            rc = tzk_spatial_delta(ctx, (const int16_t*)d_delta, N, 0, 0, entropy ? 1 : 0,
+                                   entropy ? (int16_t*)d_sd : (int16_t*)o_pay.dev, (unsigned long long*)d_hist);
+    }
+    if (rc == TZ_OK && !entropy) {
+        *table_len = -1;
+    } else if (rc == TZ_OK) {
+        std::vector<unsigned long long> hist(TZ_NBINS, 0);
+        hipError_t e = hipMemcpyAsync(hist.data(), d_hist, TZ_NBINS * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "hist download: %s", hipGetErrorString(e));
         std::vector<int16_t> lut;
         if (rc == TZ_OK) rc = tz_build_table(hist.data(), TZ_NBINS, table, table_len);  // 356-361
         if (rc == TZ_OK) rc = build_enc_lut(ctx, table, *table_len, &lut);

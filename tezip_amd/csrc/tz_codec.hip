@@ -502,6 +502,83 @@ __global__ __launch_bounds__(256) void k_sdelta(const int16_t* __restrict__ in, 
     }
 }
 
+// Lossless fast path (error_bound is the identity, compress.py:24): delta, spatial delta,
+// 1600 offset and histogram in ONE pass over pred/orig -- 7 B/element instead of 7 + 4.
+// Same arithmetic as k_delta_flat followed by k_sdelta; the element before a lane's first is
+// recomputed from pred/orig (one extra float + byte, same cache lines).
+__global__ __launch_bounds__(256) void k_delta_sd_fused(const float4* __restrict__ pred, const uint2* __restrict__ orig,
+                                                        const uint8_t* __restrict__ zero_mask, size_t n8,
+                                                        unsigned frame_elems8, int apply_offset,
+                                                        short8* __restrict__ out, unsigned long long* __restrict__ hist) {
+    __shared__ unsigned lh[TZ_NBINS + 1];
+    const bool do_hist = hist != nullptr;
+    if (do_hist) {
+        for (int k = threadIdx.x; k < TZ_NBINS + 1; k += 256) lh[k] = 0;
+        __syncthreads();
+    }
+    const int dominant = apply_offset ? TZ_OFFSET : 0;
+    unsigned ndom = 0;
+    const float* predf = (const float*)pred;
+    const uint8_t* origb = (const uint8_t*)orig;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        float4 p0 = pred[2 * i], p1 = pred[2 * i + 1];
+        uint2 o = orig[i];
+        const bool zero = zero_mask[i / frame_elems8] != 0;
+        short d[8];
+        d[0] = (short)((int)(p0.x * 255.0f) - (int)(o.x & 0xff));
+        d[1] = (short)((int)(p0.y * 255.0f) - (int)((o.x >> 8) & 0xff));
+        d[2] = (short)((int)(p0.z * 255.0f) - (int)((o.x >> 16) & 0xff));
+        d[3] = (short)((int)(p0.w * 255.0f) - (int)(o.x >> 24));
+        d[4] = (short)((int)(p1.x * 255.0f) - (int)(o.y & 0xff));
+        d[5] = (short)((int)(p1.y * 255.0f) - (int)((o.y >> 8) & 0xff));
+        d[6] = (short)((int)(p1.z * 255.0f) - (int)((o.y >> 16) & 0xff));
+        d[7] = (short)((int)(p1.w * 255.0f) - (int)(o.y >> 24));
+        short prev = 0;
+        if (i) {
+            size_t e = 8 * i - 1;
+            if (!zero_mask[(i * 8 - 1) / ((size_t)frame_elems8 * 8)]) prev = (short)((int)(predf[e] * 255.0f) - (int)origb[e]);
+        }
+        short8 r;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            short cur = zero ? (short)0 : d[k];
+            short sd = (short)(prev - cur);
+            if (i == 0 && k == 0) sd = cur;
+            short y = apply_offset ? (short)(TZ_OFFSET - sd) : sd;
+            r[k] = y;
+            prev = cur;
+            if (do_hist) {
+                if (y == dominant) ++ndom;
+                else if (y >= 0 && y < TZ_NBINS) atomicAdd(&lh[y], 1u);
+            }
+        }
+        out[i] = r;
+    }
+    if (do_hist) {
+        for (int s = 32; s >= 1; s >>= 1) ndom += __shfl_down(ndom, s);
+        if ((threadIdx.x & 63) == 0 && ndom && dominant >= 0 && dominant < TZ_NBINS) atomicAdd(&lh[dominant], ndom);
+        __syncthreads();
+        for (int k = threadIdx.x; k < TZ_NBINS; k += 256)
+            if (lh[k]) atomicAdd(&hist[k], (unsigned long long)lh[k]);
+    }
+}
+
+// returns TZ_OK and sets *done when the fused path applies (unpadded frames, whole 8-element groups)
+int tzk_delta_sd_fused(tz_ctx* ctx, const float* pred, const uint8_t* orig, const uint8_t* d_zero_mask, int nframes, int H,
+                       int W, int Hp, int Wp, int apply_offset, int16_t* out, unsigned long long* d_hist, bool* done) {
+    *done = false;
+    size_t fe = (size_t)H * W * 3;
+    if (H != Hp || W != Wp || fe % 8 || nframes <= 0) return TZ_OK;
+    size_t n8 = fe * nframes / 8;
+    tz_prof_scope ps(ctx, TZP_DELTA);
+    hipLaunchKernelGGL(k_delta_sd_fused, dim3(grid_for(n8, 256)), dim3(256), 0, ctx->stream, (const float4*)pred,
+                       (const uint2*)orig, d_zero_mask, n8, (unsigned)(fe / 8), apply_offset, (short8*)out, d_hist);
+    TZ_HIP(ctx, hipGetLastError());
+    *done = true;
+    return TZ_OK;
+}
+
 int tzk_spatial_delta(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, int16_t carry, int apply_offset,
                       int16_t* out, unsigned long long* d_hist) {
     if (n == 0) return TZ_OK;
