@@ -201,6 +201,13 @@ CASES = [
     (11, 21, 30, 1, 3, None, "pwrel", [0.05], True),
     (10, 24, 16, 0, None, "auto", "absrel", [3.0, 0.05], True),
     (10, 24, 16, 2, None, "auto", "abs", [0.0], True),
+    # edge cases
+    (6, 8, 8, 3, 1, None, "abs", [0.0], True),        # window 1: every frame after the warm-up is a key frame
+    (7, 9, 9, 0, 50, None, "abs", [1.0], True),       # one window longer than the sequence
+    (4, 8, 16, 2, 2, None, "abs", [0.0], False),      # shortest legal sequence: nt = warm_up + 2
+    (8, 16, 8, 0, None, 0.0, "abs", [0.0], True),     # DWP threshold 0: every prediction is rejected
+    (8, 16, 8, 1, None, 1e9, "rel", [0.05], True),    # DWP threshold never reached: one window
+    (5, 8, 8, 0, 2, None, "absrel", [0.0, 0.5], True),  # absrel with abs bound 0: lossless shortcut
 ]
 
 
@@ -263,3 +270,20 @@ def test_rollout_rejects_short_sequences_and_bad_sizes(ctx):
         ctx.rollout(f, 2, 2)
     with pytest.raises(TezipError):  # compress.py:178-181
         ctx.rollout(np.zeros((3, 24, 16, 3), np.uint8), 0, 2)
+
+
+def test_decode_rejects_key_stacks_that_do_not_cover_the_sequence(ctx):
+    from tezip_amd._lib import TezipError
+    cfg = SMALL
+    ctx.load_model(cfg, cfg.init_weights(seed=1))
+    ctx.prepare(16, 16, 2)
+    keys = np.zeros((6, 16, 16, 3), np.uint8)
+    with pytest.raises(TezipError):      # no key frame at all
+        ctx.rollout_decode(keys, 0)
+    keys[2] = 7
+    with pytest.raises(TezipError):      # first key frame is not frame `warm_up` (decompress.py:147-148 breaks)
+        ctx.rollout_decode(keys, 0)
+    keys[0] = 9
+    assert ctx.rollout_decode(keys, 0).tolist() == [True, False, True, False, False, False]
+    with pytest.raises(TezipError):      # payload decode without a decode rollout of matching state is fine, but
+        ctx.encode("abs", [0.0], True)   # ... encode after a decode rollout is a call-order error
