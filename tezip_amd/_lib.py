@@ -115,7 +115,6 @@ class Context:
         if rc != TZ_OK:
             raise TezipError(rc, self.lib.tz_strerror(rc).decode() + " (tz_ctx_create; a MI355X is required)")
         self.h = h
-        self._keep = []
 
     def close(self):
         if getattr(self, "h", None):

@@ -652,7 +652,7 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
         std::vector<int16_t> lut;
         if (rc == TZ_OK) rc = tz_build_table(hist.data(), TZ_NBINS, table, table_len);  // 356-361
         if (rc == TZ_OK) rc = build_enc_lut(ctx, table, *table_len, &lut);
-        if (rc == TZ_OK) rc = tzk_lut(ctx, (const int16_t*)d_sd, N, lut.data(), 0, 0, (int16_t*)o_pay.dev);  // 369
+        if (rc == TZ_OK) rc = tzk_lut(ctx, (const int16_t*)d_sd, N, lut.data(), 0, (int16_t*)o_pay.dev);  // 369
     }
     if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
     tz_pool_release_all(ctx);
@@ -721,7 +721,7 @@ extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, const int16_t* tab
         std::vector<int16_t> lut;
         build_dec_lut(table, table_len, 1, &lut);
         rc = tz_pool_alloc(ctx, N * 2, &d_sd);
-        if (rc == TZ_OK) rc = tzk_lut(ctx, (const int16_t*)d_pay, N, lut.data(), 0, 1, (int16_t*)d_sd);
+        if (rc == TZ_OK) rc = tzk_lut(ctx, (const int16_t*)d_pay, N, lut.data(), 1, (int16_t*)d_sd);
         sd = (const int16_t*)d_sd;
     }
     if (rc == TZ_OK) rc = tzk_undelta(ctx, sd, N, 0, 0, (int16_t*)d_diff);  // decompress.py:240-245
@@ -818,7 +818,7 @@ static int lut_op(tz_ctx* ctx, const int16_t* in, size_t n, const std::vector<in
     if (rc == TZ_OK) rc = tz_dev_out(ctx, out, n * 2, &o);
     if (rc == TZ_OK) {
         outs.push_back(o);
-        rc = tzk_lut(ctx, (const int16_t*)din, n, lut.data(), 0, post, (int16_t*)o.dev);
+        rc = tzk_lut(ctx, (const int16_t*)din, n, lut.data(), post, (int16_t*)o.dev);
     }
     if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
     tz_pool_release_all(ctx);

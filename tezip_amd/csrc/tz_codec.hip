@@ -16,7 +16,6 @@ static inline int grid_for(size_t work_items, int block) {
 }
 
 typedef short short8 __attribute__((ext_vector_type(8)));
-typedef short short4v __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------- delta
 // compress.py:292-314: d = (int)(pred_f32 * 255.0f) - orig ; frames flagged in zero_mask -> 0.
@@ -593,7 +592,7 @@ int tzk_spatial_delta(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, i
 
 // ----------------------------------------------------------------------- rank remap / unmap
 // compress.py:84-90 and decompress.py:31-36 are T sequential `where` passes (O(N*T)); here
-// one pass through a 2112-entry LUT held in LDS.  Values outside [lo, lo+2112) pass through
+// one pass through a 2112-entry LUT held in LDS.  Values outside [0, 2112) pass through
 // (then 1600 - v when post_offset, decompress.py:236).  The host builds the LUT so that it
 // reproduces the sequential-pass semantics exactly.
 __global__ __launch_bounds__(256) void k_lut(const int16_t* __restrict__ in, size_t n, const int16_t* __restrict__ lut,
@@ -621,8 +620,7 @@ __global__ __launch_bounds__(256) void k_lut(const int16_t* __restrict__ in, siz
     }
 }
 
-int tzk_lut(tz_ctx* ctx, const int16_t* in, size_t n, const int16_t* h_lut2112, int lo, int post_offset, int16_t* out) {
-    (void)lo;
+int tzk_lut(tz_ctx* ctx, const int16_t* in, size_t n, const int16_t* h_lut2112, int post_offset, int16_t* out) {
     if (n == 0) return TZ_OK;
     if (((uintptr_t)in & 15) || ((uintptr_t)out & 15))
         return tz_fail(ctx, TZ_ERR_INVALID, "remap buffers must be 16-byte aligned");

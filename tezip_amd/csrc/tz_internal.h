@@ -25,7 +25,6 @@ enum tz_prof_class {
     TZP_COUNT
 };
 
-struct tz_conv_job;   // tz_prednet.hip
 struct tz_model;      // tz_prednet.hip
 
 struct tz_prof_slot {
@@ -39,9 +38,9 @@ struct tz_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string last_error;
-    // staging pool for host-pointer arguments (grown on demand, reused)
-    std::vector<void*> scratch;       // device allocations handed out this call
-    std::vector<std::pair<void*, size_t>> pool;  // (ptr, bytes) free list
+    // device scratch pool (staging of host-pointer arguments, temporaries): grown on demand and
+    // reused; the top bit of the size marks a block that is handed out until tz_pool_release_all
+    std::vector<std::pair<void*, size_t>> pool;
     // model + rollout state
     tz_model* model = nullptr;
     // rollout-resident data
@@ -117,7 +116,7 @@ int tzk_error_bound(tz_ctx*, const uint8_t* orig, int16_t* diff, const uint8_t* 
                     int W, int mode, double b0, double b1);
 int tzk_spatial_delta(tz_ctx*, const int16_t* in, size_t n, int has_carry, int16_t carry, int apply_offset,
                       int16_t* out, unsigned long long* d_hist);
-int tzk_lut(tz_ctx*, const int16_t* in, size_t n, const int16_t* h_lut2112, int lo, int post_offset, int16_t* out);
+int tzk_lut(tz_ctx*, const int16_t* in, size_t n, const int16_t* h_lut2112, int post_offset, int16_t* out);
 int tzk_undelta(tz_ctx*, const int16_t* in, size_t n, int has_carry, int16_t carry, int16_t* out);
 int tzk_reconstruct(tz_ctx*, const float* pred, const uint8_t* key, const uint8_t* d_key_mask, const int16_t* diff,
                     int nframes, int H, int W, int Hp, int Wp, uint8_t* out);

@@ -43,15 +43,14 @@ struct ConvSrc {
     long long nstride;  // elements between batch items (0 = broadcast constant)
     int C;              // channels
     int up;             // 1: stored at half resolution, nearest x2 on read (prednet.py:264)
-    int cpt;            // chunks per tap = ceil(C/16)
-    int chunk_base;     // first chunk index of this source
+    int cpt;            // 16-channel blocks of this source = ceil(C/16)
 };
 
 struct ConvArgs {
     ConvSrc src[2];
-    int nsrc, nchunks;
+    int nsrc;
     int H, W, tiles_x, tiles_y, ncb;
-    const float* Wp;    // [nchunks*16][ncols]
+    const float* Wp;    // [weight slots * 16][ncols], slot order = the K-loop order (see pack_conv)
     int ncols;
     const float* bias;  // [ncols]
     const float* init;  // [H*W][ncols] accumulator start (G0), or null -> bias
@@ -469,7 +468,7 @@ struct Seg {
 struct PackedConv {
     float* d_W = nullptr;
     float* d_bias = nullptr;
-    int nchunks = 0, ncols = 0, NT = 1, ncb = 1;
+    int nslots = 0, ncols = 0, NT = 1, ncb = 1;
     std::vector<Seg> segs;
 };
 
@@ -571,7 +570,7 @@ static int pack_conv(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, con
         }
     for (int col = 0; col < ncols; ++col)
         if (cols[col].ch >= 0) B[col] = cols[col].bias[cols[col].ch];
-    pc->nchunks = nslots;
+    pc->nslots = nslots;
     pc->ncols = ncols;
     pc->NT = NT;
     pc->ncb = ncols / (16 * NT);
@@ -643,21 +642,15 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
     return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "no conv kernel for NT=%d epilogue=%d upsampled=%d", NT, epi, (int)ups);
 }
 
-static void fill_srcs(ConvArgs& a, const PackedConv& pc, const float* const* ptrs, const long long* nstrides,
-                      const int* ups) {
+static void fill_srcs(ConvArgs& a, const PackedConv& pc, const float* const* ptrs, const long long* nstrides) {
     a.nsrc = (int)pc.segs.size();
-    int base = 0;
     for (int s = 0; s < a.nsrc; ++s) {
         a.src[s].p = ptrs[s];
         a.src[s].nstride = nstrides[s];
         a.src[s].C = pc.segs[s].C;
         a.src[s].up = pc.segs[s].up;
         a.src[s].cpt = (pc.segs[s].C + 15) / 16;
-        a.src[s].chunk_base = base;
-        base += (pc.segs[s].up ? 16 : 9) * a.src[s].cpt;
-        (void)ups;
     }
-    a.nchunks = pc.nchunks;
     a.Wp = pc.d_W;
     a.bias = pc.d_bias;
     a.ncols = pc.ncols;
@@ -774,8 +767,7 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         memset(&a, 0, sizeof(a));
         const float* ptrs[2] = {l < L - 1 ? m->R0[l + 1] : nullptr, nullptr};
         long long ns[2] = {0, 0};
-        int ups[2] = {1, 0};
-        fill_srcs(a, pc, ptrs, ns, ups);
+        fill_srcs(a, pc, ptrs, ns);
         set_geom(a, hl(l), wl(l));
         a.Cout = m->rstack[l];
         a.R = m->rstack[l];
@@ -793,8 +785,7 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         memset(&a, 0, sizeof(a));
         const float* ptrs[2] = {m->R0[l], nullptr};
         long long ns[2] = {0, 0};
-        int ups[2] = {0, 0};
-        fill_srcs(a, pc, ptrs, ns, ups);
+        fill_srcs(a, pc, ptrs, ns);
         set_geom(a, hl(l), wl(l));
         a.Cout = Cout;
         a.out0 = m->Ahat0[l];
@@ -814,8 +805,7 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         memset(&a, 0, sizeof(a));
         const float* ptrs[2] = {m->R0[l], nullptr};
         long long ns[2] = {0, 0};
-        int ups[2] = {0, 0};
-        fill_srcs(a, pg, ptrs, ns, ups);
+        fill_srcs(a, pg, ptrs, ns);
         set_geom(a, hl(l), wl(l));
         a.out0 = m->G0[l];
         TZ_TRY(launch_conv(ctx, NT, EPI_RAW, a, 1));
@@ -882,8 +872,7 @@ int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int
         memset(&a, 0, sizeof(a));
         const float* ptrs[2] = {m->E[l], nullptr};
         long long ns[2] = {npx(l) * 2 * m->stack[l], 0};
-        int ups[2] = {0, 0};
-        fill_srcs(a, pc, ptrs, ns, ups);
+        fill_srcs(a, pc, ptrs, ns);
         set_geom(a, hl(l), wl(l));
         a.Cout = m->stack[l + 1];
         a.aux = m->Ahat0[l + 1];
@@ -897,8 +886,7 @@ int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int
         memset(&a, 0, sizeof(a));
         const float* ptrs[2] = {m->E[l], l < L - 1 ? m->R1[l + 1] : nullptr};
         long long ns[2] = {npx(l) * 2 * m->stack[l], l < L - 1 ? npx(l + 1) * m->rstack[l + 1] : 0};
-        int ups[2] = {0, 1};
-        fill_srcs(a, pc, ptrs, ns, ups);
+        fill_srcs(a, pc, ptrs, ns);
         set_geom(a, hl(l), wl(l));
         a.init = m->G0[l];
         a.Cout = m->rstack[l];
@@ -914,8 +902,7 @@ int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int
         memset(&a, 0, sizeof(a));
         const float* ptrs[2] = {m->R1[0], nullptr};
         long long ns[2] = {npx(0) * m->rstack[0], 0};
-        int ups[2] = {0, 0};
-        fill_srcs(a, pc, ptrs, ns, ups);
+        fill_srcs(a, pc, ptrs, ns);
         set_geom(a, Hp, Wp);
         a.Cout = m->stack[0];
         a.out0 = d_out_stack;
