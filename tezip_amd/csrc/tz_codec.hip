@@ -662,60 +662,83 @@ __device__ __forceinline__ unsigned block_scan_excl(unsigned v, unsigned* total)
     return pre + inc - v;
 }
 
-__global__ __launch_bounds__(256) void k_scan_sums(const int16_t* __restrict__ in, size_t n, int has_carry,
+// 16 consecutive int16 per thread = two 16-byte accesses (scalar fallback at the ragged tail
+// and for unaligned buffers)
+__device__ __forceinline__ void scan_load16(const int16_t* __restrict__ in, size_t base, size_t n, bool vec, int* v) {
+    if (vec && base + SCAN_EPT <= n) {
+        short8 a = *(const short8*)(in + base), b = *(const short8*)(in + base + 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = a[k];
+            v[8 + k] = b[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_EPT; ++k) v[k] = base + k < n ? (int)in[base + k] : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scan_sums(const int16_t* __restrict__ in, size_t n, int has_carry, int vec,
                                                    unsigned* __restrict__ bsum) {
     size_t base = (size_t)blockIdx.x * SCAN_BLK + (size_t)threadIdx.x * SCAN_EPT;
+    int v[SCAN_EPT];
+    scan_load16(in, base, n, vec != 0, v);
+    if (base == 0 && !has_carry) v[0] = -v[0];
     unsigned s = 0;
-    for (int k = 0; k < SCAN_EPT; ++k) {
-        size_t i = base + k;
-        if (i < n) {
-            int v = in[i];
-            if (i == 0 && !has_carry) v = -v;
-            s += (unsigned)v;
-        }
-    }
+#pragma unroll
+    for (int k = 0; k < SCAN_EPT; ++k) s += (unsigned)v[k];
     unsigned tot;
     block_scan_excl(s, &tot);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
+// exclusive scan of the block sums: every thread scans a contiguous run of them
 __global__ __launch_bounds__(256) void k_scan_blocks(unsigned* __restrict__ bsum, int nb) {
-    __shared__ unsigned running;
-    if (threadIdx.x == 0) running = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < nb; b0 += 256) {
-        int b = b0 + threadIdx.x;
-        unsigned v = b < nb ? bsum[b] : 0u, tot;
-        unsigned ex = block_scan_excl(v, &tot);
-        if (b < nb) bsum[b] = running + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) running += tot;
-        __syncthreads();
+    const int per = (nb + 255) / 256;
+    const int b0 = threadIdx.x * per, b1 = min(nb, b0 + per);
+    unsigned s = 0;
+    for (int b = b0; b < b1; ++b) s += bsum[b];
+    unsigned tot;
+    unsigned run = block_scan_excl(s, &tot);
+    for (int b = b0; b < b1; ++b) {
+        unsigned v = bsum[b];
+        bsum[b] = run;
+        run += v;
     }
 }
 
 __global__ __launch_bounds__(256) void k_scan_apply(const int16_t* __restrict__ in, size_t n, int has_carry,
-                                                    int16_t carry, const unsigned* __restrict__ bsum,
+                                                    int16_t carry, int vec, const unsigned* __restrict__ bsum,
                                                     int16_t* __restrict__ out) {
     size_t base = (size_t)blockIdx.x * SCAN_BLK + (size_t)threadIdx.x * SCAN_EPT;
     int v[SCAN_EPT];
+    scan_load16(in, base, n, vec != 0, v);
+    if (base == 0 && !has_carry) v[0] = -v[0];
     unsigned s = 0;
-    for (int k = 0; k < SCAN_EPT; ++k) {
-        size_t i = base + k;
-        v[k] = 0;
-        if (i < n) {
-            v[k] = in[i];
-            if (i == 0 && !has_carry) v[k] = -v[k];
-        }
-        s += (unsigned)v[k];
-    }
+#pragma unroll
+    for (int k = 0; k < SCAN_EPT; ++k) s += (unsigned)v[k];
     unsigned tot;
     unsigned pre = block_scan_excl(s, &tot) + bsum[blockIdx.x];
     unsigned c0 = has_carry ? (unsigned)(int)carry : 0u;
+    short r[SCAN_EPT];
+#pragma unroll
     for (int k = 0; k < SCAN_EPT; ++k) {
-        size_t i = base + k;
         pre += (unsigned)v[k];
-        if (i < n) out[i] = (int16_t)(uint16_t)(c0 - pre);
+        r[k] = (short)(uint16_t)(c0 - pre);
+    }
+    if (vec && base + SCAN_EPT <= n) {
+        short8 a, b;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a[k] = r[k];
+            b[k] = r[8 + k];
+        }
+        *(short8*)(out + base) = a;
+        *(short8*)(out + base + 8) = b;
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_EPT; ++k)
+            if (base + k < n) out[base + k] = r[k];
     }
 }
 
@@ -725,9 +748,10 @@ int tzk_undelta(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, int16_t
     void* d_bsum;
     TZ_TRY(tz_pool_alloc(ctx, sizeof(unsigned) * nb, &d_bsum));
     tz_prof_scope ps(ctx, TZP_SCAN);
-    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, ctx->stream, in, n, has_carry, (unsigned*)d_bsum);
+    const int vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, ctx->stream, in, n, has_carry, vec, (unsigned*)d_bsum);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, (unsigned*)d_bsum, nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, ctx->stream, in, n, has_carry, carry,
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, ctx->stream, in, n, has_carry, carry, vec,
                        (const unsigned*)d_bsum, out);
     TZ_HIP(ctx, hipGetLastError());
     return TZ_OK;
@@ -766,13 +790,55 @@ __global__ __launch_bounds__(256) void k_recon(const float* __restrict__ pred, c
     }
 }
 
+// Fast path: unpadded frames, 8 elements per lane (2x16 B pred, 16 B diff, 8 B key, 8 B out).
+__global__ __launch_bounds__(256) void k_recon_flat(const float4* __restrict__ pred, const uint2* __restrict__ key,
+                                                    const uint8_t* __restrict__ key_mask, const short8* __restrict__ diff,
+                                                    size_t n8, unsigned frame_elems8, uint2* __restrict__ out) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        short8 d = diff[i];
+        int base[8];
+        if (key_mask[i / frame_elems8]) {
+            uint2 k = key[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                base[j] = (k.x >> (8 * j)) & 0xff;
+                base[4 + j] = (k.y >> (8 * j)) & 0xff;
+            }
+        } else {
+            float4 p0 = pred[2 * i], p1 = pred[2 * i + 1];
+            base[0] = (int)(p0.x * 255.0f); base[1] = (int)(p0.y * 255.0f);
+            base[2] = (int)(p0.z * 255.0f); base[3] = (int)(p0.w * 255.0f);
+            base[4] = (int)(p1.x * 255.0f); base[5] = (int)(p1.y * 255.0f);
+            base[6] = (int)(p1.z * 255.0f); base[7] = (int)(p1.w * 255.0f);
+        }
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int a = base[j] - (int)d[j], b = base[4 + j] - (int)d[4 + j];
+            a = a < 0 ? 0 : (a > 255 ? 255 : a);
+            b = b < 0 ? 0 : (b > 255 ? 255 : b);
+            lo |= (unsigned)a << (8 * j);
+            hi |= (unsigned)b << (8 * j);
+        }
+        out[i] = make_uint2(lo, hi);
+    }
+}
+
 int tzk_reconstruct(tz_ctx* ctx, const float* pred, const uint8_t* key, const uint8_t* d_key_mask, const int16_t* diff,
                     int nframes, int H, int W, int Hp, int Wp, uint8_t* out) {
     size_t n = (size_t)nframes * H * W * 3;
     if (n == 0) return TZ_OK;
     tz_prof_scope ps(ctx, TZP_RECON);
-    hipLaunchKernelGGL(k_recon, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, ctx->stream, pred, key, d_key_mask, diff,
-                       n, H, W, Hp, Wp, out);
+    const size_t fe = (size_t)H * W * 3;
+    if (H == Hp && W == Wp && fe % 8 == 0 && key && ((((uintptr_t)diff | (uintptr_t)pred) & 15) == 0) &&
+        ((((uintptr_t)key | (uintptr_t)out) & 7) == 0)) {
+        hipLaunchKernelGGL(k_recon_flat, dim3(grid_for(n / 8, 256)), dim3(256), 0, ctx->stream, (const float4*)pred,
+                           (const uint2*)key, d_key_mask, (const short8*)diff, n / 8, (unsigned)(fe / 8), (uint2*)out);
+    } else {
+        hipLaunchKernelGGL(k_recon, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, ctx->stream, pred, key, d_key_mask, diff,
+                           n, H, W, Hp, Wp, out);
+    }
     TZ_HIP(ctx, hipGetLastError());
     return TZ_OK;
 }
