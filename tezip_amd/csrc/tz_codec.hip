@@ -165,11 +165,11 @@ __global__ __launch_bounds__(256) void k_q_init(int16_t* __restrict__ tmp, const
         if (!skip[i / frame_elems]) tmp[i] = TZ_SENTINEL;
 }
 
-// Wave-parallel exact greedy segmentation.  One workgroup (8 waves) per (frame, channel)
+// Wave-parallel exact greedy segmentation.  One workgroup (16 waves) per (frame, channel)
 // chain; the chain is walked in chunks of 64 elements (lane i <-> element).  A run started at s
 // breaks at the first i with min(Du[s..i]) < max(Dl[s..i]) (compress.py:60 -- a-b<0 <=> a<b in
 // IEEE), which is monotone in i, so per chunk:
-//   WORKER waves 1..7 (carry independent, one chunk each per round):
+//   WORKER waves 1..15 (carry independent, one chunk each per round):
 //   1. range tables T_k[i] = (min Du, max Dl) over [i, i+2^k) by shuffles (k = 0..5),
 //   2. nxt[s] = first break after s for EVERY s (fresh start) by binary lifting over T_k,
 //      together with the run's (u, l) up to the break,
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_q_init(int16_t* __restrict__ tmp, const
 // lengths; elements past the chain end are (+inf, -inf) and can neither break nor tighten a run.
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
-static constexpr int QW = 7;  // worker waves per chain
+static constexpr int QW = 15;  // worker waves per chain (+1 resolver wave = 1024 threads)
 
 struct QSlot {
     double cu[64], cl[64], pu[64], pl[64];
@@ -193,7 +193,7 @@ struct QSlot {
     int nxt[64];
 };
 
-__global__ __launch_bounds__(512) void k_q_heads(const uint8_t* __restrict__ orig, const int16_t* __restrict__ diff,
+__global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ orig, const int16_t* __restrict__ diff,
                                                  const uint8_t* __restrict__ skip, int HW, QParams qp,
                                                  const double* __restrict__ Echain, int16_t* __restrict__ tmp) {
     const int f = blockIdx.x / 3, c = blockIdx.x % 3;
@@ -430,7 +430,7 @@ int tzk_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8
     }
     hipLaunchKernelGGL(k_q_init, dim3(grid_for(fe * nframes, 256)), dim3(256), 0, ctx->stream, (int16_t*)d_tmp,
                        (const uint8_t*)d_skip, fe, nframes);
-    hipLaunchKernelGGL(k_q_heads, dim3(nframes * 3), dim3(512), 0, ctx->stream, orig, (const int16_t*)diff,
+    hipLaunchKernelGGL(k_q_heads, dim3(nframes * 3), dim3(64 * (QW + 1)), 0, ctx->stream, orig, (const int16_t*)diff,
                        (const uint8_t*)d_skip, HW, qp, (const double*)d_E, (int16_t*)d_tmp);
     hipLaunchKernelGGL(k_q_last, dim3(nblk, nframes), dim3(256), 0, ctx->stream, (const int16_t*)d_tmp,
                        (const uint8_t*)d_skip, HW, nblk, (int16_t*)d_carry);
@@ -452,10 +452,11 @@ int tzk_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8
 __global__ __launch_bounds__(256) void k_sdelta(const int16_t* __restrict__ in, size_t n, int has_carry, int16_t carry,
                                                 int apply_offset, int16_t* __restrict__ out,
                                                 unsigned long long* __restrict__ hist) {
-    __shared__ unsigned lh[TZ_NBINS + 1];
+    __shared__ unsigned lhs[4][TZ_NBINS + 1];  // one sub-histogram per wave: 4x less atomic contention
+    unsigned* lh = lhs[threadIdx.x >> 6];
     const bool do_hist = hist != nullptr;
     if (do_hist) {
-        for (int k = threadIdx.x; k < TZ_NBINS + 1; k += 256) lh[k] = 0;
+        for (int k = threadIdx.x; k < 4 * (TZ_NBINS + 1); k += 256) (&lhs[0][0])[k] = 0;
         __syncthreads();
     }
     const int dominant = apply_offset ? TZ_OFFSET : 0;
@@ -496,8 +497,10 @@ __global__ __launch_bounds__(256) void k_sdelta(const int16_t* __restrict__ in, 
         for (int s = 32; s >= 1; s >>= 1) ndom += __shfl_down(ndom, s);
         if ((threadIdx.x & 63) == 0 && ndom && dominant >= 0 && dominant < TZ_NBINS) atomicAdd(&lh[dominant], ndom);
         __syncthreads();
-        for (int k = threadIdx.x; k < TZ_NBINS; k += 256)
-            if (lh[k]) atomicAdd(&hist[k], (unsigned long long)lh[k]);
+        for (int k = threadIdx.x; k < TZ_NBINS; k += 256) {
+            unsigned c = lhs[0][k] + lhs[1][k] + lhs[2][k] + lhs[3][k];
+            if (c) atomicAdd(&hist[k], (unsigned long long)c);
+        }
     }
 }
 
@@ -509,10 +512,11 @@ __global__ __launch_bounds__(256) void k_delta_sd_fused(const float4* __restrict
                                                         const uint8_t* __restrict__ zero_mask, size_t n8,
                                                         unsigned frame_elems8, int apply_offset,
                                                         short8* __restrict__ out, unsigned long long* __restrict__ hist) {
-    __shared__ unsigned lh[TZ_NBINS + 1];
+    __shared__ unsigned lhs[4][TZ_NBINS + 1];  // one sub-histogram per wave: 4x less atomic contention
+    unsigned* lh = lhs[threadIdx.x >> 6];
     const bool do_hist = hist != nullptr;
     if (do_hist) {
-        for (int k = threadIdx.x; k < TZ_NBINS + 1; k += 256) lh[k] = 0;
+        for (int k = threadIdx.x; k < 4 * (TZ_NBINS + 1); k += 256) (&lhs[0][0])[k] = 0;
         __syncthreads();
     }
     const int dominant = apply_offset ? TZ_OFFSET : 0;
@@ -558,8 +562,10 @@ __global__ __launch_bounds__(256) void k_delta_sd_fused(const float4* __restrict
         for (int s = 32; s >= 1; s >>= 1) ndom += __shfl_down(ndom, s);
         if ((threadIdx.x & 63) == 0 && ndom && dominant >= 0 && dominant < TZ_NBINS) atomicAdd(&lh[dominant], ndom);
         __syncthreads();
-        for (int k = threadIdx.x; k < TZ_NBINS; k += 256)
-            if (lh[k]) atomicAdd(&hist[k], (unsigned long long)lh[k]);
+        for (int k = threadIdx.x; k < TZ_NBINS; k += 256) {
+            unsigned c = lhs[0][k] + lhs[1][k] + lhs[2][k] + lhs[3][k];
+            if (c) atomicAdd(&hist[k], (unsigned long long)c);
+        }
     }
 }
 
