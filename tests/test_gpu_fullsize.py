@@ -91,3 +91,39 @@ def test_batch_invariance_of_the_rollout(ctx):
     ctx.prepare(512, 512, max_batch=1)  # same windows, one at a time
     ctx.rollout(frames, 0, 4)
     assert np.array_equal(a, ctx.get_predictions())
+
+
+def test_cfg4_full_length_on_one_gpu(ctx):
+    """BASELINE configs[3] at its full size (320 frames of 1024x1024, eight 40-frame windows):
+    1.0e9 elements through every kernel with device-resident buffers; round trip within the bound."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(4)
+    nt, h, w = 320, 1024, 1024
+    base = torch.poisson(torch.full((nt, h, w), 3.0, device=dev), generator=g)
+    yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+    for k in range(12):  # a few drifting Bragg-like peaks
+        y0, x0 = 100 + 70 * k, 90 + 75 * k
+        t = torch.arange(nt, device=dev).view(-1, 1, 1)
+        base += 180 * torch.exp(-(((yy - y0 - 0.2 * t) ** 2 + (xx - x0 + 0.1 * t) ** 2) / 18.0))
+    frames = base.clamp(0, 255).to(torch.uint8)[..., None].expand(nt, h, w, 3).contiguous()
+    del base
+    ctx.prepare(1024, 1024, max_batch=8)
+    payload = torch.empty(nt * h * w * 3, dtype=torch.int16, device=dev)
+    # this context runs on its OWN HIP stream: order it against torch's stream explicitly
+    torch.cuda.synchronize()
+    key, _ = ctx.rollout(frames, 0, 40)
+    assert key.nonzero()[0].tolist() == list(range(0, 320, 40))
+    _, table, _ = ctx.encode("abs", [2.0], True, payload=payload)
+    ctx.synchronize()  # device outputs are asynchronous on the context's stream
+    assert 0 < len(table) <= 1021 and int(payload.max()) < len(table) and int(payload.min()) >= 0
+    keys = torch.zeros_like(frames)
+    kidx = torch.from_numpy(key).to(dev)
+    keys[kidx] = frames[kidx]
+    out = torch.empty_like(frames)
+    torch.cuda.synchronize()
+    ctx.rollout_decode(keys, 0)
+    ctx.decode(payload, table, out=out)
+    ctx.synchronize()
+    err = (out.to(torch.int16) - frames.to(torch.int16)).abs()
+    assert int(err.max()) <= 3 and int(err[kidx].max()) == 0

@@ -3,7 +3,12 @@
 This is the whole Python <-> native boundary: plain pointers and sizes.  Arguments may be
 numpy arrays (host memory) or torch CUDA tensors (device memory; only `.data_ptr()` is
 used).  There is NO CPU fallback: if the library is missing or no GPU is usable the calls
-raise."""
+raise.
+
+Streams: work on device buffers is enqueued on the context's stream and is complete only after
+`Context.synchronize()`.  When torch produces or consumes those buffers either create the
+context on torch's stream (`Context(dev, stream=torch.cuda.current_stream().cuda_stream)`, as
+bench.py does) or synchronise both sides explicitly."""
 import ctypes as C
 import os
 
