@@ -96,3 +96,44 @@ def test_cli_with_the_reference_model_files(tmp_path):
     decompress.run(mdir, cdir, udir, True, False)
     got = np.stack([np.array(Image.open(os.path.join(udir, "frame_%03d.png" % t))) for t in range(9)])
     np.testing.assert_array_equal(got, frames)
+
+
+def test_cli_under_torchrun_shards_windows_and_writes_identical_files(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m tezip_amd.tezip -c/-u ...`: the two
+    ranks (gloo transport, both on GPU 0 here) shard the windows; the files must be byte-identical
+    to the single-process run and decode to the same images."""
+    import socket
+    import subprocess
+    import sys
+    from PIL import Image
+    cfg = PredNetConfig(stack_sizes=(3, 16, 32))
+    nt, h, w = 14, 24, 40
+    frames = synth.translating_scene(nt, h, w, seed=15)
+    mdir = str(tmp_path / "model")
+    weights.save_model(mdir, cfg, cfg.init_weights(seed=8, bias_scale=0.1), 24, 40)
+    ddir = _write(tmp_path, frames, False)
+    one, two, out2 = str(tmp_path / "one"), str(tmp_path / "two"), str(tmp_path / "out2")
+    compress.run(mdir, ddir, one, 1, 4, None, "abs", [2.0], True, False, True)
+
+    def torchrun(args):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, TEZIP_DIST_BACKEND="gloo", TEZIP_SINGLE_DEVICE="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), "-m", "tezip_amd.tezip"] + args
+        r = subprocess.run(cmd, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+    torchrun(["-c", mdir, ddir, two, "-p", "1", "-w", "4", "-m", "abs", "-b", "2"])
+    for name in ("filename.txt", "key_frame.dat", "entropy.dat"):
+        assert open(os.path.join(one, name), "rb").read() == open(os.path.join(two, name), "rb").read(), name
+    torchrun(["-u", mdir, two, out2])
+    got = np.stack([np.array(Image.open(os.path.join(out2, "frame_%03d.png" % t))) for t in range(nt)])
+    assert np.abs(got.astype(int) - frames.astype(int)).max() <= 3
+    udir = str(tmp_path / "out1")
+    decompress.run(mdir, one, udir, True, False)
+    ref = np.stack([np.array(Image.open(os.path.join(udir, "frame_%03d.png" % t))) for t in range(nt)])
+    np.testing.assert_array_equal(got, ref)

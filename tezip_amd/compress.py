@@ -15,6 +15,7 @@ import time
 import numpy as np
 
 from . import _lib, weights, zstd
+from . import dist as tzdist
 from .data_utils import padding_shape
 
 
@@ -83,14 +84,16 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
     if not GPU_FLAG:
         print("ERROR: this build runs the compression path on an AMD MI355X only (no CPU path).")
         exit()
-    if not os.path.exists(OUTPUT_DIR):
+    rank0 = tzdist.active() is None or tzdist.active()[0] == 0
+    if rank0 and not os.path.exists(OUTPUT_DIR):
         os.mkdir(OUTPUT_DIR)
     origine_img, files, isRGB = load_images(DATA_DIR)
 
-    with open(os.path.join(OUTPUT_DIR, 'filename.txt'), 'w', encoding='UTF-8') as f:
-        f.write(f"{int(isRGB)}\n")
-        for file_name in files:
-            f.write("%s\n" % file_name)
+    if rank0:
+        with open(os.path.join(OUTPUT_DIR, 'filename.txt'), 'w', encoding='UTF-8') as f:
+            f.write(f"{int(isRGB)}\n")
+            for file_name in files:
+                f.write("%s\n" % file_name)
 
     nt, H, W = origine_img.shape[:3]
     cfg, wts, model_shape = open_model(WEIGHTS_DIR)
@@ -104,33 +107,52 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
         print("ERROR: need at least warm_up+2 images (%d given, warm_up %d)." % (nt, PREPROCESS))
         exit()
 
-    nwin = 1 if WINDOW_SIZE is None else max(1, (nt - PREPROCESS + WINDOW_SIZE - 1) // WINDOW_SIZE)
+    job = tzdist.active()
+    if job and WINDOW_SIZE is None:
+        if job[0] == 0:
+            print("NOTE: DWP (-t) finds its windows sequentially and does not shard: running on rank 0 only.")
+        else:
+            return
+        job = None
+    if job:
+        device = tzdist.init_from_env()
+        nt_local = max(b - a for a, b in tzdist.plan_shards(nt, PREPROCESS, WINDOW_SIZE, job[1]))
+        nwin = max(1, (nt_local + WINDOW_SIZE - 1) // WINDOW_SIZE)
+    else:
+        nwin = 1 if WINDOW_SIZE is None else max(1, (nt - PREPROCESS + WINDOW_SIZE - 1) // WINDOW_SIZE)
     ctx = make_context(cfg, wts, hp, wp, min(nwin, 64), device)
     try:
-        if VERBOSE:
-            ctx.prof_enable(True)
-        t0 = time.time()
-        key, mse = ctx.rollout(origine_img, PREPROCESS, WINDOW_SIZE, THRESHOLD, want_mse=bool(VERBOSE))
-        if VERBOSE:
-            for i in range(PREPROCESS + 1, nt):
-                print("MSE:", mse[i])
-                if key[i] and i > PREPROCESS:
-                    print("move key point")
-            print("predict:{0}".format(time.time() - t0) + "[sec]")
+        if job:
+            # frame windows sharded over the ranks (tezip_amd/dist.py); rank 0 writes the files
+            res = tzdist.compress_sharded(tzdist.HipEngine(ctx), origine_img, PREPROCESS, WINDOW_SIZE, MODE, BOUND_VALUE,
+                                          ENTROPY_RUN)
+            if res is None:
+                return
+            payload, table, key = res
+        else:
+            if VERBOSE:
+                ctx.prof_enable(True)
+            t0 = time.time()
+            key, mse = ctx.rollout(origine_img, PREPROCESS, WINDOW_SIZE, THRESHOLD, want_mse=bool(VERBOSE))
+            if VERBOSE:
+                for i in range(PREPROCESS + 1, nt):
+                    print("MSE:", mse[i])
+                    if key[i] and i > PREPROCESS:
+                        print("move key point")
+                print("predict:{0}".format(time.time() - t0) + "[sec]")
+            payload, table, _ = ctx.encode(MODE, BOUND_VALUE, ENTROPY_RUN)
+            if VERBOSE:
+                prof = ctx.prof_get()
+                print("error_bound:{0}".format(prof["quant"][0] / 1e3) + "[sec]")
+                print("finding_difference:{0}".format(prof["spatial_delta_hist"][0] / 1e3) + "[sec]")
+                if ENTROPY_RUN:
+                    print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
 
         # key frames (compress.py:271-278)
         key_frame = np.zeros_like(origine_img)
         key_frame[key] = origine_img[key]
         with open(os.path.join(OUTPUT_DIR, "key_frame.dat"), mode='wb') as f:
             f.write(zstd.compress_array(key_frame, 9))
-
-        payload, table, _ = ctx.encode(MODE, BOUND_VALUE, ENTROPY_RUN)
-        if VERBOSE:
-            prof = ctx.prof_get()
-            print("error_bound:{0}".format(prof["quant"][0] / 1e3) + "[sec]")
-            print("finding_difference:{0}".format(prof["spatial_delta_hist"][0] / 1e3) + "[sec]")
-            if ENTROPY_RUN:
-                print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
         stream = build_stream(payload, table if ENTROPY_RUN else None, (1, nt, H, W, 3), PREPROCESS)
         with open(os.path.join(OUTPUT_DIR, "entropy.dat"), mode='wb') as f:
             f.write(zstd.compress_array(stream, 9))

@@ -8,6 +8,7 @@ import time
 import numpy as np
 
 from . import _lib, zstd
+from . import dist as tzdist
 from .compress import make_context, open_model
 from .data_utils import padding_shape
 
@@ -31,7 +32,9 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
     if not GPU_FLAG:
         print("ERROR: this build runs the decompression path on an AMD MI355X only (no CPU path).")
         exit()
-    if not os.path.exists(OUTPUT_DIR):
+    job = tzdist.active()
+    rank0 = job is None or job[0] == 0
+    if rank0 and not os.path.exists(OUTPUT_DIR):
         os.mkdir(OUTPUT_DIR)
     isRGB = True
     try:
@@ -70,20 +73,28 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
         print("number of images", nt)
         exit()
 
+    if job:
+        device = tzdist.init_from_env()
     ctx = make_context(cfg, wts, hp, wp, 64 if nt > 64 else max(1, nt), device)
     try:
-        if VERBOSE:
-            ctx.prof_enable(True)
-        t0 = time.time()
-        ctx.rollout_decode(np.ascontiguousarray(key_frames), warm_up)
-        if VERBOSE:
-            print("predict:{0}".format(time.time() - t0) + "[sec]")
-        frames = ctx.decode(np.ascontiguousarray(payload), None if table is None else np.ascontiguousarray(table))
-        if VERBOSE:
-            prof = ctx.prof_get()
-            if table is not None:
-                print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
-            print("finding_difference:{0}".format(prof["undelta_scan"][0] / 1e3) + "[sec]")
+        if job:
+            # key intervals sharded over the ranks (tezip_amd/dist.py); rank 0 saves the images
+            frames = tzdist.decompress_sharded(tzdist.HipEngine(ctx), key_frames, payload, table, warm_up)
+            if frames is None:
+                return
+        else:
+            if VERBOSE:
+                ctx.prof_enable(True)
+            t0 = time.time()
+            ctx.rollout_decode(np.ascontiguousarray(key_frames), warm_up)
+            if VERBOSE:
+                print("predict:{0}".format(time.time() - t0) + "[sec]")
+            frames = ctx.decode(np.ascontiguousarray(payload), None if table is None else np.ascontiguousarray(table))
+            if VERBOSE:
+                prof = ctx.prof_get()
+                if table is not None:
+                    print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
+                print("finding_difference:{0}".format(prof["undelta_scan"][0] / 1e3) + "[sec]")
     finally:
         ctx.close()
 

@@ -80,6 +80,40 @@ def _dist():
     return dist
 
 
+def active():
+    """(rank, world) when this process is part of an initialised torch.distributed job with
+    more than one rank, else None."""
+    try:
+        import torch.distributed as dist
+    except Exception:
+        return None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_rank(), dist.get_world_size()
+    return None
+
+
+def init_from_env():
+    """Join the job described by torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_*), one process per GPU.  Backend: RCCL ("nccl"), or TEZIP_DIST_BACKEND (e.g. "gloo"
+    to rehearse several ranks on one GPU).  Returns the local device index."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("TEZIP_SINGLE_DEVICE"):
+        local = 0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            backend = os.environ.get("TEZIP_DIST_BACKEND", "nccl")
+            if backend == "nccl":
+                torch.cuda.set_device(local)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend)
+    return local
+
+
 def _device(dist):
     import torch
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")

@@ -98,6 +98,9 @@ def check_compress(arg):
 
 
 def main(arg):
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # launched by torch.distributed.run: one rank per GPU
+        from . import dist as tzdist
+        tzdist.init_from_env()
     gpu = probe_gpu(arg.force)
     print("GPU MODE" if gpu else "CPU MODE")
     chosen = [name for name in ("learn", "compress", "uncompress") if getattr(arg, name) is not None]
