@@ -56,6 +56,9 @@ struct tz_ctx {
     // out of it is truly asynchronous and the memory outlives the caller's locals
     uint8_t* ring = nullptr;
     size_t ring_size = 0, ring_pos = 0;
+    // index table of the static rollout schedule (SWP encoder / decoder replay): [batches][3][stride]
+    int* d_sched = nullptr;
+    size_t cap_sched = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool prof_on = false;
@@ -126,5 +129,7 @@ int tzk_sse(tz_ctx*, const uint8_t* orig, const float* pred, int nframes, int H,
 void tz_model_free(tz_ctx* ctx);
 int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int* h_in_idx, const int* h_out_idx,
                            const uint8_t* d_frames_u8, int H, int W, const float* d_in_stack, float* d_out_stack);
+int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride, const uint8_t* d_frames_u8, int H, int W,
+                               const float* d_in_stack, float* d_out_stack);
 int tz_model_c0_dev(tz_ctx* ctx, const float** c0);
 int tz_model_dims(tz_ctx* ctx, int* Hp, int* Wp, int* max_batch);

@@ -848,7 +848,6 @@ int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int
     tz_model* m = ctx->model;
     if (!m || !m->prepared) return tz_fail(ctx, TZ_ERR_STATE, "model not prepared");
     if (n < 1 || n > m->maxB) return tz_fail(ctx, TZ_ERR_INVALID, "batch %d outside 1..%d", n, m->maxB);
-    const int L = m->L, Hp = m->Hp, Wp = m->Wp;
     std::vector<int> idx(3 * (size_t)m->maxB, 0);
     for (int i = 0; i < n; ++i) {
         idx[i] = h_in_is_key[i];
@@ -856,14 +855,25 @@ int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int
         idx[2 * m->maxB + i] = h_out_idx[i];
     }
     TZ_TRY(tz_upload(ctx, m->d_idx, idx.data(), sizeof(int) * idx.size()));
+    return tz_model_predict_batch_dev(ctx, n, m->d_idx, m->maxB, d_frames_u8, H, W, d_in_stack, d_out_stack);
+}
+
+// Launch-only form: d_idx holds [is_key | in_idx | out_idx], each `stride` ints apart, already
+// on the device.  Nothing here allocates or copies.
+int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride, const uint8_t* d_frames_u8, int H, int W,
+                               const float* d_in_stack, float* d_out_stack) {
+    tz_model* m = ctx->model;
+    if (!m || !m->prepared) return tz_fail(ctx, TZ_ERR_STATE, "model not prepared");
+    if (n < 1 || n > m->maxB) return tz_fail(ctx, TZ_ERR_INVALID, "batch %d outside 1..%d", n, m->maxB);
+    const int L = m->L, Hp = m->Hp, Wp = m->Wp;
     auto hl = [&](int l) { return Hp >> l; };
     auto wl = [&](int l) { return Wp >> l; };
     auto npx = [&](int l) { return (long long)hl(l) * wl(l); };
     {
         tz_prof_scope ps(ctx, TZP_ERR0);
         int gx = (int)std::min<long long>((npx(0) + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_err0, dim3(gx, n), dim3(256), 0, ctx->stream, d_frames_u8, H, W, d_in_stack, m->d_idx,
-                           m->d_idx + m->maxB, m->Ahat0[0], Hp, Wp, m->stack[0], m->E[0]);
+        hipLaunchKernelGGL(k_err0, dim3(gx, n), dim3(256), 0, ctx->stream, d_frames_u8, H, W, d_in_stack, d_idx,
+                           d_idx + stride, m->Ahat0[0], Hp, Wp, m->stack[0], m->E[0]);
         TZ_HIP(ctx, hipGetLastError());
     }
     for (int l = 0; l < L - 1; ++l) {  // t0 bottom-up
@@ -907,7 +917,7 @@ int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int
         a.Cout = m->stack[0];
         a.out0 = d_out_stack;
         a.out0_nstride = npx(0) * m->stack[0];
-        a.out_idx = m->d_idx + 2 * m->maxB;
+        a.out_idx = d_idx + 2 * stride;
         a.clip1 = 1;
         TZ_TRY(launch_conv(ctx, pc.NT, EPI_RELU, a, n));
     }
