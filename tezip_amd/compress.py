@@ -11,12 +11,25 @@ Output directory:
 import glob
 import os
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
 from . import _lib, weights, zstd
 from . import dist as tzdist
 from .data_utils import padding_shape
+
+
+def io_threads():
+    """Threads for PNG decode/encode: the CPUs this process may use, at most 16."""
+    try:
+        n = len(os.sched_getaffinity(0))
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
 
 
 def load_images(data_dir):
@@ -33,14 +46,18 @@ def load_images(data_dir):
             print("ERROR: input image is {0}. Only RGB and grayscale are supported.".format(image_mode))
             exit()
         is_rgb = image_mode == 'RGB'
-        frames, files = [], []
-        for path in file_paths:
+
+        def decode(path):
             img = Image.open(path)
             arr = np.array(img if is_rgb else img.convert('RGB'))
             if arr.ndim != 3 or arr.shape[2] != 3:
                 raise IndexError(path)
-            frames.append(arr)
-            files.append(os.path.basename(path))
+            return arr
+
+        # PIL's codecs release the GIL: decode on a few threads (order is kept by map)
+        with ThreadPoolExecutor(max_workers=io_threads()) as pool:
+            frames = list(pool.map(decode, file_paths))
+        files = [os.path.basename(path) for path in file_paths]
         stack = np.ascontiguousarray(np.stack(frames), dtype=np.uint8)
     except (PermissionError, IndexError, UnidentifiedImageError, IsADirectoryError, ValueError):
         print(data_dir, "contains files or folders that are not images.")

@@ -98,10 +98,14 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
     finally:
         ctx.close()
 
+    from concurrent.futures import ThreadPoolExecutor
     from PIL import Image
-    for j in range(nt):
-        img = Image.fromarray(frames[j])
-        if j == 0:
-            print("save as RGB" if isRGB else "save as gray")
+    from .compress import io_threads
+    print("save as RGB" if isRGB else "save as gray")
+
+    def save(j):
         # decompress.py:272-278: the grayscale save is overwritten by an unconditional RGB save
-        img.save(os.path.join(OUTPUT_DIR, file_names[j]))
+        Image.fromarray(frames[j]).save(os.path.join(OUTPUT_DIR, file_names[j]))
+
+    with ThreadPoolExecutor(max_workers=io_threads()) as pool:  # PIL's encoder releases the GIL
+        list(pool.map(save, range(nt)))
