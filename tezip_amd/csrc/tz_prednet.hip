@@ -82,13 +82,21 @@ enum { MAP_LINEAR = 0, MAP_POOL = 1, MAP_PARITY = 2 };
 //  POOL:   the 4 accumulator registers of a lane form one 2x2 pooling window.
 //  PARITY: every 16-row MFMA tile holds pixels of ONE parity class (py&1, px&1), so that the
 //          parity-specific collapsed weights of an upsampled source can be its B operand.
+// Tile shapes and patch strides were chosen by exhaustive search so that every ds_read_b32 of
+// an A fragment (16 rows x 2 k per 32-lane group) is bank-conflict free at stride 18 for LINEAR
+// and POOL (PARITY keeps a 2-way conflict, see below; LDS is not the critical path).
 template <int MAP>
 __device__ __forceinline__ void row_to_patch(int m, int& py, int& px) {
     int w = m >> 5, mt = (m >> 4) & 1, r16 = m & 15;
     if (MAP == MAP_POOL) {
-        py = 2 * w + ((r16 & 3) >> 1);
-        px = 8 * mt + 2 * (r16 >> 2) + (r16 & 1);
+        // M-tile = 8 rows x 2 columns = four stacked 2x2 windows (conflict-free at stride 18)
+        int T = 2 * w + mt;
+        py = 8 * (T >> 3) + 2 * (r16 >> 2) + ((r16 & 3) >> 1);
+        px = 2 * (T & 7) + (r16 & 1);
     } else if (MAP == MAP_PARITY) {
+        // M-tile = two rows x 8 columns of the 8x8 grid of one parity class (2-way conflicts on its
+        // A reads; the conflict-free alternative -- rows (sub, sub+4) at stride 17 -- needs 4-byte
+        // patch stores and measured 2.5 % slower)
         int T = 2 * w + mt, pc = T >> 2, sub = T & 3;
         py = 2 * (2 * sub + (r16 >> 3)) + (pc >> 1);
         px = 2 * (r16 & 7) + (pc & 1);
@@ -106,9 +114,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int NT, int EPI, bool UPS>
+// FULLK: every source has a multiple of 16 channels, so every same-resolution step runs all four
+// k-steps (lets the compiler schedule the 32 MFMAs of a step as one straight-line block).
+template <int NT, int EPI, bool UPS, bool FULLK>
 __global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
-    constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : ((EPI == EPI_LSTM || EPI == EPI_LSTM_PACKED) ? MAP_PARITY : MAP_LINEAR);
+    // parity tiles only where an upsampled source needs them (the top level has none)
+    constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
+    constexpr int SAH = SA;                           // floats per pixel of the same-resolution patch
+    constexpr int SAL = SA;                           // ... of the half-resolution patch
     constexpr int NTC = NT * 16;
     constexpr int SB = NTC + ((NTC % 32) == 0 ? 16 : 0);
     constexpr int QPR = NTC / 4;                     // float4 items per weight row
@@ -180,9 +193,17 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
         for (int j = 0; j < A_PER_THREAD; ++j) {
             int i = tid + NTHR * j;
             if (up ? (j == 0 && i < LPIX * 4) : (i < A_ITEMS)) {
-                float* d = sA + (i >> 2) * SA + 4 * aq;
-                *(float2*)d = make_float2(ra[j].x, ra[j].y);
-                *(float2*)(d + 2) = make_float2(ra[j].z, ra[j].w);
+                if (up || (SAH & 1) == 0) {
+                    float* d = sA + (i >> 2) * (up ? SAL : SAH) + 4 * aq;
+                    *(float2*)d = make_float2(ra[j].x, ra[j].y);
+                    *(float2*)(d + 2) = make_float2(ra[j].z, ra[j].w);
+                } else {  // odd stride: only 4-byte alignment
+                    float* d = sA + (i >> 2) * SAH + 4 * aq;
+                    d[0] = ra[j].x;
+                    d[1] = ra[j].y;
+                    d[2] = ra[j].z;
+                    d[3] = ra[j].w;
+                }
             }
         }
     };
@@ -243,8 +264,8 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
         for (int mt = 0; mt < MT; ++mt) {
             int py, px;
             row_to_patch<MAP>(wv * 32 + mt * 16 + (lane & 15), py, px);
-            arow_hi[mt] = (py * PW + px) * SA + (lane >> 4);
-            arow_lo[mt] = (((py >> 1) + (py & 1)) * LW + (px >> 1) + (px & 1)) * SA + (lane >> 4);
+            arow_hi[mt] = (py * PW + px) * SAH + (lane >> 4);
+            arow_lo[mt] = (((py >> 1) + (py & 1)) * LW + (px >> 1) + (px & 1)) * SAL + (lane >> 4);
         }
         const int wcls = MAP == MAP_PARITY ? (wv >> 1) : 0;  // parity class of this wave's rows
         const int boff = (lane >> 4) * SB + (lane & 15);
@@ -271,8 +292,8 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
                 // one compute body for both kinds of step: the first pair of k-steps always runs,
                 // the second pair only when the step holds more than 8 channels
                 const int tap = up ? st / UPN : st;
-                const int toff = (up ? ((tap >> 1) * LW + (tap & 1)) : ((tap / 3) * PW + (tap % 3))) * SA;
-                const bool second = up ? (UPH == 16) : (cw > 8);
+                const int toff = up ? ((tap >> 1) * LW + (tap & 1)) * SAL : ((tap / 3) * PW + (tap % 3)) * SAH;
+                const bool second = up ? (UPH == 16) : (FULLK || cw > 8);
                 const float* pa = sA + toff + (up ? UPH * (st % UPN) : 0);
                 const float* pb = sB + cur * BUF + boff + (up ? wcls * UPH * SB : 0);
                 int ar[MT];
@@ -617,21 +638,25 @@ static int gate_cols(tz_ctx* ctx, const tz_model* m, int l, std::vector<ColSrc>*
     return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "R_stack_sizes[%d]=%d: need a multiple of 16 or <= 4", l, R);
 }
 
-template <int NT, int EPI, bool UPS>
+template <int NT, int EPI, bool UPS, bool FULLK>
 static void launch_conv_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
     int blocks = a.ncb * a.tiles_x * a.tiles_y * nbatch;
-    hipLaunchKernelGGL((k_conv3x3<NT, EPI, UPS>), dim3(blocks), dim3(NTHR), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k_conv3x3<NT, EPI, UPS, FULLK>), dim3(blocks), dim3(NTHR), 0, ctx->stream, a);
 }
 
 static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbatch) {
     tz_prof_scope ps(ctx, TZP_CONV);
-    bool ups = false;
-    for (int s = 0; s < a.nsrc; ++s) ups = ups || a.src[s].up;
-#define TZ_CASE(nt, e, u)                      \
-    if (NT == nt && epi == e && ups == u) {    \
-        launch_conv_t<nt, e, u>(ctx, a, nbatch); \
-        TZ_HIP(ctx, hipGetLastError());        \
-        return TZ_OK;                          \
+    bool ups = false, fullk = true;
+    for (int s = 0; s < a.nsrc; ++s) {
+        ups = ups || a.src[s].up;
+        fullk = fullk && (a.src[s].C % 16) == 0;
+    }
+#define TZ_CASE(nt, e, u)                                                   \
+    if (NT == nt && epi == e && ups == u) {                                 \
+        if (fullk) launch_conv_t<nt, e, u, true>(ctx, a, nbatch);           \
+        else launch_conv_t<nt, e, u, false>(ctx, a, nbatch);                \
+        TZ_HIP(ctx, hipGetLastError());                                     \
+        return TZ_OK;                                                       \
     }
     TZ_CASE(1, EPI_RAW, false) TZ_CASE(4, EPI_RAW, false)
     TZ_CASE(1, EPI_RELU, false) TZ_CASE(3, EPI_RELU, false) TZ_CASE(4, EPI_RELU, false)
