@@ -30,6 +30,7 @@
 // registers during the 9 taps.  LDS row strides (18 / NT*16[+16] floats) keep fragment reads
 // conflict free.  33-44 KB LDS, <=100 VGPRs, 512 threads => 3 workgroups (24 waves) per CU.
 #include <algorithm>
+#include <type_traits>
 
 #include "tz_internal.h"
 #include "tz_math.hip.h"
@@ -51,6 +52,8 @@ struct ConvArgs {
     int nsrc;
     int H, W, tiles_x, tiles_y, ncb;
     const float* Wp;    // [weight slots * 16][ncols], slot order = the K-loop order (see pack_conv)
+    const float* Wimg;  // the same weights in LDS image order for k_conv16 (see pack_conv), or null
+    const float* zero;  // >= 16 bytes of zeros: LDS-DMA source of out-of-image patch pixels
     int ncols;
     const float* bias;  // [ncols]
     const float* init;  // [H*W][ncols] accumulator start (G0), or null -> bias
@@ -112,6 +115,137 @@ __device__ __forceinline__ void row_to_patch(int m, int& py, int& px) {
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Fused epilogues on the accumulator tiles of one wave (shared by both convolution kernels):
+// acc[mt][nt], element r <-> GEMM row (lane>>4)*4 + r of M-tile mt, column lane&15 of N-tile nt.
+template <int NT, int EPI, int MAP>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int n, int cb, int ty0, int tx0,
+                                              int wv, int lane) {
+    constexpr int NTC = NT * 16;
+    const int col0 = cb * NTC + (lane & 15);
+    auto out_pix = [&](int mt, int r, int& y, int& x) {
+        int py, px;
+        row_to_patch<MAP>(wv * 32 + mt * 16 + (lane >> 4) * 4 + r, py, px);
+        y = ty0 + py;
+        x = tx0 + px;
+    };
+    const int j = lane & 15;
+    if (EPI == EPI_RAW) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int y, x;
+                out_pix(mt, r, y, x);
+                if (y >= a.H || x >= a.W) continue;
+                long long pix = (long long)y * a.W + x;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a.out0[pix * a.ncols + col0 + nt * 16] = acc[mt][nt][r];
+            }
+    } else if (EPI == EPI_RELU) {
+        float* o = a.out0 + (long long)(a.out_idx ? a.out_idx[n] : n) * a.out0_nstride;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int y, x;
+                out_pix(mt, r, y, x);
+                if (y >= a.H || x >= a.W) continue;
+                long long pix = (long long)y * a.W + x;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    int ch = col0 + nt * 16;
+                    if (ch < a.Cout) {
+                        float v = tz_relu(acc[mt][nt][r]);
+                        if (a.clip1 && v > 1.0f) v = 1.0f;
+                        o[pix * a.Cout + ch] = v;
+                    }
+                }
+            }
+    } else if (EPI == EPI_LSTM) {
+        // columns of this block: [i | f | g | o] x 16 channels of channel group cb
+        // prednet.py:255-259: c = f*c_prev + i*g ; r = o*tanh(c)
+        const int ch = cb * 16 + j, R = a.Cout;
+        float* o0 = a.out0 + (long long)n * a.out0_nstride;
+        float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int y, x;
+                out_pix(mt, r, y, x);
+                if (y >= a.H || x >= a.W) continue;
+                long long pix = (long long)y * a.W + x;
+                float gi = tz_hard_sigmoid(acc[mt][0 % NT][r]);
+                float gf = tz_hard_sigmoid(acc[mt][1 % NT][r]);
+                float gg = tz_tanh(acc[mt][2 % NT][r]);
+                float go = tz_hard_sigmoid(acc[mt][3 % NT][r]);
+                float cp = a.aux ? a.aux[pix * R + ch] : 0.0f;
+                float t1 = gf * cp;
+                float t2 = gi * gg;
+                float c = t1 + t2;
+                float rr = go * tz_tanh(c);
+                o0[pix * R + ch] = rr;
+                if (o1) o1[pix * R + ch] = c;
+            }
+    } else if (EPI == EPI_LSTM_PACKED) {
+        // one 16-column tile holds [i(R) f(R) g(R) o(R)], R <= 4: gather the 4 gates by shuffle
+        const int R = a.R;
+        float* o0 = a.out0 + (long long)n * a.out0_nstride;
+        float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
+        const int lbase = lane & 48;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[mt][0][r];
+                float vi = __shfl(v, lbase + (j % 4), 64);
+                float vf = __shfl(v, lbase + ((j % 4) + R) % 16, 64);
+                float vg = __shfl(v, lbase + ((j % 4) + 2 * R) % 16, 64);
+                float vo = __shfl(v, lbase + ((j % 4) + 3 * R) % 16, 64);
+                int y, x;
+                out_pix(mt, r, y, x);
+                if (j >= R || y >= a.H || x >= a.W) continue;
+                long long pix = (long long)y * a.W + x;
+                float gi = tz_hard_sigmoid(vi), gf = tz_hard_sigmoid(vf), gg = tz_tanh(vg), go = tz_hard_sigmoid(vo);
+                float cp = a.aux ? a.aux[pix * R + j] : 0.0f;
+                float t1 = gf * cp;
+                float t2 = gi * gg;
+                float c = t1 + t2;
+                float rr = go * tz_tanh(c);
+                o0[pix * R + j] = rr;
+                if (o1) o1[pix * R + j] = c;
+            }
+    } else if (EPI == EPI_POOL_ERR) {
+        // prednet.py:289-291 then 274-277 of the next level: A = maxpool2x2(relu(conv));
+        // e = [relu(Ahat0 - A), relu(A - Ahat0)] written at the pooled resolution.
+        const int H2 = a.H >> 1, W2 = a.W >> 1, C = a.Cout;
+        float* o = a.out0 + (long long)n * a.out0_nstride;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int y, x;
+            out_pix(mt, 0, y, x);
+            int yp = y >> 1, xp = x >> 1;
+            if (yp >= H2 || xp >= W2) continue;
+            long long pp = (long long)yp * W2 + xp;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                int ch = col0 + nt * 16;
+                if (ch >= C) continue;
+                float m = tz_relu(acc[mt][nt][0]);
+#pragma unroll
+                for (int r = 1; r < 4; ++r) {
+                    float t = tz_relu(acc[mt][nt][r]);
+                    if (t > m) m = t;
+                }
+                float h = a.aux[pp * C + ch];
+                float d1 = h - m, d2 = m - h;
+                o[pp * 2 * C + ch] = tz_relu(d1);
+                o[pp * 2 * C + C + ch] = tz_relu(d2);
+            }
+        }
+    }
 }
 
 // FULLK: every source has a multiple of 16 channels, so every same-resolution step runs all four
@@ -283,12 +417,15 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
             const int cw = s.C - (blk >= nb0 ? blk - nb0 : blk) * 16;
             const bool more_blk = blk + 1 < nblk;
             const bool up_next = UPS && more_blk && (blk + 1 >= nb0 ? a.src[1].up : a.src[0].up) != 0;
-            if (more_blk) load_patch(blk + 1);
 #pragma unroll 1
             for (int st = 0; st < nsteps; ++st) {
                 const bool last = st == nsteps - 1;
                 if (!last) load_b(up ? slot0 + 4 * ((st + 1) / UPN) : slot0 + st + 1, up, (st + 1) % UPN);
                 else if (more_blk) load_b(slot0 + (up ? 16 : 9), up_next, 0);
+                // The next block's patch gather is issued AFTER this step's weight load: vmcnt
+                // retires in order, so the end-of-step wait for the (older) weight load leaves the
+                // patch loads in flight for one more step instead of forcing them after one.
+                if (st == 0 && more_blk) load_patch(blk + 1);
                 // one compute body for both kinds of step: the first pair of k-steps always runs,
                 // the second pair only when the step holds more than 8 channels
                 const int tap = up ? st / UPN : st;
@@ -332,124 +469,208 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
             }
         }
     }
+    conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane);
+}
 
-    // ---- epilogues
-    const int j = lane & 15;
-    if (EPI == EPI_RAW) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int y, x;
-                out_pix(mt, r, y, x);
-                if (y >= a.H || x >= a.W) continue;
-                long long pix = (long long)y * a.W + x;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) a.out0[pix * a.ncols + col0 + nt * 16] = acc[mt][nt][r];
+// ------------------------------------------------------------------------------------------
+// k_conv16: the same implicit GEMM (same tiles, same fmaf-chain order, same epilogues) for
+// convolutions whose sources all have a multiple of 16 channels -- every hot launch of levels >= 1.
+// All staging is LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, so the
+// K loop holds only accumulators, fragments and addresses (k_conv3x3 keeps a register-staged
+// prefetch of the next patch and weight chunk alive across its steps: 22 spilled VGPRs and a
+// vmcnt(0) in front of every use at the 80-VGPR budget; MFMA pipe 68-80 % busy at 2.39 GHz).
+//
+// An LDS-DMA writes wave-uniform base + lane*16 B, so both LDS images are lane-linear and the
+// layout work moves to the SOURCE address:
+//  * weights are packed on the host in image order [slot][column block][k-step][lane][4]: lane
+//    (g = lane>>4, j = lane&15) of k-step kk holds W[4kk+g][16nt+j], nt = 0..3 -- one
+//    ds_read_b128 per k-step gives the B fragments of all four column tiles, conflict free;
+//    a (slot, column block) chunk is 4 KB = four 1 KB wave-instructions;
+//  * the halo patch is [slot][16 channels] at 64 B per pixel (no padding possible), made 2-way
+//    conflict free for the ds_read_b32 A fragments by (a) XOR-ing the 16-byte quad index with
+//    (slot>>1)&3 and (b), for parity tiles, swapping the pixels of each x pair in rows with
+//    (y>>1) odd -- both applied to the per-lane source address; out-of-image pixels read a zero
+//    page.  18x18 pixels = 21 wave-instructions, the 10x10 half-resolution patch = 7.
+// Protocol per step: issue the DMA of the next step's weights into the other buffer, MFMAs of
+// this step, s_waitcnt vmcnt(0), barrier.  The patch is single-buffered: after the last step of
+// a block its DMA is issued, waited for and published by one more barrier (the other workgroups
+// of the CU cover that gap).  29-37 KB LDS, no spills: 3-4 workgroups per CU.
+static constexpr int P16_PIECES = 21;                   // 1 KB pieces of the patch region (324 px -> 20.25)
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int NT, int EPI, bool UPS>
+__global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
+    constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
+    constexpr int WPIECES = UPS ? 8 : 4;                // 1 KB pieces per weight buffer
+    __shared__ __attribute__((aligned(16))) float smem[(P16_PIECES + 2 * WPIECES) * 256];
+    float* const sA = smem;
+    float* const sW = smem + P16_PIECES * 256;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id, scalar
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = bid % a.ncb;
+    bid /= a.ncb;
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int tile = bid % ntiles, n = bid / ntiles;
+    const int ty0 = (tile / a.tiles_x) * 16, tx0 = (tile % a.tiles_x) * 16;
+    const int nb0 = a.src[0].cpt;
+    const int nblk = nb0 + (a.nsrc > 1 ? a.src[1].cpt : 0);
+    const int g = lane >> 4;
+
+    // ---- LDS-DMA issue.  Item i of a piece = 16 bytes: patch slot i>>2, stored quad i&3.
+    const int qsrc = 4 * ((lane & 3) ^ ((lane >> 3) & 3));  // channel offset this lane fetches (quad swizzle)
+    auto issue_patch = [&](int blk) {
+        const bool s1 = blk >= nb0;
+        const ConvSrc& s = s1 ? a.src[1] : a.src[0];
+        const int c0 = (s1 ? blk - nb0 : blk) * 16 + qsrc;
+        const float* base = s.p + (long long)n * s.nstride;
+        if (UPS && s.up) {
+            if (wv < (LPIX * 4 + 63) / 64) {
+                const int slot = wv * 16 + (lane >> 2);
+                const int Y = slot / LW, X = slot - Y * LW;
+                const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
+                const bool ok = slot < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
+                glds16(ok ? base + ((long long)ly * (a.W >> 1) + lx) * s.C + c0 : a.zero, sA + wv * 256);
             }
-    } else if (EPI == EPI_RELU) {
-        float* o = a.out0 + (long long)(a.out_idx ? a.out_idx[n] : n) * a.out0_nstride;
+        } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int y, x;
-                out_pix(mt, r, y, x);
-                if (y >= a.H || x >= a.W) continue;
-                long long pix = (long long)y * a.W + x;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    int ch = col0 + nt * 16;
-                    if (ch < a.Cout) {
-                        float v = tz_relu(acc[mt][nt][r]);
-                        if (a.clip1 && v > 1.0f) v = 1.0f;
-                        o[pix * a.Cout + ch] = v;
-                    }
+            for (int j = 0; j < (P16_PIECES + 7) / 8; ++j) {
+                const int piece = wv + 8 * j;
+                if (piece < P16_PIECES) {
+                    const int slot = piece * 16 + (lane >> 2);
+                    const int y = slot / PW, xs = slot - y * PW;
+                    const int x = MAP == MAP_PARITY ? xs ^ ((y >> 1) & 1) : xs;
+                    const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
+                    const bool ok = slot < PPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+                    glds16(ok ? base + ((long long)yy * a.W + xx) * s.C + c0 : a.zero, sA + piece * 256);
                 }
-            }
-    } else if (EPI == EPI_LSTM) {
-        // columns of this block: [i | f | g | o] x 16 channels of channel group cb
-        // prednet.py:255-259: c = f*c_prev + i*g ; r = o*tanh(c)
-        const int ch = cb * 16 + j, R = a.Cout;
-        float* o0 = a.out0 + (long long)n * a.out0_nstride;
-        float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int y, x;
-                out_pix(mt, r, y, x);
-                if (y >= a.H || x >= a.W) continue;
-                long long pix = (long long)y * a.W + x;
-                float gi = tz_hard_sigmoid(acc[mt][0 % NT][r]);
-                float gf = tz_hard_sigmoid(acc[mt][1 % NT][r]);
-                float gg = tz_tanh(acc[mt][2 % NT][r]);
-                float go = tz_hard_sigmoid(acc[mt][3 % NT][r]);
-                float cp = a.aux ? a.aux[pix * R + ch] : 0.0f;
-                float t1 = gf * cp;
-                float t2 = gi * gg;
-                float c = t1 + t2;
-                float rr = go * tz_tanh(c);
-                o0[pix * R + ch] = rr;
-                if (o1) o1[pix * R + ch] = c;
-            }
-    } else if (EPI == EPI_LSTM_PACKED) {
-        // one 16-column tile holds [i(R) f(R) g(R) o(R)], R <= 4: gather the 4 gates by shuffle
-        const int R = a.R;
-        float* o0 = a.out0 + (long long)n * a.out0_nstride;
-        float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
-        const int lbase = lane & 48;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[mt][0][r];
-                float vi = __shfl(v, lbase + (j % 4), 64);
-                float vf = __shfl(v, lbase + ((j % 4) + R) % 16, 64);
-                float vg = __shfl(v, lbase + ((j % 4) + 2 * R) % 16, 64);
-                float vo = __shfl(v, lbase + ((j % 4) + 3 * R) % 16, 64);
-                int y, x;
-                out_pix(mt, r, y, x);
-                if (j >= R || y >= a.H || x >= a.W) continue;
-                long long pix = (long long)y * a.W + x;
-                float gi = tz_hard_sigmoid(vi), gf = tz_hard_sigmoid(vf), gg = tz_tanh(vg), go = tz_hard_sigmoid(vo);
-                float cp = a.aux ? a.aux[pix * R + j] : 0.0f;
-                float t1 = gf * cp;
-                float t2 = gi * gg;
-                float c = t1 + t2;
-                float rr = go * tz_tanh(c);
-                o0[pix * R + j] = rr;
-                if (o1) o1[pix * R + j] = c;
-            }
-    } else if (EPI == EPI_POOL_ERR) {
-        // prednet.py:289-291 then 274-277 of the next level: A = maxpool2x2(relu(conv));
-        // e = [relu(Ahat0 - A), relu(A - Ahat0)] written at the pooled resolution.
-        const int H2 = a.H >> 1, W2 = a.W >> 1, C = a.Cout;
-        float* o = a.out0 + (long long)n * a.out0_nstride;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            int y, x;
-            out_pix(mt, 0, y, x);
-            int yp = y >> 1, xp = x >> 1;
-            if (yp >= H2 || xp >= W2) continue;
-            long long pp = (long long)yp * W2 + xp;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                int ch = col0 + nt * 16;
-                if (ch >= C) continue;
-                float m = tz_relu(acc[mt][nt][0]);
-#pragma unroll
-                for (int r = 1; r < 4; ++r) {
-                    float t = tz_relu(acc[mt][nt][r]);
-                    if (t > m) m = t;
-                }
-                float h = a.aux[pp * C + ch];
-                float d1 = h - m, d2 = m - h;
-                o[pp * 2 * C + ch] = tz_relu(d1);
-                o[pp * 2 * C + C + ch] = tz_relu(d2);
             }
         }
+    };
+    // weights of one step into buffer `buf`.  Same-resolution step: the 4 k-steps of (block, tap),
+    // one piece each from the waves of half `buf` of the workgroup.  Upsampled step (tap, hf): for
+    // each parity class the 2 k-steps 2hf, 2hf+1 -- wave w fetches piece w = (class w>>1, k-step w&1).
+    auto issue_w = [&](int slot, bool up, int hf, int buf) {
+        if (UPS && up) {
+            glds16(a.Wimg + (((long long)(slot + (wv >> 1)) * a.ncb + cb) * 4 + 2 * hf + (wv & 1)) * 256 + lane * 4,
+                   sW + (buf * WPIECES + wv) * 256);
+        } else if ((wv >> 2) == buf) {
+            glds16(a.Wimg + (((long long)slot * a.ncb + cb) * 4 + (wv & 3)) * 256 + lane * 4,
+                   sW + (buf * WPIECES + (wv & 3)) * 256);
+        }
+    };
+
+    // ---- accumulators (as in k_conv3x3)
+    f32x4 acc[MT][NT];
+    {
+        const int col0 = cb * (NT * 16) + (lane & 15);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (a.init) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int py, px;
+                        row_to_patch<MAP>(wv * 32 + mt * 16 + g * 4 + r, py, px);
+                        const int y = ty0 + py, x = tx0 + px;
+                        acc[mt][nt][r] = (y < a.H && x < a.W) ? a.init[((long long)y * a.W + x) * a.ncols + col0 + nt * 16] : 0.0f;
+                    }
+                } else {
+                    const float b = a.bias[col0 + nt * 16];
+                    acc[mt][nt] = (f32x4){b, b, b, b};
+                }
+            }
     }
+
+    // tile pixel of this lane's A row in each M-tile
+    int tpy[MT], tpx[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) row_to_patch<MAP>(wv * 32 + mt * 16 + (lane & 15), tpy[mt], tpx[mt]);
+    const int wcls = MAP == MAP_PARITY ? (wv >> 1) : 0;
+
+    // The K loop is written as two loop nests in sequence -- the blocks of same-resolution
+    // sources, then the blocks of the upsampled source -- each with ONE MFMA body: with both kinds
+    // of step in one loop body hipcc moves the accumulators between register sets per branch and
+    // spills them.  src[] is ordered same-resolution first (or holds only the upsampled source).
+    const bool up0 = UPS && a.src[0].up != 0;
+    const int nbe = up0 ? 0 : (UPS && a.nsrc > 1 && a.src[1].up ? nb0 : nblk);  // same-resolution blocks
+    issue_patch(0);
+    issue_w(0, up0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int cur = 0, slot0 = 0;
+    auto run_phase = [&](auto upc, int b0, int b1) {
+        constexpr bool UP = decltype(upc)::value;
+        constexpr int nsteps = UP ? 8 : 9, bslots = UP ? 16 : 9;
+#pragma unroll 1
+        for (int blk = b0; blk < b1; ++blk) {
+            const bool more_blk = blk + 1 < nblk;
+            const bool up_next = UP || (UPS && blk + 1 >= nbe);
+#pragma unroll 1
+            for (int st = 0; st < nsteps; ++st) {
+                if (st + 1 < nsteps) issue_w(UP ? slot0 + 4 * ((st + 1) >> 1) : slot0 + st + 1, UP, (st + 1) & 1, cur ^ 1);
+                else if (more_blk) issue_w(slot0 + bslots, up_next, 0, cur ^ 1);
+                const float* wb = sW + cur * WPIECES * 256 + lane * 4;
+                if (UP) {
+                    const int tap = st >> 1, hf = st & 1;
+                    float fa[MT][2];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int Y = (tpy[mt] >> 1) + (tpy[mt] & 1) + (tap >> 1), X = (tpx[mt] >> 1) + (tpx[mt] & 1) + (tap & 1);
+                        const int slot = Y * LW + X, f = (slot >> 1) & 3;
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2) fa[mt][k2] = sA[slot * 16 + 4 * ((2 * hf + k2) ^ f) + g];
+                    }
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const f32x4 fb = *(const f32x4*)(wb + (wcls * 2 + k2) * 256);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][k2], fb[nt], acc[mt][nt], 0, 0, 0);
+                    }
+                } else {
+                    const int dy = st / 3, dx = st - 3 * dy;
+                    float fa[MT][4];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int y = tpy[mt] + dy, x = tpx[mt] + dx;
+                        const int slot = y * PW + (MAP == MAP_PARITY ? x ^ ((y >> 1) & 1) : x), f = (slot >> 1) & 3;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = sA[slot * 16 + 4 * (kk ^ f) + g];
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const f32x4 fb = *(const f32x4*)(wb + kk * 256);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][kk], fb[nt], acc[mt][nt], 0, 0, 0);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                cur ^= 1;
+            }
+            slot0 += bslots;
+            if (more_blk) {
+                issue_patch(blk + 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    };
+    run_phase(std::false_type{}, 0, nbe);
+    if (UPS) run_phase(std::true_type{}, nbe, nblk);
+    conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane);
 }
 
 // level-0 error unit (prednet.py:274-277 with a = input frame, Ahat = Ahat_0(t0)):
@@ -488,6 +709,8 @@ struct Seg {
 };
 struct PackedConv {
     float* d_W = nullptr;
+    float* d_Wimg = nullptr;  // LDS image order for k_conv16 (every source a multiple of 16 channels), else null
+    const float* d_zero = nullptr;
     float* d_bias = nullptr;
     int nslots = 0, ncols = 0, NT = 1, ncb = 1;
     std::vector<Seg> segs;
@@ -503,6 +726,7 @@ struct tz_model {
     float *R0[TZ_MAX_LEVELS] = {0}, *C0[TZ_MAX_LEVELS] = {0}, *Ahat0[TZ_MAX_LEVELS] = {0}, *G0[TZ_MAX_LEVELS] = {0};
     float *E[TZ_MAX_LEVELS] = {0}, *R1[TZ_MAX_LEVELS] = {0};
     PackedConv a_conv[TZ_MAX_LEVELS], gate_t1[TZ_MAX_LEVELS], ahat0_t1;
+    float* d_zero = nullptr;  // zero page for LDS-DMA halo pixels
     int* d_idx = nullptr;  // 3*maxB ints: is_key, in_idx, out_idx
     std::vector<void*> allocs;
     // weight list accessors
@@ -600,6 +824,23 @@ static int pack_conv(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, con
     TZ_TRY(dmalloc(ctx, m, (void**)&pc->d_bias, B.size() * 4));
     TZ_HIP(ctx, hipMemcpy(pc->d_W, W.data(), W.size() * 4, hipMemcpyHostToDevice));
     TZ_HIP(ctx, hipMemcpy(pc->d_bias, B.data(), B.size() * 4, hipMemcpyHostToDevice));
+    // k_conv16's LDS image: [slot][column block][k-step][lane = (k row & 3) * 16 + column][column tile]
+    bool all16 = nslots > 0 && NT >= 3;
+    for (auto& s : segs) all16 = all16 && (s.C % 16) == 0;
+    if (all16) {
+        const int ncb = pc->ncb;
+        std::vector<float> I((size_t)nslots * ncb * 4 * 256, 0.0f);
+        for (int sl = 0; sl < nslots; ++sl)
+            for (int cb = 0; cb < ncb; ++cb)
+                for (int kk = 0; kk < 4; ++kk)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int nt = 0; nt < NT; ++nt)
+                            I[((((size_t)sl * ncb + cb) * 4 + kk) * 64 + lane) * 4 + nt] =
+                                W[((size_t)sl * 16 + 4 * kk + (lane >> 4)) * ncols + cb * NT * 16 + nt * 16 + (lane & 15)];
+        TZ_TRY(dmalloc(ctx, m, (void**)&pc->d_Wimg, I.size() * 4));
+        TZ_HIP(ctx, hipMemcpy(pc->d_Wimg, I.data(), I.size() * 4, hipMemcpyHostToDevice));
+        pc->d_zero = m->d_zero;
+    }
     return TZ_OK;
 }
 
@@ -644,12 +885,38 @@ static void launch_conv_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
     hipLaunchKernelGGL((k_conv3x3<NT, EPI, UPS, FULLK>), dim3(blocks), dim3(NTHR), 0, ctx->stream, a);
 }
 
+template <int NT, int EPI, bool UPS>
+static void launch_conv16_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
+    int blocks = a.ncb * a.tiles_x * a.tiles_y * nbatch;
+    hipLaunchKernelGGL((k_conv16<NT, EPI, UPS>), dim3(blocks), dim3(NTHR), 0, ctx->stream, a);
+}
+
+// TEZIP_CONV16=0 keeps every launch on k_conv3x3 (A/B timing; results are bit-identical)
+static bool use_conv16() {
+    static const bool on = [] {
+        const char* e = getenv("TEZIP_CONV16");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbatch) {
     tz_prof_scope ps(ctx, TZP_CONV);
     bool ups = false, fullk = true;
     for (int s = 0; s < a.nsrc; ++s) {
         ups = ups || a.src[s].up;
         fullk = fullk && (a.src[s].C % 16) == 0;
+    }
+    if (a.Wimg && a.nsrc > 0 && fullk && use_conv16()) {
+#define TZ_CASE16(nt, e, u)                          \
+    if (NT == nt && epi == e && ups == u) {          \
+        launch_conv16_t<nt, e, u>(ctx, a, nbatch);   \
+        TZ_HIP(ctx, hipGetLastError());              \
+        return TZ_OK;                                \
+    }
+        TZ_CASE16(4, EPI_LSTM, false) TZ_CASE16(4, EPI_LSTM, true)
+        TZ_CASE16(3, EPI_POOL_ERR, false) TZ_CASE16(4, EPI_POOL_ERR, false)
+#undef TZ_CASE16
     }
 #define TZ_CASE(nt, e, u)                                                   \
     if (NT == nt && epi == e && ups == u) {                                 \
@@ -677,6 +944,8 @@ static void fill_srcs(ConvArgs& a, const PackedConv& pc, const float* const* ptr
         a.src[s].cpt = (pc.segs[s].C + 15) / 16;
     }
     a.Wp = pc.d_W;
+    a.Wimg = pc.d_Wimg;
+    a.zero = pc.d_zero;
     a.bias = pc.d_bias;
     a.ncols = pc.ncols;
     a.ncb = pc.ncb;
@@ -778,6 +1047,8 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         TZ_TRY(dmalloc(ctx, m, (void**)&m->R1[l], (size_t)max_batch * npx * R * 4));
     }
     TZ_TRY(dmalloc(ctx, m, (void**)&m->d_idx, sizeof(int) * 3 * max_batch));
+    TZ_TRY(dmalloc(ctx, m, (void**)&m->d_zero, 256));
+    TZ_HIP(ctx, hipMemsetAsync(m->d_zero, 0, 256, ctx->stream));
 
     // ---- t=0 top-down from zero state (prednet.py:143-190, 249-264): only r_up is non-zero
     for (int l = L - 1; l >= 0; --l) {
