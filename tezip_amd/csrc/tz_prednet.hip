@@ -491,24 +491,37 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
 //    (slot>>1)&3 and (b), for parity tiles, swapping the pixels of each x pair in rows with
 //    (y>>1) odd -- both applied to the per-lane source address; out-of-image pixels read a zero
 //    page.  18x18 pixels = 21 wave-instructions, the 10x10 half-resolution patch = 7.
-// Protocol per step: issue the DMA of the next step's weights into the other buffer, MFMAs of
-// this step, s_waitcnt vmcnt(0), barrier.  The patch is single-buffered: after the last step of
-// a block its DMA is issued, waited for and published by one more barrier (the other workgroups
-// of the CU cover that gap).  29-37 KB LDS, no spills: 3-4 workgroups per CU.
-static constexpr int P16_PIECES = 21;                   // 1 KB pieces of the patch region (324 px -> 20.25)
+// Protocol per step: issue the DMA of the next step's weights into the other weight buffer, MFMAs
+// of this step, s_waitcnt vmcnt(0), s_barrier.  The NEXT block's patch is issued into the other
+// patch buffer ahead of a block's first step and retires with that step's wait, one whole step of
+// MFMAs later: waves do not stall for a patch.
+// LDS = 50 pieces of 1 KB (3 workgroups per CU).  Same-resolution phase: patches P0 = [0,21),
+// P1 = [21,42), weight buffers 42 + 4*buf.  The upsampled source's steps need 8-piece weight
+// buffers but only 7-piece patches, so its phase re-partitions the same 50 pieces around the
+// region R = 21 * (nbe & 1) that the last same-resolution block leaves free: patches at R and at
+// (R ? 0 : 23), weight buffers at R + 7 + 8*buf (each region is first written only after the
+// barrier that ends its last reader).
+static constexpr int P16_PIECES = 21;                   // 1 KB pieces of an 18x18 patch (324 px -> 20.25)
+static constexpr int U16_PIECES = 7;                    // ... of a 10x10 half-resolution patch
+static constexpr int C16_LDS_PIECES = 2 * P16_PIECES + 8;
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// waits for all of this wave's vector-memory operations (LDS-DMA included)
+__device__ __forceinline__ void wait_vm(int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int NT, int EPI, bool UPS>
 __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
-    constexpr int WPIECES = UPS ? 8 : 4;                // 1 KB pieces per weight buffer
-    __shared__ __attribute__((aligned(16))) float smem[(P16_PIECES + 2 * WPIECES) * 256];
-    float* const sA = smem;
-    float* const sW = smem + P16_PIECES * 256;
+    __shared__ __attribute__((aligned(16))) float smem[C16_LDS_PIECES * 256];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id, scalar
     int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -520,47 +533,52 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     const int nb0 = a.src[0].cpt;
     const int nblk = nb0 + (a.nsrc > 1 ? a.src[1].cpt : 0);
     const int g = lane >> 4;
+    // src[] is ordered same-resolution first (or holds only the upsampled source)
+    const bool up0 = UPS && a.src[0].up != 0;
+    const int nbe = up0 ? 0 : (UPS && a.nsrc > 1 && a.src[1].up ? nb0 : nblk);  // same-resolution blocks
+    const int R = P16_PIECES * (nbe & 1);                                         // upsampled phase region
 
     // ---- LDS-DMA issue.  Item i of a piece = 16 bytes: patch slot i>>2, stored quad i&3.
     const int qsrc = 4 * ((lane & 3) ^ ((lane >> 3) & 3));  // channel offset this lane fetches (quad swizzle)
-    auto issue_patch = [&](int blk) {
+    auto issue_patch = [&](int blk, int piece0) {
         const bool s1 = blk >= nb0;
         const ConvSrc& s = s1 ? a.src[1] : a.src[0];
         const int c0 = (s1 ? blk - nb0 : blk) * 16 + qsrc;
         const float* base = s.p + (long long)n * s.nstride;
-        if (UPS && s.up) {
-            if (wv < (LPIX * 4 + 63) / 64) {
-                const int slot = wv * 16 + (lane >> 2);
-                const int Y = slot / LW, X = slot - Y * LW;
-                const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
-                const bool ok = slot < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
-                glds16(ok ? base + ((long long)ly * (a.W >> 1) + lx) * s.C + c0 : a.zero, sA + wv * 256);
-            }
-        } else {
+        float* dst = smem + piece0 * 256;
+        if (UPS && blk >= nbe) {
+            if (wv >= U16_PIECES) return;
+            const int slot = wv * 16 + (lane >> 2);
+            const int Y = slot / LW, X = slot - Y * LW;
+            const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
+            const bool ok = slot < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
+            glds16(ok ? base + ((long long)ly * (a.W >> 1) + lx) * s.C + c0 : a.zero, dst + wv * 256);
+            return;
+        }
 #pragma unroll
-            for (int j = 0; j < (P16_PIECES + 7) / 8; ++j) {
-                const int piece = wv + 8 * j;
-                if (piece < P16_PIECES) {
-                    const int slot = piece * 16 + (lane >> 2);
-                    const int y = slot / PW, xs = slot - y * PW;
-                    const int x = MAP == MAP_PARITY ? xs ^ ((y >> 1) & 1) : xs;
-                    const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
-                    const bool ok = slot < PPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-                    glds16(ok ? base + ((long long)yy * a.W + xx) * s.C + c0 : a.zero, sA + piece * 256);
-                }
+        for (int j = 0; j < (P16_PIECES + 7) / 8; ++j) {
+            const int piece = wv + 8 * j;
+            if (piece < P16_PIECES) {
+                const int slot = piece * 16 + (lane >> 2);
+                const int y = slot / PW, xs = slot - y * PW;
+                const int x = MAP == MAP_PARITY ? xs ^ ((y >> 1) & 1) : xs;
+                const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
+                const bool ok = slot < PPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+                glds16(ok ? base + ((long long)yy * a.W + xx) * s.C + c0 : a.zero, dst + piece * 256);
             }
         }
     };
-    // weights of one step into buffer `buf`.  Same-resolution step: the 4 k-steps of (block, tap),
-    // one piece each from the waves of half `buf` of the workgroup.  Upsampled step (tap, hf): for
-    // each parity class the 2 k-steps 2hf, 2hf+1 -- wave w fetches piece w = (class w>>1, k-step w&1).
-    auto issue_w = [&](int slot, bool up, int hf, int buf) {
+    // weights of one step into the pieces starting at piece0.  Same-resolution step: the 4 k-steps
+    // of (block, tap), one piece each from the waves of half `half` of the workgroup.  Upsampled
+    // step (tap, hf): for each parity class the 2 k-steps 2hf, 2hf+1 -- wave w fetches piece
+    // w = (class w>>1, k-step w&1).
+    auto issue_w = [&](int slot, bool up, int hf, int piece0, int half) {
         if (UPS && up) {
             glds16(a.Wimg + (((long long)(slot + (wv >> 1)) * a.ncb + cb) * 4 + 2 * hf + (wv & 1)) * 256 + lane * 4,
-                   sW + (buf * WPIECES + wv) * 256);
-        } else if ((wv >> 2) == buf) {
+                   smem + (piece0 + wv) * 256);
+        } else if ((wv >> 2) == half) {
             glds16(a.Wimg + (((long long)slot * a.ncb + cb) * 4 + (wv & 3)) * 256 + lane * 4,
-                   sW + (buf * WPIECES + (wv & 3)) * 256);
+                   smem + (piece0 + (wv & 3)) * 256);
         }
     };
 
@@ -593,30 +611,35 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt) row_to_patch<MAP>(wv * 32 + mt * 16 + (lane & 15), tpy[mt], tpx[mt]);
     const int wcls = MAP == MAP_PARITY ? (wv >> 1) : 0;
 
-    // The K loop is written as two loop nests in sequence -- the blocks of same-resolution
-    // sources, then the blocks of the upsampled source -- each with ONE MFMA body: with both kinds
-    // of step in one loop body hipcc moves the accumulators between register sets per branch and
-    // spills them.  src[] is ordered same-resolution first (or holds only the upsampled source).
-    const bool up0 = UPS && a.src[0].up != 0;
-    const int nbe = up0 ? 0 : (UPS && a.nsrc > 1 && a.src[1].up ? nb0 : nblk);  // same-resolution blocks
-    issue_patch(0);
-    issue_w(0, up0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // first patch and first weights
+    issue_patch(0, up0 ? R : 0);
+    issue_w(0, up0, 0, up0 ? R + U16_PIECES : 2 * P16_PIECES, 0);
+    wait_vm(0);
+    wg_barrier();
 
-    int cur = 0, slot0 = 0;
+    // The K loop is two loop nests in sequence -- the blocks of the same-resolution sources, then
+    // the blocks of the upsampled source -- each with ONE MFMA body: with both kinds of step in one
+    // loop body hipcc moves the accumulators between register sets per branch and spills them.
+    int slot0 = 0;
     auto run_phase = [&](auto upc, int b0, int b1) {
         constexpr bool UP = decltype(upc)::value;
-        constexpr int nsteps = UP ? 8 : 9, bslots = UP ? 16 : 9;
+        constexpr int nsteps = UP ? 8 : 9, bslots = UP ? 16 : 9, WP = UP ? 8 : 4;
+        const int pA0 = UP ? R : 0, pA1 = UP ? (R ? 0 : P16_PIECES + 2) : P16_PIECES;  // patch buffers
+        const int wA = UP ? R + U16_PIECES : 2 * P16_PIECES;                             // weight buffers
+        int pi = 0, cur = 0;
 #pragma unroll 1
         for (int blk = b0; blk < b1; ++blk) {
-            const bool more_blk = blk + 1 < nblk;
-            const bool up_next = UP || (UPS && blk + 1 >= nbe);
+            const bool more_blk = blk + 1 < nblk, same_next = blk + 1 < b1;
+            // the next block's patch goes into the other patch buffer while this block computes; it
+            // is retired together with the first step's weight DMA (a whole step later)
+            if (more_blk) issue_patch(blk + 1, same_next ? (pi ? pA0 : pA1) : R);
 #pragma unroll 1
             for (int st = 0; st < nsteps; ++st) {
-                if (st + 1 < nsteps) issue_w(UP ? slot0 + 4 * ((st + 1) >> 1) : slot0 + st + 1, UP, (st + 1) & 1, cur ^ 1);
-                else if (more_blk) issue_w(slot0 + bslots, up_next, 0, cur ^ 1);
-                const float* wb = sW + cur * WPIECES * 256 + lane * 4;
+                if (st + 1 < nsteps) issue_w(UP ? slot0 + 4 * ((st + 1) >> 1) : slot0 + st + 1, UP, (st + 1) & 1, wA + WP * (cur ^ 1), cur ^ 1);
+                else if (same_next) issue_w(slot0 + bslots, UP, 0, wA + WP * (cur ^ 1), cur ^ 1);
+                else if (more_blk) issue_w(slot0 + bslots, true, 0, R + U16_PIECES, 0);  // first step of the upsampled phase
+                const float* pa = smem + (pi ? pA1 : pA0) * 256;
+                const float* wb = smem + (wA + WP * cur) * 256 + lane * 4;
                 if (UP) {
                     const int tap = st >> 1, hf = st & 1;
                     float fa[MT][2];
@@ -625,7 +648,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
                         const int Y = (tpy[mt] >> 1) + (tpy[mt] & 1) + (tap >> 1), X = (tpx[mt] >> 1) + (tpx[mt] & 1) + (tap & 1);
                         const int slot = Y * LW + X, f = (slot >> 1) & 3;
 #pragma unroll
-                        for (int k2 = 0; k2 < 2; ++k2) fa[mt][k2] = sA[slot * 16 + 4 * ((2 * hf + k2) ^ f) + g];
+                        for (int k2 = 0; k2 < 2; ++k2) fa[mt][k2] = pa[slot * 16 + 4 * ((2 * hf + k2) ^ f) + g];
                     }
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2) {
@@ -644,7 +667,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
                         const int y = tpy[mt] + dy, x = tpx[mt] + dx;
                         const int slot = y * PW + (MAP == MAP_PARITY ? x ^ ((y >> 1) & 1) : x), f = (slot >> 1) & 3;
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = sA[slot * 16 + 4 * (kk ^ f) + g];
+                        for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[slot * 16 + 4 * (kk ^ f) + g];
                     }
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
@@ -656,16 +679,12 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][kk], fb[nt], acc[mt][nt], 0, 0, 0);
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                wait_vm(0);
+                wg_barrier();
                 cur ^= 1;
             }
             slot0 += bslots;
-            if (more_blk) {
-                issue_patch(blk + 1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
+            pi ^= 1;
         }
     };
     run_phase(std::false_type{}, 0, nbe);
