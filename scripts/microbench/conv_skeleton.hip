@@ -1,0 +1,255 @@
+// Skeleton of k_conv16's K loop, built up feature by feature to find what keeps the MFMA pipe idle:
+//   F_ADDR  real A-fragment addressing (tap offsets, XOR swizzle) instead of fixed addresses
+//   F_WDMA  weight LDS-DMA per step (4 x 1 KB from a global stream) + vmcnt(0) before the barrier
+//   F_PDMA  patch LDS-DMA per 9 steps (21 x 1 KB gather) into the other patch buffer
+//   F_BAR   one workgroup barrier per step
+// 512-thread workgroups, 50 KB LDS (3 per CU), 2 x 4 MFMA tiles per wave, 32 MFMAs per step.
+//   hipcc --offload-arch=gfx950 -O3 conv_skeleton.hip -o conv_skeleton
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+enum { F_ADDR = 1, F_WDMA = 2, F_PDMA = 4, F_BAR = 8, F_PRIO = 16, F_PLANAR = 32 };
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int F>
+__global__ __launch_bounds__(512, 6) void k(float* out, unsigned long long* stamps, int nblk, const float* act, const float* wimg,
+                                            int W, int C) {
+    __shared__ __attribute__((aligned(16))) float smem[50 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4;
+    const int tile = blockIdx.x % 256, cb = blockIdx.x / 256 % 3;
+    const int ty0 = (tile / 16) * 16, tx0 = (tile % 16) * 16;
+    for (int i = tid; i < 50 * 256; i += 512) smem[i] = act[i & 4095];
+    __syncthreads();
+    f32x4 acc[2][4];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int tpy[2] = {2 * wv, 2 * wv + 1}, tpx[2] = {lane & 15, lane & 15};
+    const int qsrc = 4 * ((lane & 3) ^ ((lane >> 3) & 3));
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int cur = 0, pi = 0, slot0 = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (F & F_PDMA) {
+            float* dst = smem + (pi ? 0 : 21) * 256;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int piece = wv + 8 * j;
+                if (piece < 21) {
+                    const int slot = piece * 16 + (lane >> 2);
+                    const int y = slot / 18, x = slot - y * 18;
+                    const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
+                    const bool ok = slot < 324 && yy >= 0 && yy < W && xx >= 0 && xx < W;
+                    glds16(ok ? act + ((long long)yy * W + xx) * C + (blk % (C / 16)) * 16 + qsrc : act, dst + piece * 256);
+                }
+            }
+        }
+#pragma unroll 1
+        for (int st = 0; st < 9; ++st) {
+            if (F & F_WDMA) {
+                if ((wv >> 2) == (cur ^ 1))
+                    glds16(wimg + (((long long)(slot0 + st + 1) * 3 + cb) * 4 + (wv & 3)) * 256 + lane * 4,
+                           smem + (42 + 4 * (cur ^ 1) + (wv & 3)) * 256);
+            }
+            const float* pa = smem + (pi ? 21 : 0) * 256;
+            const float* wb = smem + (42 + 4 * cur) * 256 + lane * 4;
+            float fa[2][4];
+            if (F & F_PLANAR) {
+                // quad-planar patch image: item (slot, quad q) at q * 336 + slot -> tap and k-step are pure offsets
+                const int toff = ((st / 3) * 18 + st % 3) * 4;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[(tpy[mt] * 18 + tpx[mt]) * 4 + g + toff + kk * 1344];
+            } else if (F & F_ADDR) {
+                const int dy = st / 3, dx = st - 3 * dy;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int slot = (tpy[mt] + dy) * 18 + tpx[mt] + dx, f = (slot >> 1) & 3;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[slot * 16 + 4 * (kk ^ f) + g];
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[(tpy[mt] * 18 + tpx[mt]) * 16 + 4 * kk + g];
+            }
+            if (F & F_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const f32x4 fb = *(const f32x4*)(wb + kk * 256);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][kk], fb[nt], acc[mt][nt], 0, 0, 0);
+            }
+            if (F & F_PRIO) __builtin_amdgcn_s_setprio(0);
+            if (F & (F_WDMA | F_PDMA)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (F & F_BAR) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            cur ^= 1;
+        }
+        slot0 += 9;
+        pi ^= 1;
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+    if (tid == 0) {
+        stamps[2 * blockIdx.x] = t1 - t0;
+        stamps[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
+
+// Variant: one step = one ROW of taps (3 taps, 96 MFMAs per barrier, 12 KB of weights per step),
+// single patch buffer re-filled between blocks.  LDS 45 KB.
+template <int F>
+__global__ __launch_bounds__(512, 6) void k3(float* out, unsigned long long* stamps, int nblk, const float* act, const float* wimg,
+                                             int W, int C) {
+    __shared__ __attribute__((aligned(16))) float smem[45 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4;
+    const int tile = blockIdx.x % 256, cb = blockIdx.x / 256 % 3;
+    const int ty0 = (tile / 16) * 16, tx0 = (tile % 16) * 16;
+    for (int i = tid; i < 45 * 256; i += 512) smem[i] = act[i & 4095];
+    __syncthreads();
+    f32x4 acc[2][4];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int tpy[2] = {2 * wv, 2 * wv + 1}, tpx[2] = {lane & 15, lane & 15};
+    const int qsrc = 4 * ((lane & 3) ^ ((lane >> 3) & 3));
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int cur = 0, slot0 = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll 1
+        for (int st = 0; st < 3; ++st) {
+            {   // weights of the next row: 12 pieces, wave w takes w and (w < 4) w + 8
+                const float* src = wimg + (((long long)(slot0 + 3 * (st + 1)) * 3 + cb) * 4) * 256 + lane * 4;
+                float* dst = smem + (21 + 12 * (cur ^ 1)) * 256;
+                glds16(src + wv * 256, dst + wv * 256);
+                if (wv < 4) glds16(src + (wv + 8) * 256, dst + (wv + 8) * 256);
+            }
+            const float* pa = smem;
+            const float* wb = smem + (21 + 12 * cur) * 256 + lane * 4;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                float fa[2][4];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int slot = (tpy[mt] + st) * 18 + tpx[mt] + dx, f = (slot >> 1) & 3;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[slot * 16 + 4 * (kk ^ f) + g];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const f32x4 fb = *(const f32x4*)(wb + (dx * 4 + kk) * 256);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][kk], fb[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur ^= 1;
+        }
+        slot0 += 9;
+        if (F & F_PDMA) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int piece = wv + 8 * j;
+                if (piece < 21) {
+                    const int slot = piece * 16 + (lane >> 2);
+                    const int y = slot / 18, x = slot - y * 18;
+                    const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
+                    const bool ok = slot < 324 && yy >= 0 && yy < W && xx >= 0 && xx < W;
+                    glds16(ok ? act + ((long long)yy * W + xx) * C + (blk % (C / 16)) * 16 + qsrc : act, smem + piece * 256);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+    if (tid == 0) {
+        stamps[2 * blockIdx.x] = t1 - t0;
+        stamps[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
+static float *g_out, *g_act, *g_w;
+static unsigned long long* g_st;
+typedef void (*kern_t)(float*, unsigned long long*, int, const float*, const float*, int, int);
+template <int F>
+static void run(const char* name, int blocks, int nblk, kern_t kf = nullptr) {
+    if (!kf) kf = k<F>;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(kf, dim3(blocks), dim3(512), 0, 0, g_out, g_st, nblk, g_act, g_w, 256, 96);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    const int reps = 5;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kf, dim3(blocks), dim3(512), 0, 0, g_out, g_st, nblk, g_act, g_w, 256, 96);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    unsigned long long* h = (unsigned long long*)malloc(16 * blocks);
+    (void)hipMemcpy(h, g_st, 16 * blocks, hipMemcpyDeviceToHost);
+    double clk = 0;
+    for (int i = 0; i < blocks; ++i) clk += (double)h[2 * i] / (double)h[2 * i + 1] * 100.0;
+    clk /= blocks;
+    double flops = (double)blocks * 8 * nblk * 9 * 32.0 * 2048.0;
+    printf("%-44s %7.3f ms  %6.1f TFLOP/s  clock %.0f MHz  pipe busy %.1f %%\n", name, ms, flops / (ms * 1e-3) / 1e12, clk,
+           100.0 * (flops / (ms * 1e-3)) / (256.0 * 4 * 64 * clk * 1e6));
+    free(h);
+}
+
+int main() {
+    const int blocks = 768 * 4, nblk = 12;  // 4 rounds of 3 workgroups per CU, 108 steps each
+    size_t nact = (size_t)256 * 256 * 96, nw = (size_t)(nblk * 9 + 12) * 3 * 4 * 256;
+    (void)hipMalloc(&g_out, sizeof(float) * 512 * blocks);
+    (void)hipMalloc(&g_st, 16 * blocks);
+    (void)hipMalloc(&g_act, nact * 4);
+    (void)hipMalloc(&g_w, nw * 4);
+    float* h = (float*)malloc((nact > nw ? nact : nw) * 4);
+    srand(1);
+    for (size_t i = 0; i < nact; ++i) h[i] = (float)rand() / RAND_MAX - 0.5f;
+    (void)hipMemcpy(g_act, h, nact * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(g_w, h, nw * 4, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 2; ++rep) {
+        run<F_BAR>("reads + barrier", blocks, nblk);
+        run<F_BAR | F_ADDR>("+ real A addressing", blocks, nblk);
+        run<F_BAR | F_WDMA>("+ weight DMA (fixed A addr)", blocks, nblk);
+        run<F_BAR | F_ADDR | F_WDMA>("+ real A addressing + weight DMA", blocks, nblk);
+        run<F_BAR | F_ADDR | F_WDMA | F_PDMA>("+ patch DMA (= k_conv16 K loop)", blocks, nblk);
+        run<F_BAR | F_ADDR | F_WDMA | F_PDMA | F_PRIO>("+ setprio(1) around the MFMAs", blocks, nblk);
+        run<F_BAR | F_PLANAR | F_WDMA | F_PDMA>("quad-planar patch image (offset-only A addr)", blocks, nblk);
+        run<0>("row steps (96 MFMA/barrier), no patch DMA", blocks, nblk, k3<0>);
+        run<F_PDMA>("row steps + single-buffer patch DMA", blocks, nblk, k3<F_PDMA>);
+    }
+    return 0;
+}

@@ -486,11 +486,17 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
 //    (g = lane>>4, j = lane&15) of k-step kk holds W[4kk+g][16nt+j], nt = 0..3 -- one
 //    ds_read_b128 per k-step gives the B fragments of all four column tiles, conflict free;
 //    a (slot, column block) chunk is 4 KB = four 1 KB wave-instructions;
-//  * the halo patch is [slot][16 channels] at 64 B per pixel (no padding possible), made 2-way
-//    conflict free for the ds_read_b32 A fragments by (a) XOR-ing the 16-byte quad index with
-//    (slot>>1)&3 and (b), for parity tiles, swapping the pixels of each x pair in rows with
-//    (y>>1) odd -- both applied to the per-lane source address; out-of-image pixels read a zero
-//    page.  18x18 pixels = 21 wave-instructions, the 10x10 half-resolution patch = 7.
+//  * the halo patch is QUAD-PLANAR: the 16-byte item (slot, channel quad q) sits at item index
+//    q * NP + slot (NP = 336 slots per plane for the 18x18 patch, 112 for the 10x10 one; 4 planes =
+//    exactly 21 / 7 wave-instructions).  An A fragment address is then lane base + tap offset +
+//    k-step offset with the last two uniform (a scalar add and an instruction immediate): the K
+//    loop carries almost no address arithmetic, which measured as the largest single loss of the
+//    DMA'd loop (scripts/microbench/conv_skeleton.hip: 133 -> 140 TFLOP/s; 8-way LDS conflicts on
+//    the same reads cost nothing measurable).  A ds_read_b32 of 16 rows x 2 k is 2-way conflicted
+//    at best in any 16-byte-granular image (lanes 0-31 only touch elements 0,1 of a quad); the
+//    plane layout reaches that for all three row maps, with the columns of a parity-tile patch
+//    stored evens first (x -> (x>>1) + 9*(x&1)) so that one parity class is contiguous.
+//    Out-of-image pixels read a zero page.
 // Protocol per step: issue the DMA of the next step's weights into the other weight buffer, MFMAs
 // of this step, s_waitcnt vmcnt(0), s_barrier.  The NEXT block's patch is issued into the other
 // patch buffer ahead of a block's first step and retires with that step's wait, one whole step of
@@ -503,6 +509,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
 // barrier that ends its last reader).
 static constexpr int P16_PIECES = 21;                   // 1 KB pieces of an 18x18 patch (324 px -> 20.25)
 static constexpr int U16_PIECES = 7;                    // ... of a 10x10 half-resolution patch
+static constexpr int NP16 = P16_PIECES * 16, NPU16 = U16_PIECES * 16;  // slots per quad plane (336 / 112)
 static constexpr int C16_LDS_PIECES = 2 * P16_PIECES + 8;
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
@@ -538,33 +545,32 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     const int nbe = up0 ? 0 : (UPS && a.nsrc > 1 && a.src[1].up ? nb0 : nblk);  // same-resolution blocks
     const int R = P16_PIECES * (nbe & 1);                                         // upsampled phase region
 
-    // ---- LDS-DMA issue.  Item i of a piece = 16 bytes: patch slot i>>2, stored quad i&3.
-    const int qsrc = 4 * ((lane & 3) ^ ((lane >> 3) & 3));  // channel offset this lane fetches (quad swizzle)
+    // ---- LDS-DMA issue.  Item i = piece * 64 + lane of a patch = quad plane i / NP, slot i % NP.
     auto issue_patch = [&](int blk, int piece0) {
         const bool s1 = blk >= nb0;
         const ConvSrc& s = s1 ? a.src[1] : a.src[0];
-        const int c0 = (s1 ? blk - nb0 : blk) * 16 + qsrc;
+        const int c0 = (s1 ? blk - nb0 : blk) * 16;
         const float* base = s.p + (long long)n * s.nstride;
         float* dst = smem + piece0 * 256;
         if (UPS && blk >= nbe) {
             if (wv >= U16_PIECES) return;
-            const int slot = wv * 16 + (lane >> 2);
+            const int i = wv * 64 + lane, q = i / NPU16, slot = i - q * NPU16;
             const int Y = slot / LW, X = slot - Y * LW;
             const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
             const bool ok = slot < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
-            glds16(ok ? base + ((long long)ly * (a.W >> 1) + lx) * s.C + c0 : a.zero, dst + wv * 256);
+            glds16(ok ? base + ((long long)ly * (a.W >> 1) + lx) * s.C + c0 + 4 * q : a.zero, dst + wv * 256);
             return;
         }
 #pragma unroll
         for (int j = 0; j < (P16_PIECES + 7) / 8; ++j) {
             const int piece = wv + 8 * j;
             if (piece < P16_PIECES) {
-                const int slot = piece * 16 + (lane >> 2);
+                const int i = piece * 64 + lane, q = i / NP16, slot = i - q * NP16;
                 const int y = slot / PW, xs = slot - y * PW;
-                const int x = MAP == MAP_PARITY ? xs ^ ((y >> 1) & 1) : xs;
+                const int x = MAP == MAP_PARITY ? (xs < PW / 2 ? 2 * xs : 2 * (xs - PW / 2) + 1) : xs;
                 const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
                 const bool ok = slot < PPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-                glds16(ok ? base + ((long long)yy * a.W + xx) * s.C + c0 : a.zero, dst + piece * 256);
+                glds16(ok ? base + ((long long)yy * a.W + xx) * s.C + c0 + 4 * q : a.zero, dst + piece * 256);
             }
         }
     };
@@ -605,11 +611,17 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
             }
     }
 
-    // tile pixel of this lane's A row in each M-tile
-    int tpy[MT], tpx[MT];
+    // float index of this lane's A row (tile pixel of GEMM row lane&15, element g of the quad) in
+    // plane 0 of each patch image, for tap (0,0)
+    int abase[MT], abase_lo[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) row_to_patch<MAP>(wv * 32 + mt * 16 + (lane & 15), tpy[mt], tpx[mt]);
-    const int wcls = MAP == MAP_PARITY ? (wv >> 1) : 0;
+    for (int mt = 0; mt < MT; ++mt) {
+        int py, px;
+        row_to_patch<MAP>(wv * 32 + mt * 16 + (lane & 15), py, px);
+        abase[mt] = 4 * (py * PW + (MAP == MAP_PARITY ? (px >> 1) + (PW / 2) * (px & 1) : px)) + g;
+        abase_lo[mt] = 4 * (((py >> 1) + (py & 1)) * LW + (px >> 1) + (px & 1)) + g;
+    }
+    const int wcls = MAP == MAP_PARITY ? (wv >> 1) : 0;  // parity class (py&1, px&1) of this wave's rows
 
     // first patch and first weights
     issue_patch(0, up0 ? R : 0);
@@ -642,14 +654,12 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
                 const float* wb = smem + (wA + WP * cur) * 256 + lane * 4;
                 if (UP) {
                     const int tap = st >> 1, hf = st & 1;
+                    const int toff = 4 * ((tap >> 1) * LW + (tap & 1)) + 2 * hf * 4 * NPU16;
                     float fa[MT][2];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int Y = (tpy[mt] >> 1) + (tpy[mt] & 1) + (tap >> 1), X = (tpx[mt] >> 1) + (tpx[mt] & 1) + (tap & 1);
-                        const int slot = Y * LW + X, f = (slot >> 1) & 3;
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int k2 = 0; k2 < 2; ++k2) fa[mt][k2] = pa[slot * 16 + 4 * ((2 * hf + k2) ^ f) + g];
-                    }
+                        for (int k2 = 0; k2 < 2; ++k2) fa[mt][k2] = pa[abase_lo[mt] + toff + k2 * 4 * NPU16];
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2) {
                         const f32x4 fb = *(const f32x4*)(wb + (wcls * 2 + k2) * 256);
@@ -660,15 +670,16 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][k2], fb[nt], acc[mt][nt], 0, 0, 0);
                     }
                 } else {
+                    // tap offset in slots: dy rows of 18; a parity-tile patch stores its columns evens
+                    // first, so one step in x is +9 / -8 from an even / odd column and two steps are +1
                     const int dy = st / 3, dx = st - 3 * dy;
+                    const int xo = MAP == MAP_PARITY ? (dx == 1 ? ((wcls & 1) ? 1 - PW / 2 : PW / 2) : (dx >> 1)) : dx;
+                    const int toff = 4 * (dy * PW + xo);
                     float fa[MT][4];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int y = tpy[mt] + dy, x = tpx[mt] + dx;
-                        const int slot = y * PW + (MAP == MAP_PARITY ? x ^ ((y >> 1) & 1) : x), f = (slot >> 1) & 3;
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[slot * 16 + 4 * (kk ^ f) + g];
-                    }
+                        for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[abase[mt] + toff + kk * 4 * NP16];
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
                         const f32x4 fb = *(const f32x4*)(wb + kk * 256);
