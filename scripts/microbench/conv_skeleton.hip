@@ -198,6 +198,71 @@ __global__ __launch_bounds__(512, 6) void k3(float* out, unsigned long long* sta
     }
 }
 
+// Upsampled-phase skeleton: 16 KB of weights per 32-MFMA step (4 parity classes), 7-piece patch per
+// 4 steps.  WPS = weight pieces per wave and step (2 = as k_conv16; 1, 0 = what less DMA would buy).
+template <int WPS>
+__global__ __launch_bounds__(512, 6) void k4(float* out, unsigned long long* stamps, int nblk, const float* act, const float* wimg,
+                                             int W, int C) {
+    __shared__ __attribute__((aligned(16))) float smem[50 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4;
+    const int cb = blockIdx.x / 256 % 3;
+    for (int i = tid; i < 50 * 256; i += 512) smem[i] = act[i & 4095];
+    __syncthreads();
+    f32x4 acc[2][4];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int abase[2] = {4 * ((wv & 3) * 10 + (lane & 7)) + g, 4 * (((wv & 3) + 1) * 10 + (lane & 7)) + g};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int cur = 0, pi = 0, slot0 = 0;
+    nblk = nblk * 9 / 4;  // same MFMA count as the 9-step blocks
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (wv < 7) glds16(act + ((long long)(blockIdx.x % 256) * 4096 + wv * 64 + lane) * 4, smem + ((pi ? 0 : 7) + wv) * 256);
+#pragma unroll 1
+        for (int st = 0; st < 4; ++st) {
+            if (WPS >= 1) {
+                const float* src = wimg + (((long long)((slot0 + st + 1) % 100) * 3 + cb) * 4 + 2 * (wv & 1)) * 256 + lane * 4;
+                float* dst = smem + (14 + 16 * (cur ^ 1) + 2 * wv) * 256;
+                glds16(src, dst);
+                if (WPS >= 2) glds16(src + 256, dst + 256);
+            }
+            const float* pa = smem + (pi ? 7 : 0) * 256;
+            const float* wb = smem + (14 + 16 * cur + 4 * (wv >> 1)) * 256 + lane * 4;
+            const int toff = 4 * ((st >> 1) * 10 + (st & 1));
+            float fa[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[abase[mt] + toff + kk * 448];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const f32x4 fb = *(const f32x4*)(wb + kk * 256);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][kk], fb[nt], acc[mt][nt], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur ^= 1;
+        }
+        slot0 += 4;
+        pi ^= 1;
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+    if (tid == 0) {
+        stamps[2 * blockIdx.x] = t1 - t0;
+        stamps[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
 static float *g_out, *g_act, *g_w;
 static unsigned long long* g_st;
 typedef void (*kern_t)(float*, unsigned long long*, int, const float*, const float*, int, int);
@@ -248,6 +313,9 @@ int main() {
         run<F_BAR | F_ADDR | F_WDMA | F_PDMA>("+ patch DMA (= k_conv16 K loop)", blocks, nblk);
         run<F_BAR | F_ADDR | F_WDMA | F_PDMA | F_PRIO>("+ setprio(1) around the MFMAs", blocks, nblk);
         run<F_BAR | F_PLANAR | F_WDMA | F_PDMA>("quad-planar patch image (offset-only A addr)", blocks, nblk);
+        run<0>("up phase: 16 KB weights / step (k_conv16)", blocks, nblk, k4<2>);
+        run<0>("up phase:  8 KB weights / step", blocks, nblk, k4<1>);
+        run<0>("up phase: no weight DMA", blocks, nblk, k4<0>);
         run<0>("row steps (96 MFMA/barrier), no patch DMA", blocks, nblk, k3<0>);
         run<F_PDMA>("row steps + single-buffer patch DMA", blocks, nblk, k3<F_PDMA>);
     }

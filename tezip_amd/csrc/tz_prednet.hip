@@ -166,28 +166,40 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
     } else if (EPI == EPI_LSTM) {
         // columns of this block: [i | f | g | o] x 16 channels of channel group cb
         // prednet.py:255-259: c = f*c_prev + i*g ; r = o*tanh(c)
+        // All c_prev loads are issued first, from clamped (always valid) addresses: a load inside
+        // the per-pixel bounds branch costs one memory round trip per pixel (8 per wave).
         const int ch = cb * 16 + j, R = a.Cout;
         float* o0 = a.out0 + (long long)n * a.out0_nstride;
         float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
+        long long pix[MT][4];
+        bool ok[MT][4];
+        float cp[MT][4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int y, x;
                 out_pix(mt, r, y, x);
-                if (y >= a.H || x >= a.W) continue;
-                long long pix = (long long)y * a.W + x;
+                ok[mt][r] = y < a.H && x < a.W;
+                pix[mt][r] = ok[mt][r] ? (long long)y * a.W + x : 0;
+                cp[mt][r] = a.aux ? a.aux[pix[mt][r] * R + ch] : 0.0f;
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
                 float gi = tz_hard_sigmoid(acc[mt][0 % NT][r]);
                 float gf = tz_hard_sigmoid(acc[mt][1 % NT][r]);
                 float gg = tz_tanh(acc[mt][2 % NT][r]);
                 float go = tz_hard_sigmoid(acc[mt][3 % NT][r]);
-                float cp = a.aux ? a.aux[pix * R + ch] : 0.0f;
-                float t1 = gf * cp;
+                float t1 = gf * cp[mt][r];
                 float t2 = gi * gg;
                 float c = t1 + t2;
                 float rr = go * tz_tanh(c);
-                o0[pix * R + ch] = rr;
-                if (o1) o1[pix * R + ch] = c;
+                if (ok[mt][r]) {
+                    o0[pix[mt][r] * R + ch] = rr;
+                    if (o1) o1[pix[mt][r] * R + ch] = c;
+                }
             }
     } else if (EPI == EPI_LSTM_PACKED) {
         // one 16-column tile holds [i(R) f(R) g(R) o(R)], R <= 4: gather the 4 gates by shuffle
@@ -195,6 +207,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
         float* o0 = a.out0 + (long long)n * a.out0_nstride;
         float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
         const int lbase = lane & 48;
+        long long pix[MT][4];
+        bool ok[MT][4];
+        float cp[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int y, x;
+                out_pix(mt, r, y, x);
+                ok[mt][r] = j < R && y < a.H && x < a.W;
+                pix[mt][r] = ok[mt][r] ? ((long long)y * a.W + x) * R + j : 0;
+                cp[mt][r] = a.aux ? a.aux[pix[mt][r]] : 0.0f;
+            }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -204,47 +229,55 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
                 float vf = __shfl(v, lbase + ((j % 4) + R) % 16, 64);
                 float vg = __shfl(v, lbase + ((j % 4) + 2 * R) % 16, 64);
                 float vo = __shfl(v, lbase + ((j % 4) + 3 * R) % 16, 64);
-                int y, x;
-                out_pix(mt, r, y, x);
-                if (j >= R || y >= a.H || x >= a.W) continue;
-                long long pix = (long long)y * a.W + x;
                 float gi = tz_hard_sigmoid(vi), gf = tz_hard_sigmoid(vf), gg = tz_tanh(vg), go = tz_hard_sigmoid(vo);
-                float cp = a.aux ? a.aux[pix * R + j] : 0.0f;
-                float t1 = gf * cp;
+                float t1 = gf * cp[mt][r];
                 float t2 = gi * gg;
                 float c = t1 + t2;
                 float rr = go * tz_tanh(c);
-                o0[pix * R + j] = rr;
-                if (o1) o1[pix * R + j] = c;
+                if (ok[mt][r]) {
+                    o0[pix[mt][r]] = rr;
+                    if (o1) o1[pix[mt][r]] = c;
+                }
             }
     } else if (EPI == EPI_POOL_ERR) {
         // prednet.py:289-291 then 274-277 of the next level: A = maxpool2x2(relu(conv));
         // e = [relu(Ahat0 - A), relu(A - Ahat0)] written at the pooled resolution.
         const int H2 = a.H >> 1, W2 = a.W >> 1, C = a.Cout;
         float* o = a.out0 + (long long)n * a.out0_nstride;
+        long long pp[MT];
+        bool ok[MT][NT];
+        float h[MT][NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             int y, x;
             out_pix(mt, 0, y, x);
-            int yp = y >> 1, xp = x >> 1;
-            if (yp >= H2 || xp >= W2) continue;
-            long long pp = (long long)yp * W2 + xp;
+            const int yp = y >> 1, xp = x >> 1;
+            const bool okp = yp < H2 && xp < W2;
+            pp[mt] = okp ? (long long)yp * W2 + xp : 0;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                int ch = col0 + nt * 16;
-                if (ch >= C) continue;
+                const int ch = col0 + nt * 16;
+                ok[mt][nt] = okp && ch < C;
+                h[mt][nt] = a.aux[ok[mt][nt] ? pp[mt] * C + ch : 0];
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int ch = col0 + nt * 16;
                 float m = tz_relu(acc[mt][nt][0]);
 #pragma unroll
                 for (int r = 1; r < 4; ++r) {
                     float t = tz_relu(acc[mt][nt][r]);
                     if (t > m) m = t;
                 }
-                float h = a.aux[pp * C + ch];
-                float d1 = h - m, d2 = m - h;
-                o[pp * 2 * C + ch] = tz_relu(d1);
-                o[pp * 2 * C + C + ch] = tz_relu(d2);
+                float d1 = h[mt][nt] - m, d2 = m - h[mt][nt];
+                if (ok[mt][nt]) {
+                    o[pp[mt] * 2 * C + ch] = tz_relu(d1);
+                    o[pp[mt] * 2 * C + C + ch] = tz_relu(d2);
+                }
             }
-        }
     }
 }
 
@@ -375,11 +408,13 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (a.init) {
+                // (clamped address instead of a bounds branch: rows outside the image are never stored)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int y, x;
                     out_pix(mt, r, y, x);
-                    acc[mt][nt][r] = (y < a.H && x < a.W) ? a.init[((long long)y * a.W + x) * a.ncols + col0 + nt * 16] : 0.0f;
+                    const long long pix = (y < a.H && x < a.W) ? (long long)y * a.W + x : 0;
+                    acc[mt][nt][r] = a.init[pix * a.ncols + col0 + nt * 16];
                 }
             } else {
                 float b = a.bias[col0 + nt * 16];
@@ -502,15 +537,14 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
 // patch buffer ahead of a block's first step and retires with that step's wait, one whole step of
 // MFMAs later: waves do not stall for a patch.
 // LDS = 50 pieces of 1 KB (3 workgroups per CU).  Same-resolution phase: patches P0 = [0,21),
-// P1 = [21,42), weight buffers 42 + 4*buf.  The upsampled source's steps need 8-piece weight
-// buffers but only 7-piece patches, so its phase re-partitions the same 50 pieces around the
-// region R = 21 * (nbe & 1) that the last same-resolution block leaves free: patches at R and at
-// (R ? 0 : 23), weight buffers at R + 7 + 8*buf (each region is first written only after the
-// barrier that ends its last reader).
+// P1 = [21,42), weight buffers 42 + 4*buf.  The upsampled source's steps (one collapsed tap each:
+// 4 k-steps x 4 parity classes = 16 pieces of weights, 32 MFMAs per wave and barrier) use
+// 7-piece patches [0,7), [7,14) and weight buffers 14 + 16*buf; the switch between the two
+// layouts happens once per workgroup behind a barrier, with an un-overlapped first load.
 static constexpr int P16_PIECES = 21;                   // 1 KB pieces of an 18x18 patch (324 px -> 20.25)
 static constexpr int U16_PIECES = 7;                    // ... of a 10x10 half-resolution patch
 static constexpr int NP16 = P16_PIECES * 16, NPU16 = U16_PIECES * 16;  // slots per quad plane (336 / 112)
-static constexpr int C16_LDS_PIECES = 2 * P16_PIECES + 8;
+static constexpr int C16_LDS_PIECES = 2 * P16_PIECES + 8;   // >= 2 * U16_PIECES + 32
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -518,7 +552,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 }
 
 // waits for all of this wave's vector-memory operations (LDS-DMA included)
-__device__ __forceinline__ void wait_vm(int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_vm(int = 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -543,7 +577,6 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     // src[] is ordered same-resolution first (or holds only the upsampled source)
     const bool up0 = UPS && a.src[0].up != 0;
     const int nbe = up0 ? 0 : (UPS && a.nsrc > 1 && a.src[1].up ? nb0 : nblk);  // same-resolution blocks
-    const int R = P16_PIECES * (nbe & 1);                                         // upsampled phase region
 
     // ---- LDS-DMA issue.  Item i = piece * 64 + lane of a patch = quad plane i / NP, slot i % NP.
     auto issue_patch = [&](int blk, int piece0) {
@@ -552,9 +585,13 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
         const int c0 = (s1 ? blk - nb0 : blk) * 16;
         const float* base = s.p + (long long)n * s.nstride;
         float* dst = smem + piece0 * 256;
+        // the patch geometry is recomputed per call (once per block): kept live across the K loop
+        // it costs ~12 VGPRs and spills
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
         if (UPS && blk >= nbe) {
             if (wv >= U16_PIECES) return;
-            const int i = wv * 64 + lane, q = i / NPU16, slot = i - q * NPU16;
+            const int i = wv * 64 + ln, q = i / NPU16, slot = i - q * NPU16;
             const int Y = slot / LW, X = slot - Y * LW;
             const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
             const bool ok = slot < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
@@ -565,7 +602,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
         for (int j = 0; j < (P16_PIECES + 7) / 8; ++j) {
             const int piece = wv + 8 * j;
             if (piece < P16_PIECES) {
-                const int i = piece * 64 + lane, q = i / NP16, slot = i - q * NP16;
+                const int i = piece * 64 + ln, q = i / NP16, slot = i - q * NP16;
                 const int y = slot / PW, xs = slot - y * PW;
                 const int x = MAP == MAP_PARITY ? (xs < PW / 2 ? 2 * xs : 2 * (xs - PW / 2) + 1) : xs;
                 const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
@@ -576,12 +613,14 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     };
     // weights of one step into the pieces starting at piece0.  Same-resolution step: the 4 k-steps
     // of (block, tap), one piece each from the waves of half `half` of the workgroup.  Upsampled
-    // step (tap, hf): for each parity class the 2 k-steps 2hf, 2hf+1 -- wave w fetches piece
-    // w = (class w>>1, k-step w&1).
-    auto issue_w = [&](int slot, bool up, int hf, int piece0, int half) {
+    // step: the 4 k-steps of one collapsed tap for each of the 4 parity classes, piece index
+    // class * 4 + k-step; wave w fetches k-steps 2(w&1), 2(w&1)+1 of class w>>1.
+    auto issue_w = [&](int slot, bool up, int piece0, int half) {
         if (UPS && up) {
-            glds16(a.Wimg + (((long long)(slot + (wv >> 1)) * a.ncb + cb) * 4 + 2 * hf + (wv & 1)) * 256 + lane * 4,
-                   smem + (piece0 + wv) * 256);
+            const float* src = a.Wimg + (((long long)(slot + (wv >> 1)) * a.ncb + cb) * 4 + 2 * (wv & 1)) * 256 + lane * 4;
+            float* dst = smem + (piece0 + 2 * wv) * 256;
+            glds16(src, dst);
+            glds16(src + 256, dst + 256);
         } else if ((wv >> 2) == half) {
             glds16(a.Wimg + (((long long)slot * a.ncb + cb) * 4 + (wv & 3)) * 256 + lane * 4,
                    smem + (piece0 + (wv & 3)) * 256);
@@ -597,12 +636,14 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (a.init) {
+                    // (clamped address instead of a bounds branch: rows outside the image are never stored)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         int py, px;
                         row_to_patch<MAP>(wv * 32 + mt * 16 + g * 4 + r, py, px);
                         const int y = ty0 + py, x = tx0 + px;
-                        acc[mt][nt][r] = (y < a.H && x < a.W) ? a.init[((long long)y * a.W + x) * a.ncols + col0 + nt * 16] : 0.0f;
+                        const long long pix = (y < a.H && x < a.W) ? (long long)y * a.W + x : 0;
+                        acc[mt][nt][r] = a.init[pix * a.ncols + col0 + nt * 16];
                     }
                 } else {
                     const float b = a.bias[col0 + nt * 16];
@@ -623,72 +664,59 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     }
     const int wcls = MAP == MAP_PARITY ? (wv >> 1) : 0;  // parity class (py&1, px&1) of this wave's rows
 
-    // first patch and first weights
-    issue_patch(0, up0 ? R : 0);
-    issue_w(0, up0, 0, up0 ? R + U16_PIECES : 2 * P16_PIECES, 0);
-    wait_vm(0);
-    wg_barrier();
-
     // The K loop is two loop nests in sequence -- the blocks of the same-resolution sources, then
     // the blocks of the upsampled source -- each with ONE MFMA body: with both kinds of step in one
     // loop body hipcc moves the accumulators between register sets per branch and spills them.
     int slot0 = 0;
     auto run_phase = [&](auto upc, int b0, int b1) {
         constexpr bool UP = decltype(upc)::value;
-        constexpr int nsteps = UP ? 8 : 9, bslots = UP ? 16 : 9, WP = UP ? 8 : 4;
-        const int pA0 = UP ? R : 0, pA1 = UP ? (R ? 0 : P16_PIECES + 2) : P16_PIECES;  // patch buffers
-        const int wA = UP ? R + U16_PIECES : 2 * P16_PIECES;                             // weight buffers
+        constexpr int nsteps = UP ? 4 : 9, bslots = UP ? 16 : 9, WP = UP ? 16 : 4;
+        constexpr int pA0 = 0, pA1 = UP ? U16_PIECES : P16_PIECES;   // patch buffers
+        constexpr int wA = 2 * pA1;                                  // weight buffers
+        if (b0 >= b1) return;
+        // first patch and first weights of the phase (nothing of the previous phase is live)
+        issue_patch(b0, pA0);
+        issue_w(slot0, UP, wA, 0);
+        wait_vm(0);
+        wg_barrier();
         int pi = 0, cur = 0;
 #pragma unroll 1
         for (int blk = b0; blk < b1; ++blk) {
-            const bool more_blk = blk + 1 < nblk, same_next = blk + 1 < b1;
+            const bool more_blk = blk + 1 < b1;
             // the next block's patch goes into the other patch buffer while this block computes; it
             // is retired together with the first step's weight DMA (a whole step later)
-            if (more_blk) issue_patch(blk + 1, same_next ? (pi ? pA0 : pA1) : R);
+            if (more_blk) issue_patch(blk + 1, pi ? pA0 : pA1);
 #pragma unroll 1
             for (int st = 0; st < nsteps; ++st) {
-                if (st + 1 < nsteps) issue_w(UP ? slot0 + 4 * ((st + 1) >> 1) : slot0 + st + 1, UP, (st + 1) & 1, wA + WP * (cur ^ 1), cur ^ 1);
-                else if (same_next) issue_w(slot0 + bslots, UP, 0, wA + WP * (cur ^ 1), cur ^ 1);
-                else if (more_blk) issue_w(slot0 + bslots, true, 0, R + U16_PIECES, 0);  // first step of the upsampled phase
+                if (st + 1 < nsteps) issue_w(UP ? slot0 + 4 * (st + 1) : slot0 + st + 1, UP, wA + WP * (cur ^ 1), cur ^ 1);
+                else if (more_blk) issue_w(slot0 + bslots, UP, wA + WP * (cur ^ 1), cur ^ 1);
                 const float* pa = smem + (pi ? pA1 : pA0) * 256;
-                const float* wb = smem + (wA + WP * cur) * 256 + lane * 4;
+                const float* wb = smem + (wA + WP * cur + (UP ? 4 * wcls : 0)) * 256 + lane * 4;
+                // tap offset in slots.  Same resolution: dy rows of 18; a parity-tile patch stores its
+                // columns evens first, so one step in x is +9 / -8 from an even / odd column and two
+                // steps are +1.  Upsampled: the 2x2 collapsed taps of the 10-wide half-resolution patch.
+                int toff;
                 if (UP) {
-                    const int tap = st >> 1, hf = st & 1;
-                    const int toff = 4 * ((tap >> 1) * LW + (tap & 1)) + 2 * hf * 4 * NPU16;
-                    float fa[MT][2];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int k2 = 0; k2 < 2; ++k2) fa[mt][k2] = pa[abase_lo[mt] + toff + k2 * 4 * NPU16];
-#pragma unroll
-                    for (int k2 = 0; k2 < 2; ++k2) {
-                        const f32x4 fb = *(const f32x4*)(wb + (wcls * 2 + k2) * 256);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][k2], fb[nt], acc[mt][nt], 0, 0, 0);
-                    }
+                    toff = 4 * ((st >> 1) * LW + (st & 1));
                 } else {
-                    // tap offset in slots: dy rows of 18; a parity-tile patch stores its columns evens
-                    // first, so one step in x is +9 / -8 from an even / odd column and two steps are +1
                     const int dy = st / 3, dx = st - 3 * dy;
                     const int xo = MAP == MAP_PARITY ? (dx == 1 ? ((wcls & 1) ? 1 - PW / 2 : PW / 2) : (dx >> 1)) : dx;
-                    const int toff = 4 * (dy * PW + xo);
-                    float fa[MT][4];
+                    toff = 4 * (dy * PW + xo);
+                }
+                constexpr int KOFF = 4 * (UP ? NPU16 : NP16);  // floats between the quad planes
+                float fa[MT][4];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[(UP ? abase_lo[mt] : abase[mt]) + toff + kk * KOFF];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const f32x4 fb = *(const f32x4*)(wb + kk * 256);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[abase[mt] + toff + kk * 4 * NP16];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const f32x4 fb = *(const f32x4*)(wb + kk * 256);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][kk], fb[nt], acc[mt][nt], 0, 0, 0);
-                    }
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][kk], fb[nt], acc[mt][nt], 0, 0, 0);
                 }
                 wait_vm(0);
                 wg_barrier();
@@ -698,8 +726,12 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
             pi ^= 1;
         }
     };
+    // waves in the K loop outrank the waves of other workgroups that are in their prologue or
+    // epilogue (VALU-dense, and older): the matrix pipe is issued first
+    __builtin_amdgcn_s_setprio(1);
     run_phase(std::false_type{}, 0, nbe);
     if (UPS) run_phase(std::true_type{}, nbe, nblk);
+    __builtin_amdgcn_s_setprio(0);
     conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane);
 }
 
