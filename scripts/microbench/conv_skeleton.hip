@@ -9,7 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-enum { F_ADDR = 1, F_WDMA = 2, F_PDMA = 4, F_BAR = 8, F_PRIO = 16, F_PLANAR = 32 };
+enum { F_ADDR = 1, F_WDMA = 2, F_PDMA = 4, F_BAR = 8, F_PRIO = 16, F_PLANAR = 32, F_PREF = 64, F_W3 = 128 };
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -35,11 +35,11 @@ __global__ __launch_bounds__(512, 6) void k(float* out, unsigned long long* stam
     int cur = 0, pi = 0, slot0 = 0;
     for (int blk = 0; blk < nblk; ++blk) {
         if (F & F_PDMA) {
-            float* dst = smem + (pi ? 0 : 21) * 256;
+            float* dst = smem + (pi ? 0 : ((F & F_W3) ? 19 : 21)) * 256;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int piece = wv + 8 * j;
-                if (piece < 21) {
+                if (piece < ((F & F_W3) ? 19 : 21)) {
                     const int slot = piece * 16 + (lane >> 2);
                     const int y = slot / 18, x = slot - y * 18;
                     const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
@@ -50,13 +50,19 @@ __global__ __launch_bounds__(512, 6) void k(float* out, unsigned long long* stam
         }
 #pragma unroll 1
         for (int st = 0; st < 9; ++st) {
-            if (F & F_WDMA) {
+            const int sg = slot0 + st;  // global step number
+            if (F & F_W3) {
+                // three weight buffers: the DMA issued in step s fills the buffer of step s+2
+                if ((wv >> 2) == (sg & 1))
+                    glds16(wimg + (((long long)(sg + 2) * 3 + cb) * 4 + (wv & 3)) * 256 + lane * 4,
+                           smem + (38 + 4 * ((sg + 2) % 3) + (wv & 3)) * 256);
+            } else if (F & F_WDMA) {
                 if ((wv >> 2) == (cur ^ 1))
                     glds16(wimg + (((long long)(slot0 + st + 1) * 3 + cb) * 4 + (wv & 3)) * 256 + lane * 4,
                            smem + (42 + 4 * (cur ^ 1) + (wv & 3)) * 256);
             }
-            const float* pa = smem + (pi ? 21 : 0) * 256;
-            const float* wb = smem + (42 + 4 * cur) * 256 + lane * 4;
+            const float* pa = smem + (pi ? ((F & F_W3) ? 19 : 21) : 0) * 256;
+            const float* wb = smem + ((F & F_W3) ? 38 + 4 * (sg % 3) : 42 + 4 * cur) * 256 + lane * 4;
             float fa[2][4];
             if (F & F_PLANAR) {
                 // quad-planar patch image: item (slot, quad q) at q * 336 + slot -> tap and k-step are pure offsets
@@ -80,6 +86,23 @@ __global__ __launch_bounds__(512, 6) void k(float* out, unsigned long long* stam
                     for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[(tpy[mt] * 18 + tpx[mt]) * 16 + 4 * kk + g];
             }
             if (F & F_PRIO) __builtin_amdgcn_s_setprio(1);
+            if (F & F_PREF) {
+                // fragments of k-step kk+1 are requested before the MFMAs of k-step kk are issued
+                f32x4 fb = *(const f32x4*)(wb);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    f32x4 fbn = fb;
+                    if (kk < 3) fbn = *(const f32x4*)(wb + (kk + 1) * 256);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][kk], fb[nt], acc[mt][nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fb = fbn;
+                }
+            } else
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const f32x4 fb = *(const f32x4*)(wb + kk * 256);
@@ -90,7 +113,10 @@ __global__ __launch_bounds__(512, 6) void k(float* out, unsigned long long* stam
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][kk], fb[nt], acc[mt][nt], 0, 0, 0);
             }
             if (F & F_PRIO) __builtin_amdgcn_s_setprio(0);
-            if (F & (F_WDMA | F_PDMA)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (F & F_W3) {
+                if ((wv >> 2) == (sg & 1)) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (F & (F_WDMA | F_PDMA)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (F & F_BAR) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -313,6 +339,8 @@ int main() {
         run<F_BAR | F_ADDR | F_WDMA | F_PDMA>("+ patch DMA (= k_conv16 K loop)", blocks, nblk);
         run<F_BAR | F_ADDR | F_WDMA | F_PDMA | F_PRIO>("+ setprio(1) around the MFMAs", blocks, nblk);
         run<F_BAR | F_PLANAR | F_WDMA | F_PDMA>("quad-planar patch image (offset-only A addr)", blocks, nblk);
+        run<F_BAR | F_PLANAR | F_WDMA | F_PDMA | F_PREF>("quad-planar + fragment prefetch", blocks, nblk);
+        run<F_BAR | F_PLANAR | F_WDMA | F_PDMA | F_W3>("quad-planar + weights 2 steps ahead (3 bufs)", blocks, nblk);
         run<0>("up phase: 16 KB weights / step (k_conv16)", blocks, nblk, k4<2>);
         run<0>("up phase:  8 KB weights / step", blocks, nblk, k4<1>);
         run<0>("up phase: no weight DMA", blocks, nblk, k4<0>);

@@ -121,7 +121,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // acc[mt][nt], element r <-> GEMM row (lane>>4)*4 + r of M-tile mt, column lane&15 of N-tile nt.
 template <int NT, int EPI, int MAP>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int n, int cb, int ty0, int tx0,
-                                              int wv, int lane) {
+                                              int wv, int lane, float* scratch) {
     constexpr int NTC = NT * 16;
     const int col0 = cb * NTC + (lane & 15);
     auto out_pix = [&](int mt, int r, int& y, int& x) {
@@ -202,43 +202,51 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
                 }
             }
     } else if (EPI == EPI_LSTM_PACKED) {
-        // one 16-column tile holds [i(R) f(R) g(R) o(R)], R <= 4: gather the 4 gates by shuffle
+        // one 16-column tile holds [i(R) f(R) g(R) o(R)], R <= 4.  Only R of 16 lanes of the
+        // accumulator layout own a channel, so the LSTM update (two tanh per item) is re-distributed:
+        // the wave's 32 x 16 tile goes through its private LDS scratch and every lane takes
+        // (pixel, channel) items lane, lane + 64 of the 32 * R -- 4x less VALU than 8 masked rows per
+        // lane (the level-0 gate launch was VALU-bound in this epilogue).
         const int R = a.R;
         float* o0 = a.out0 + (long long)n * a.out0_nstride;
         float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
-        const int lbase = lane & 48;
-        long long pix[MT][4];
-        bool ok[MT][4];
-        float cp[MT][4];
+        float* t = scratch + wv * (32 * 17);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int y, x;
-                out_pix(mt, r, y, x);
-                ok[mt][r] = j < R && y < a.H && x < a.W;
-                pix[mt][r] = ok[mt][r] ? ((long long)y * a.W + x) * R + j : 0;
-                cp[mt][r] = a.aux ? a.aux[pix[mt][r]] : 0.0f;
-            }
+            for (int r = 0; r < 4; ++r) t[(mt * 16 + (lane >> 4) * 4 + r) * 17 + j] = acc[mt][0][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int row[2], c[2];
+        long long pix[2];
+        bool ok[2];
+        float cp[2];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int it = 0; it < 2; ++it) {
+            const int item = lane + 64 * it;
+            row[it] = item / R;
+            c[it] = item - row[it] * R;
+            int py, px;
+            row_to_patch<MAP>(wv * 32 + (row[it] & 31), py, px);
+            const int y = ty0 + py, x = tx0 + px;
+            ok[it] = item < 32 * R && y < a.H && x < a.W;
+            pix[it] = ok[it] ? ((long long)y * a.W + x) * R + c[it] : 0;
+            cp[it] = a.aux ? a.aux[pix[it]] : 0.0f;
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[mt][0][r];
-                float vi = __shfl(v, lbase + (j % 4), 64);
-                float vf = __shfl(v, lbase + ((j % 4) + R) % 16, 64);
-                float vg = __shfl(v, lbase + ((j % 4) + 2 * R) % 16, 64);
-                float vo = __shfl(v, lbase + ((j % 4) + 3 * R) % 16, 64);
-                float gi = tz_hard_sigmoid(vi), gf = tz_hard_sigmoid(vf), gg = tz_tanh(vg), go = tz_hard_sigmoid(vo);
-                float t1 = gf * cp[mt][r];
-                float t2 = gi * gg;
-                float c = t1 + t2;
-                float rr = go * tz_tanh(c);
-                if (ok[mt][r]) {
-                    o0[pix[mt][r]] = rr;
-                    if (o1) o1[pix[mt][r]] = c;
-                }
+        for (int it = 0; it < 2; ++it) {
+            const float* tr = t + (row[it] & 31) * 17 + c[it];
+            float gi = tz_hard_sigmoid(tr[0]), gf = tz_hard_sigmoid(tr[R]), gg = tz_tanh(tr[2 * R]), go = tz_hard_sigmoid(tr[3 * R]);
+            float t1 = gf * cp[it];
+            float t2 = gi * gg;
+            float cc = t1 + t2;
+            float rr = go * tz_tanh(cc);
+            if (ok[it]) {
+                o0[pix[it]] = rr;
+                if (o1) o1[pix[it]] = cc;
             }
+        }
     } else if (EPI == EPI_POOL_ERR) {
         // prednet.py:289-291 then 274-277 of the next level: A = maxpool2x2(relu(conv));
         // e = [relu(Ahat0 - A), relu(A - Ahat0)] written at the pooled resolution.
@@ -284,7 +292,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
 // FULLK: every source has a multiple of 16 channels, so every same-resolution step runs all four
 // k-steps (lets the compiler schedule the 32 MFMAs of a step as one straight-line block).
 template <int NT, int EPI, bool UPS, bool FULLK>
-__global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
+__global__ __launch_bounds__(NTHR, NT == 1 ? 8 : 6) void k_conv3x3(const ConvArgs a) {
     // parity tiles only where an upsampled source needs them (the top level has none)
     constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
     constexpr int SAH = SA;                           // floats per pixel of the same-resolution patch
@@ -504,7 +512,9 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv3x3(const ConvArgs a) {
             }
         }
     }
-    conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane);
+    if (EPI == EPI_LSTM_PACKED) __syncthreads();  // the patch buffer becomes the epilogue's scratch
+    static_assert(8 * 32 * 17 <= PPIX * SA, "epilogue scratch fits the patch buffer");
+    conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane, sA);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -732,7 +742,51 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     run_phase(std::false_type{}, 0, nbe);
     if (UPS) run_phase(std::true_type{}, nbe, nblk);
     __builtin_amdgcn_s_setprio(0);
-    conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane);
+    conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane, smem);
+}
+
+// Level-0 prediction Ahat_0 = min(relu(conv3x3(r_0)), 1) (prednet.py:268-271) with CIN, COUT <= 4:
+// 81 fmaf per pixel do not need the matrix cores (the MFMA kernel pads K and N to 16 and spends
+// its time in 9 barrier-separated staging steps: 55 us per launch at 512^2 x 4).  One thread per
+// pixel, 18x18 halo tile in LDS, weights by scalar loads.  Same chain as the MFMA kernel and the
+// oracle: acc = bias; for tap (ky, kx) ascending; for ci ascending: acc = fmaf(x, w, acc), where a
+// tap outside the image multiplies a stored zero.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_conv_small(const ConvArgs a) {
+    __shared__ float tile[PPIX * CIN];
+    const int tid = threadIdx.x;
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int tileid = blockIdx.x % ntiles, n = blockIdx.x / ntiles;
+    const int ty0 = (tileid / a.tiles_x) * 16, tx0 = (tileid % a.tiles_x) * 16;
+    const float* base = a.src[0].p + (long long)n * a.src[0].nstride;
+    for (int i = tid; i < PPIX * CIN; i += 256) {
+        const int pp = i / CIN, ci = i - pp * CIN;
+        const int yy = ty0 - 1 + pp / PW, xx = tx0 - 1 + pp % PW;
+        tile[i] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? base[((long long)yy * a.W + xx) * CIN + ci] : 0.0f;
+    }
+    __syncthreads();
+    const int py = tid >> 4, px = tid & 15;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = a.bias[co];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const float* x = tile + ((py + tap / 3) * PW + px + tap % 3) * CIN;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[co] = __builtin_fmaf(x[ci], a.Wp[(tap * 16 + ci) * a.ncols + co], acc[co]);
+    }
+    const int y = ty0 + py, xq = tx0 + px;
+    if (y < a.H && xq < a.W) {
+        float* o = a.out0 + (long long)(a.out_idx ? a.out_idx[n] : n) * a.out0_nstride + ((long long)y * a.W + xq) * COUT;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float v = tz_relu(acc[co]);
+            if (a.clip1 && v > 1.0f) v = 1.0f;
+            o[co] = v;
+        }
+    }
 }
 
 // level-0 error unit (prednet.py:274-277 with a = input frame, Ahat = Ahat_0(t0)):
@@ -968,6 +1022,11 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
     for (int s = 0; s < a.nsrc; ++s) {
         ups = ups || a.src[s].up;
         fullk = fullk && (a.src[s].C % 16) == 0;
+    }
+    if (epi == EPI_RELU && a.nsrc == 1 && !ups && a.src[0].C == 3 && a.Cout == 3 && use_conv16()) {
+        hipLaunchKernelGGL((k_conv_small<3, 3>), dim3(a.tiles_x * a.tiles_y * nbatch), dim3(256), 0, ctx->stream, a);
+        TZ_HIP(ctx, hipGetLastError());
+        return TZ_OK;
     }
     if (a.Wimg && a.nsrc > 0 && fullk && use_conv16()) {
 #define TZ_CASE16(nt, e, u)                          \
