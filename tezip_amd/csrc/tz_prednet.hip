@@ -43,6 +43,7 @@ struct ConvSrc {
     const float* p;
     long long nstride;  // elements between batch items (0 = broadcast constant)
     int C;              // channels
+    int pstride;        // floats between pixels (>= C; level-0 error maps are stored 8 wide)
     int up;             // 1: stored at half resolution, nearest x2 on read (prednet.py:264)
     int cpt;            // 16-channel blocks of this source = ceil(C/16)
 };
@@ -53,6 +54,7 @@ struct ConvArgs {
     int H, W, tiles_x, tiles_y, ncb;
     const float* Wp;    // [weight slots * 16][ncols], slot order = the K-loop order (see pack_conv)
     const float* Wimg;  // the same weights in LDS image order for k_conv16 (see pack_conv), or null
+    const float* Wblk;  // block-step image for k_conv16b (see pack_block_image), or null
     const float* zero;  // >= 16 bytes of zeros: LDS-DMA source of out-of-image patch pixels
     int ncols;
     const float* bias;  // [ncols]
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(NTHR, NT == 1 ? 8 : 6) void k_conv3x3(const ConvArg
 
     auto load_quad = [&](const ConvSrc& s, const float* ptr, int c0) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((s.C & 3) == 0) {
+        if ((s.C & 3) == 0 && (s.pstride & 3) == 0) {
             v = *(const float4*)ptr;
         } else {
             v.x = ptr[0];
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(NTHR, NT == 1 ? 8 : 6) void k_conv3x3(const ConvArg
             const int ly = (ty0 >> 1) - 1 + pp / LW, lx = (tx0 >> 1) - 1 + pp % LW;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (pp < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1) && c0 < s.C)
-                v = load_quad(s, base + ((long long)ly * (a.W >> 1) + lx) * s.C + c0, c0);
+                v = load_quad(s, base + ((long long)ly * (a.W >> 1) + lx) * s.pstride + c0, c0);
             ra[0] = v;
         } else {
 #pragma unroll
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(NTHR, NT == 1 ? 8 : 6) void k_conv3x3(const ConvArg
                 const int yy = ty0 - 1 + pp / PW, xx = tx0 - 1 + pp % PW;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (i < A_ITEMS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && c0 < s.C)
-                    v = load_quad(s, base + ((long long)yy * a.W + xx) * s.C + c0, c0);
+                    v = load_quad(s, base + ((long long)yy * a.W + xx) * s.pstride + c0, c0);
                 ra[j] = v;
             }
         }
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
             const int Y = slot / LW, X = slot - Y * LW;
             const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
             const bool ok = slot < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
-            glds16(ok ? base + ((long long)ly * (a.W >> 1) + lx) * s.C + c0 + 4 * q : a.zero, dst + wv * 256);
+            glds16(ok ? base + ((long long)ly * (a.W >> 1) + lx) * s.pstride + c0 + 4 * q : a.zero, dst + wv * 256);
             return;
         }
 #pragma unroll
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
                 const int x = MAP == MAP_PARITY ? (xs < PW / 2 ? 2 * xs : 2 * (xs - PW / 2) + 1) : xs;
                 const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
                 const bool ok = slot < PPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-                glds16(ok ? base + ((long long)yy * a.W + xx) * s.C + c0 + 4 * q : a.zero, dst + piece * 256);
+                glds16(ok ? base + ((long long)yy * a.W + xx) * s.pstride + c0 + 4 * q : a.zero, dst + piece * 256);
             }
         }
     };
@@ -745,6 +747,202 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane, smem);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_conv16b: the level-0 convolutions -- A_0 (e_0: 6 channels -> 48 columns) and the level-0
+// gates ([e_0 (6), up(r_1) (48)] -> 16 columns) -- as BLOCK STEPS.  With 3..16 useful columns a
+// tap step holds 4-12 MFMAs per wave, and k_conv3x3 spends the launch in the latency of 9-21
+// barrier-separated staging steps (35-45 % matrix pipe use).  Here everything a block of input
+// channels needs -- its patch and the weights of ALL its taps (and parity classes) -- is one
+// LDS-DMA batch: one barrier pair per block, 32-108 MFMAs per wave between them, the next
+// block's batch in flight meanwhile.  Same tiles, fmaf-chain order and epilogues as k_conv16.
+//   block 0: the same-resolution source, stored 8 floats per pixel (6 real channels + 2 zeros):
+//            2 quad planes = 11 pieces, 9 taps x 2 k-steps;
+//   blocks 1..: 16 channels of the upsampled source: 7 pieces, 4 taps x 4 classes x 4 k-steps.
+// Weight image per block: [tap][(class)][k-step][lane][NTI], NTI = 1 float per lane for one
+// column tile (ds_read_b32), 4 otherwise (ds_read_b128).
+static constexpr int E8_PIECES = 11;
+
+__device__ __forceinline__ void wait_vm_n(int n) {  // wave-uniform n: leave the n youngest operations in flight
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    }
+}
+
+template <int NT>
+struct C16b {
+    static constexpr int NTI = NT == 1 ? 1 : 4;
+    static constexpr int W8 = (18 * 64 * NTI * 4 + 1023) / 1024;  // weight pieces of block 0
+    static constexpr int WU = 16 * NTI;                           // ... of an upsampled block
+    static constexpr int bufp(bool ups) {
+        return !ups ? E8_PIECES + W8 : (E8_PIECES + W8 > U16_PIECES + WU ? E8_PIECES + W8 : U16_PIECES + WU);
+    }
+};
+
+template <int NT, int EPI, bool UPS>
+__global__ __launch_bounds__(NTHR, 6) void k_conv16b(const ConvArgs a) {
+    constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
+    constexpr int NTI = C16b<NT>::NTI, W8 = C16b<NT>::W8, WU = C16b<NT>::WU, BUFP = C16b<NT>::bufp(UPS);
+    constexpr int NBUF = UPS ? 2 : 1;
+    constexpr int SCRATCH = EPI == EPI_LSTM_PACKED ? 8 * 32 * 17 : 0;  // epilogue scratch (re-uses the buffers)
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * BUFP * 256 > SCRATCH ? NBUF * BUFP * 256 : SCRATCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = bid % a.ncb;
+    bid /= a.ncb;
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int tile = bid % ntiles, n = bid / ntiles;
+    const int ty0 = (tile / a.tiles_x) * 16, tx0 = (tile % a.tiles_x) * 16;
+    const int nblk = 1 + (UPS ? a.src[1].cpt : 0);
+    const int g = lane >> 4;
+
+    // one LDS-DMA batch = patch pieces then weight pieces of block b, dealt round-robin to the
+    // waves; returns how many this wave issued
+    auto issue_block = [&](int b, int buf) -> int {
+        float* dst = smem + buf * BUFP * 256;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int P = b == 0 ? E8_PIECES : U16_PIECES, T = P + (b == 0 ? W8 : WU);
+        const float* wsrc = b == 0 ? a.Wblk + (long long)cb * W8 * 256
+                                   : a.Wblk + ((long long)a.ncb * W8 + ((long long)(b - 1) * a.ncb + cb) * WU) * 256;
+        int cnt = 0;
+        for (int piece = wv; piece < T; piece += 8, ++cnt) {
+            if (piece >= P) {
+                glds16(wsrc + (piece - P) * 256 + ln * 4, dst + piece * 256);
+            } else if (b == 0) {
+                const ConvSrc& s = a.src[0];
+                const int i = piece * 64 + ln, q = i / NP16, slot = i - q * NP16;
+                const int y = slot / PW, xs = slot - y * PW;
+                const int x = MAP == MAP_PARITY ? (xs < PW / 2 ? 2 * xs : 2 * (xs - PW / 2) + 1) : xs;
+                const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
+                const bool ok = q < 2 && slot < PPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+                glds16(ok ? s.p + (long long)n * s.nstride + ((long long)yy * a.W + xx) * s.pstride + 4 * q : a.zero, dst + piece * 256);
+            } else {
+                const ConvSrc& s = a.src[1];
+                const int i = piece * 64 + ln, q = i / NPU16, slot = i - q * NPU16;
+                const int Y = slot / LW, X = slot - Y * LW;
+                const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
+                const bool ok = slot < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
+                glds16(ok ? s.p + (long long)n * s.nstride + ((long long)ly * (a.W >> 1) + lx) * s.pstride + (b - 1) * 16 + 4 * q : a.zero,
+                       dst + piece * 256);
+            }
+        }
+        return cnt;
+    };
+
+    issue_block(0, 0);
+
+    // ---- accumulators (as in k_conv16; the loads overlap the first DMA batch)
+    f32x4 acc[MT][NT];
+    {
+        const int col0 = cb * (NT * 16) + (lane & 15);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (a.init) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int py, px;
+                        row_to_patch<MAP>(wv * 32 + mt * 16 + g * 4 + r, py, px);
+                        const int y = ty0 + py, x = tx0 + px;
+                        const long long pix = (y < a.H && x < a.W) ? (long long)y * a.W + x : 0;
+                        acc[mt][nt][r] = a.init[pix * a.ncols + col0 + nt * 16];
+                    }
+                } else {
+                    const float b = a.bias[col0 + nt * 16];
+                    acc[mt][nt] = (f32x4){b, b, b, b};
+                }
+            }
+    }
+    int abase[MT], abase_lo[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int py, px;
+        row_to_patch<MAP>(wv * 32 + mt * 16 + (lane & 15), py, px);
+        abase[mt] = 4 * (py * PW + (MAP == MAP_PARITY ? (px >> 1) + (PW / 2) * (px & 1) : px)) + g;
+        abase_lo[mt] = 4 * (((py >> 1) + (py & 1)) * LW + (px >> 1) + (px & 1)) + g;
+    }
+    const int wcls = MAP == MAP_PARITY ? (wv >> 1) : 0;
+    int inflight = 0;
+    if (nblk > 1) inflight = issue_block(1, 1);  // younger than everything block 0 waits for
+
+    auto mfma_step = [&](const float (&fa)[MT], const float* wp) {
+        float fb[4];
+        if (NTI == 1) {
+            fb[0] = wp[0];
+        } else {
+            const f32x4 t = *(const f32x4*)wp;
+            fb[0] = t[0]; fb[1] = t[1]; fb[2] = t[2]; fb[3] = t[3];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+    };
+
+    __builtin_amdgcn_s_setprio(1);
+    // ---- block 0: 9 taps x 2 k-steps of the 8-wide same-resolution source
+    wait_vm_n(inflight);
+    wg_barrier();
+    {
+        const float* pa = smem;
+        const float* wb = smem + E8_PIECES * 256 + lane * NTI;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            const int xo = MAP == MAP_PARITY ? (dx == 1 ? ((wcls & 1) ? 1 - PW / 2 : PW / 2) : (dx >> 1)) : dx;
+            const int toff = 4 * (dy * PW + xo);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                float fa[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) fa[mt] = pa[abase[mt] + toff + kk * 4 * NP16];
+                mfma_step(fa, wb + (tap * 2 + kk) * 64 * NTI);
+            }
+        }
+    }
+    // ---- blocks 1..: 4 collapsed taps x 4 k-steps of 16 channels of the upsampled source
+    if (UPS) {
+#pragma unroll 1
+        for (int b = 1; b < nblk; ++b) {
+            if (b + 1 < nblk) {  // buffer (b+1)&1 was last read by block b-1
+                wg_barrier();
+                inflight = issue_block(b + 1, (b + 1) & 1);
+            } else {
+                inflight = 0;
+            }
+            wait_vm_n(inflight);
+            wg_barrier();
+            const float* pa = smem + (b & 1) * BUFP * 256;
+            const float* wb = pa + U16_PIECES * 256 + lane * NTI;
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {
+                const int toff = 4 * ((tap >> 1) * LW + (tap & 1));
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    float fa[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) fa[mt] = pa[abase_lo[mt] + toff + kk * 4 * NPU16];
+                    mfma_step(fa, wb + ((tap * 4 + wcls) * 4 + kk) * 64 * NTI);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (EPI == EPI_LSTM_PACKED) wg_barrier();  // the staging buffers become the epilogue's scratch
+    conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane, smem);
+}
+
 // Level-0 prediction Ahat_0 = min(relu(conv3x3(r_0)), 1) (prednet.py:268-271) with CIN, COUT <= 4:
 // 81 fmaf per pixel do not need the matrix cores (the MFMA kernel pads K and N to 16 and spends
 // its time in 9 barrier-separated staging steps: 55 us per launch at 512^2 x 4).  One thread per
@@ -795,7 +993,7 @@ __global__ __launch_bounds__(256) void k_conv_small(const ConvArgs a) {
 __global__ __launch_bounds__(256) void k_err0(const uint8_t* __restrict__ frames_u8, int H, int W,
                                               const float* __restrict__ in_stack, const int* __restrict__ is_key,
                                               const int* __restrict__ in_idx, const float* __restrict__ ahat0, int Hp,
-                                              int Wp, int C, float* __restrict__ e0) {
+                                              int Wp, int C, int Cs, float* __restrict__ e0) {
     int n = blockIdx.y;
     long long npx = (long long)Hp * Wp;
     const bool key = is_key[n] != 0;
@@ -812,9 +1010,10 @@ __global__ __launch_bounds__(256) void k_err0(const uint8_t* __restrict__ frames
             }
             float h = ahat0[p * C + c];
             float d1 = h - av, d2 = av - h;
-            e0[((long long)n * npx + p) * 2 * C + c] = tz_relu(d1);
-            e0[((long long)n * npx + p) * 2 * C + C + c] = tz_relu(d2);
+            e0[((long long)n * npx + p) * Cs + c] = tz_relu(d1);
+            e0[((long long)n * npx + p) * Cs + C + c] = tz_relu(d2);
         }
+        for (int c = 2 * C; c < Cs; ++c) e0[((long long)n * npx + p) * Cs + c] = 0.0f;  // stride padding reads as zero channels
     }
 }
 
@@ -826,6 +1025,7 @@ struct Seg {
 struct PackedConv {
     float* d_W = nullptr;
     float* d_Wimg = nullptr;  // LDS image order for k_conv16 (every source a multiple of 16 channels), else null
+    float* d_Wblk = nullptr;  // block-step image for k_conv16b (first source <= 8 channels at stride 8), else null
     const float* d_zero = nullptr;
     float* d_bias = nullptr;
     int nslots = 0, ncols = 0, NT = 1, ncb = 1;
@@ -843,6 +1043,7 @@ struct tz_model {
     float *E[TZ_MAX_LEVELS] = {0}, *R1[TZ_MAX_LEVELS] = {0};
     PackedConv a_conv[TZ_MAX_LEVELS], gate_t1[TZ_MAX_LEVELS], ahat0_t1;
     float* d_zero = nullptr;  // zero page for LDS-DMA halo pixels
+    int e0s = 0;              // floats per pixel of E[0]: 2*stack[0] rounded up to 8 (k_conv16b reads 16-byte quads)
     int* d_idx = nullptr;  // 3*maxB ints: is_key, in_idx, out_idx
     std::vector<void*> allocs;
     // weight list accessors
@@ -957,6 +1158,39 @@ static int pack_conv(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, con
         TZ_HIP(ctx, hipMemcpy(pc->d_Wimg, I.data(), I.size() * 4, hipMemcpyHostToDevice));
         pc->d_zero = m->d_zero;
     }
+    // k_conv16b's image: block 0 = the <= 8-channel same-resolution source [cb][tap][k-step 0..1][lane][NTI]
+    // (padded to whole 1 KB pieces), then per 16-channel block of the upsampled source
+    // [block][cb][tap][class][k-step][lane][NTI]
+    const bool blk_ok = !segs.empty() && !segs[0].up && segs[0].C <= 8 && (NT == 1 || NT >= 3) &&
+                        (segs.size() == 1 || (segs.size() == 2 && segs[1].up && segs[1].C % 16 == 0));
+    if (blk_ok) {
+        const int ncb = pc->ncb, NTI = NT == 1 ? 1 : 4;
+        const int W8 = (18 * 64 * NTI * 4 + 1023) / 1024, WU = 16 * NTI;
+        const int nub = segs.size() == 2 ? segs[1].C / 16 : 0;
+        std::vector<float> I(((size_t)ncb * W8 + (size_t)nub * ncb * WU) * 256, 0.0f);
+        auto wv = [&](int sl, int k, int cb, int nt, int lane) {
+            return W[((size_t)sl * 16 + k) * ncols + cb * NT * 16 + nt * 16 + (lane & 15)];
+        };
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int kk = 0; kk < 2; ++kk)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int nt = 0; nt < std::min(NT, NTI); ++nt)
+                            I[(size_t)cb * W8 * 256 + (((size_t)tap * 2 + kk) * 64 + lane) * NTI + nt] = wv(tap, 4 * kk + (lane >> 4), cb, nt, lane);
+        for (int b = 0; b < nub; ++b)
+            for (int cb = 0; cb < ncb; ++cb)
+                for (int tap = 0; tap < 4; ++tap)
+                    for (int cls = 0; cls < 4; ++cls)
+                        for (int kk = 0; kk < 4; ++kk)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int nt = 0; nt < std::min(NT, NTI); ++nt)
+                                    I[((size_t)ncb * W8 + ((size_t)b * ncb + cb) * WU) * 256 +
+                                      ((((size_t)tap * 4 + cls) * 4 + kk) * 64 + lane) * NTI + nt] =
+                                        wv(9 + 16 * b + 4 * tap + cls, 4 * kk + (lane >> 4), cb, nt, lane);
+        TZ_TRY(dmalloc(ctx, m, (void**)&pc->d_Wblk, I.size() * 4));
+        TZ_HIP(ctx, hipMemcpy(pc->d_Wblk, I.data(), I.size() * 4, hipMemcpyHostToDevice));
+        pc->d_zero = m->d_zero;
+    }
     return TZ_OK;
 }
 
@@ -1028,6 +1262,18 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         TZ_HIP(ctx, hipGetLastError());
         return TZ_OK;
     }
+    if (a.Wblk && a.nsrc > 0 && !a.src[0].up && a.src[0].pstride == 8 && use_conv16()) {
+        const int blocks = a.ncb * a.tiles_x * a.tiles_y * nbatch;
+#define TZ_CASE16B(nt, e, u)                                                                                    \
+    if (NT == nt && epi == e && ups == u) {                                                                     \
+        hipLaunchKernelGGL((k_conv16b<nt, e, u>), dim3(blocks), dim3(NTHR), 0, ctx->stream, a);                 \
+        TZ_HIP(ctx, hipGetLastError());                                                                         \
+        return TZ_OK;                                                                                           \
+    }
+        TZ_CASE16B(1, EPI_LSTM_PACKED, true) TZ_CASE16B(1, EPI_LSTM_PACKED, false)
+        TZ_CASE16B(1, EPI_POOL_ERR, false) TZ_CASE16B(3, EPI_POOL_ERR, false) TZ_CASE16B(4, EPI_POOL_ERR, false)
+#undef TZ_CASE16B
+    }
     if (a.Wimg && a.nsrc > 0 && fullk && use_conv16()) {
 #define TZ_CASE16(nt, e, u)                          \
     if (NT == nt && epi == e && ups == u) {          \
@@ -1055,17 +1301,20 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
     return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "no conv kernel for NT=%d epilogue=%d upsampled=%d", NT, epi, (int)ups);
 }
 
-static void fill_srcs(ConvArgs& a, const PackedConv& pc, const float* const* ptrs, const long long* nstrides) {
+static void fill_srcs(ConvArgs& a, const PackedConv& pc, const float* const* ptrs, const long long* nstrides,
+                      int pstride0 = 0) {
     a.nsrc = (int)pc.segs.size();
     for (int s = 0; s < a.nsrc; ++s) {
         a.src[s].p = ptrs[s];
         a.src[s].nstride = nstrides[s];
         a.src[s].C = pc.segs[s].C;
+        a.src[s].pstride = s == 0 && pstride0 ? pstride0 : pc.segs[s].C;
         a.src[s].up = pc.segs[s].up;
         a.src[s].cpt = (pc.segs[s].C + 15) / 16;
     }
     a.Wp = pc.d_W;
     a.Wimg = pc.d_Wimg;
+    a.Wblk = pc.d_Wblk;
     a.zero = pc.d_zero;
     a.bias = pc.d_bias;
     a.ncols = pc.ncols;
@@ -1164,7 +1413,8 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         TZ_TRY(dmalloc(ctx, m, (void**)&m->R0[l], npx * R * 4));
         TZ_TRY(dmalloc(ctx, m, (void**)&m->C0[l], npx * R * 4));
         TZ_TRY(dmalloc(ctx, m, (void**)&m->Ahat0[l], npx * m->stack[l] * 4));
-        TZ_TRY(dmalloc(ctx, m, (void**)&m->E[l], (size_t)max_batch * npx * 2 * m->stack[l] * 4));
+        const int ec = l == 0 ? (m->e0s = (2 * m->stack[0] + 7) / 8 * 8) : 2 * m->stack[l];
+        TZ_TRY(dmalloc(ctx, m, (void**)&m->E[l], (size_t)max_batch * npx * ec * 4));
         TZ_TRY(dmalloc(ctx, m, (void**)&m->R1[l], (size_t)max_batch * npx * R * 4));
     }
     TZ_TRY(dmalloc(ctx, m, (void**)&m->d_idx, sizeof(int) * 3 * max_batch));
@@ -1290,7 +1540,7 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         tz_prof_scope ps(ctx, TZP_ERR0);
         int gx = (int)std::min<long long>((npx(0) + 255) / 256, 2048);
         hipLaunchKernelGGL(k_err0, dim3(gx, n), dim3(256), 0, ctx->stream, d_frames_u8, H, W, d_in_stack, d_idx,
-                           d_idx + stride, m->Ahat0[0], Hp, Wp, m->stack[0], m->E[0]);
+                           d_idx + stride, m->Ahat0[0], Hp, Wp, m->stack[0], m->e0s, m->E[0]);
         TZ_HIP(ctx, hipGetLastError());
     }
     for (int l = 0; l < L - 1; ++l) {  // t0 bottom-up
@@ -1298,8 +1548,9 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         ConvArgs a;
         memset(&a, 0, sizeof(a));
         const float* ptrs[2] = {m->E[l], nullptr};
-        long long ns[2] = {npx(l) * 2 * m->stack[l], 0};
-        fill_srcs(a, pc, ptrs, ns);
+        const int ec = l == 0 ? m->e0s : 2 * m->stack[l];  // floats per pixel of E[l]
+        long long ns[2] = {npx(l) * ec, 0};
+        fill_srcs(a, pc, ptrs, ns, ec);
         set_geom(a, hl(l), wl(l));
         a.Cout = m->stack[l + 1];
         a.aux = m->Ahat0[l + 1];
@@ -1312,8 +1563,9 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         ConvArgs a;
         memset(&a, 0, sizeof(a));
         const float* ptrs[2] = {m->E[l], l < L - 1 ? m->R1[l + 1] : nullptr};
-        long long ns[2] = {npx(l) * 2 * m->stack[l], l < L - 1 ? npx(l + 1) * m->rstack[l + 1] : 0};
-        fill_srcs(a, pc, ptrs, ns);
+        const int ec = l == 0 ? m->e0s : 2 * m->stack[l];
+        long long ns[2] = {npx(l) * ec, l < L - 1 ? npx(l + 1) * m->rstack[l + 1] : 0};
+        fill_srcs(a, pc, ptrs, ns, ec);
         set_geom(a, hl(l), wl(l));
         a.init = m->G0[l];
         a.Cout = m->rstack[l];
@@ -1384,8 +1636,9 @@ extern "C" int tz_predict_tap(tz_ctx* ctx, int kind, int level, float* out) {
     if (level < 0 || level >= m->L || kind < 0 || kind > 1) return tz_fail(ctx, TZ_ERR_INVALID, "bad tap");
     size_t npx = (size_t)(m->Hp >> level) * (m->Wp >> level);
     const float* src = kind == 0 ? m->E[level] : m->R1[level];
-    size_t bytes = npx * (kind == 0 ? 2 * m->stack[level] : m->rstack[level]) * 4;
-    TZ_HIP(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDefault, ctx->stream));
+    const size_t ch = kind == 0 ? 2 * m->stack[level] : m->rstack[level];
+    const size_t sch = kind == 0 && level == 0 ? m->e0s : ch;  // E[0] is stored with a pixel stride of 8 floats
+    TZ_HIP(ctx, hipMemcpy2DAsync(out, ch * 4, src, sch * 4, ch * 4, npx, hipMemcpyDefault, ctx->stream));
     TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TZ_OK;
 }
