@@ -75,6 +75,11 @@ int tz_predict_next(tz_ctx* ctx, const float* frames, int n, float* out);
 /* Debug/parity taps of the last tz_predict_next call with n == 1: kind 0 = e_l(t0),
  * 1 = r_l(t1); out sized (Hp>>l)*(Wp>>l)*channels. */
 int tz_predict_tap(tz_ctx* ctx, int kind, int level, float* out);
+/* Diagnostic: which convolution kernels the predictor launches.  1 (default; env TEZIP_CONV16=0
+ * starts a context at 0) = the LDS-DMA kernels k_conv16 / k_conv16b / k_conv_small wherever a
+ * convolution qualifies, 0 = the general register-staged kernel k_conv3x3 everywhere.  Both walk
+ * the same fmaf chains: results are bit-identical (tests/test_gpu_fullsize.py). */
+int tz_set_conv_impl(tz_ctx* ctx, int lds_dma);
 
 /* ---- rollout (compress.py:183-268 encoder; decompress.py:115-186 decoder) -----------------
  * frames: nt*H*W*3 uint8.  window > 0: SWP (-w); window == 0: DWP with `threshold` (-t).

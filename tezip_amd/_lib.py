@@ -35,6 +35,7 @@ _SIGS = {
     "tz_predict_c0": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tz_predict_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tz_predict_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tz_set_conv_impl": (C.c_int, [C.c_void_p, C.c_int]),
     "tz_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                              C.c_void_p, C.c_void_p]),
     "tz_rollout_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -171,6 +172,10 @@ class Context:
         out = np.empty((self.hp >> level, self.wp >> level, ch), np.float32)
         self._ck(self.lib.tz_predict_tap(self.h, kind, level, out.ctypes.data))
         return out
+
+    def set_conv_impl(self, lds_dma):
+        """Diagnostic: 1 = LDS-DMA convolution kernels where they apply (default), 0 = the general kernel."""
+        self._ck(self.lib.tz_set_conv_impl(self.h, int(bool(lds_dma))))
 
     # ---- rollout + encode / decode
     def rollout(self, frames, warm_up, window, threshold=0.0, want_mse=False):

@@ -44,6 +44,10 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
     if (device < 0 || device >= ndev) return TZ_ERR_INVALID;
     if (hipSetDevice(device) != hipSuccess) return TZ_ERR_NO_DEVICE;
     tz_ctx* ctx = new tz_ctx();
+    {
+        const char* e = getenv("TEZIP_CONV16");  // diagnostic default of tz_set_conv_impl
+        if (e && e[0] == '0') ctx->conv_impl = 0;
+    }
     ctx->device = device;
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;

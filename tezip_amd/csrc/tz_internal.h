@@ -43,6 +43,7 @@ struct tz_ctx {
     std::vector<std::pair<void*, size_t>> pool;
     // model + rollout state
     tz_model* model = nullptr;
+    int conv_impl = 1;                // tz_set_conv_impl: 1 = LDS-DMA kernels where they apply
     // rollout-resident data
     int nt = 0, H = 0, W = 0, Hp = 0, Wp = 0, warm_up = 0;
     uint8_t* d_frames = nullptr;      // nt*H*W*3 (encoder: originals; decoder: key stack)

@@ -1000,6 +1000,25 @@ __global__ __launch_bounds__(256) void k_err0(const uint8_t* __restrict__ frames
     const long long fi = in_idx[n];
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (long long)gridDim.x * blockDim.x) {
         int y = (int)(p / Wp), x = (int)(p - (long long)y * Wp);
+        float* o = e0 + ((long long)n * npx + p) * Cs;
+        if (C == 3 && Cs == 8) {  // RGB frames (compress.py:114): one pixel = two 16-byte stores
+            float av[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (key) av[c] = (y < H && x < W) ? (float)frames_u8[(fi * H * W + (long long)y * W + x) * 3 + c] / 255.0f : 0.0f;
+                else av[c] = in_stack[(fi * npx + p) * 3 + c];
+            }
+            float d1[3], d2[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float h = ahat0[p * 3 + c];
+                d1[c] = h - av[c];
+                d2[c] = av[c] - h;
+            }
+            *(float4*)o = make_float4(tz_relu(d1[0]), tz_relu(d1[1]), tz_relu(d1[2]), tz_relu(d2[0]));
+            *(float4*)(o + 4) = make_float4(tz_relu(d2[1]), tz_relu(d2[2]), 0.0f, 0.0f);
+            continue;
+        }
         for (int c = 0; c < C; ++c) {
             float av;
             if (key) {
@@ -1010,10 +1029,10 @@ __global__ __launch_bounds__(256) void k_err0(const uint8_t* __restrict__ frames
             }
             float h = ahat0[p * C + c];
             float d1 = h - av, d2 = av - h;
-            e0[((long long)n * npx + p) * Cs + c] = tz_relu(d1);
-            e0[((long long)n * npx + p) * Cs + C + c] = tz_relu(d2);
+            o[c] = tz_relu(d1);
+            o[C + c] = tz_relu(d2);
         }
-        for (int c = 2 * C; c < Cs; ++c) e0[((long long)n * npx + p) * Cs + c] = 0.0f;  // stride padding reads as zero channels
+        for (int c = 2 * C; c < Cs; ++c) o[c] = 0.0f;  // stride padding reads as zero channels
     }
 }
 
@@ -1241,13 +1260,10 @@ static void launch_conv16_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
     hipLaunchKernelGGL((k_conv16<NT, EPI, UPS>), dim3(blocks), dim3(NTHR), 0, ctx->stream, a);
 }
 
-// TEZIP_CONV16=0 keeps every launch on k_conv3x3 (A/B timing; results are bit-identical)
-static bool use_conv16() {
-    static const bool on = [] {
-        const char* e = getenv("TEZIP_CONV16");
-        return !(e && e[0] == '0');
-    }();
-    return on;
+extern "C" int tz_set_conv_impl(tz_ctx* ctx, int lds_dma) {
+    if (!ctx) return TZ_ERR_INVALID;
+    ctx->conv_impl = lds_dma ? 1 : 0;
+    return TZ_OK;
 }
 
 static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbatch) {
@@ -1257,12 +1273,12 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         ups = ups || a.src[s].up;
         fullk = fullk && (a.src[s].C % 16) == 0;
     }
-    if (epi == EPI_RELU && a.nsrc == 1 && !ups && a.src[0].C == 3 && a.Cout == 3 && use_conv16()) {
+    if (epi == EPI_RELU && a.nsrc == 1 && !ups && a.src[0].C == 3 && a.Cout == 3 && ctx->conv_impl) {
         hipLaunchKernelGGL((k_conv_small<3, 3>), dim3(a.tiles_x * a.tiles_y * nbatch), dim3(256), 0, ctx->stream, a);
         TZ_HIP(ctx, hipGetLastError());
         return TZ_OK;
     }
-    if (a.Wblk && a.nsrc > 0 && !a.src[0].up && a.src[0].pstride == 8 && use_conv16()) {
+    if (a.Wblk && a.nsrc > 0 && !a.src[0].up && a.src[0].pstride == 8 && ctx->conv_impl) {
         const int blocks = a.ncb * a.tiles_x * a.tiles_y * nbatch;
 #define TZ_CASE16B(nt, e, u)                                                                                    \
     if (NT == nt && epi == e && ups == u) {                                                                     \
@@ -1274,7 +1290,7 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         TZ_CASE16B(1, EPI_POOL_ERR, false) TZ_CASE16B(3, EPI_POOL_ERR, false) TZ_CASE16B(4, EPI_POOL_ERR, false)
 #undef TZ_CASE16B
     }
-    if (a.Wimg && a.nsrc > 0 && fullk && use_conv16()) {
+    if (a.Wimg && a.nsrc > 0 && fullk && ctx->conv_impl) {
 #define TZ_CASE16(nt, e, u)                          \
     if (NT == nt && epi == e && ups == u) {          \
         launch_conv16_t<nt, e, u>(ctx, a, nbatch);   \
