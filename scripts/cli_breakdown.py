@@ -22,7 +22,8 @@ t0 = time.time(); key, _ = ctx.rollout(stack, 0, 20); payload, table, _ = ctx.en
 kf = np.zeros_like(stack); kf[key] = stack[key]
 t0 = time.time(); a = zstd.compress_array(kf, 9); T["zstd-9 key_frame (%d MB -> %.1f MB)" % (kf.nbytes >> 20, len(a) / 2**20)] = time.time() - t0
 st = compress.build_stream(payload, table, (1, 80, 512, 512, 3), 0)
-t0 = time.time(); b = zstd.compress_array(st, 9); T["zstd-9 entropy (%d MB -> %.1f MB)" % (st.nbytes >> 20, len(b) / 2**20)] = time.time() - t0
+t0 = time.time(); b = zstd.compress_array(st, 9); T["zstd-9 entropy, 1 thread (%d MB -> %.1f MB)" % (st.nbytes >> 20, len(b) / 2**20)] = time.time() - t0
+t0 = time.time(); b = zstd.compress_array(st, 9, zstd.default_threads()); T["zstd-9 entropy, %d worker threads (-> %.1f MB)" % (zstd.default_threads() if zstd.multithreaded() else 1, len(b) / 2**20)] = time.time() - t0
 ctx.close()
 t0 = time.time(); compress.run(m, d, os.path.join(tmp, "c"), 0, 20, None, "abs", [2.0], True, False, True); T["compress.run total"] = time.time() - t0
 t0 = time.time(); decompress.run(m, os.path.join(tmp, "c"), os.path.join(tmp, "u"), True, False); T["decompress.run total"] = time.time() - t0

@@ -101,6 +101,20 @@ def test_zstd_frames_are_standard_and_carry_content_size():
     assert zstd.decompress(zstd.compress(b"", 9)) == b""
 
 
+def test_zstd_job_parallel_frame_is_one_standard_frame():
+    """compress.run compresses entropy.dat with libzstd's worker threads when the library has them:
+    still one frame with its content size (what the reference's zstd.decompress needs,
+    decompress.py:89,98); falls back to one thread otherwise."""
+    rng = np.random.default_rng(0)
+    data = (rng.integers(0, 9, 6_000_000) ** 2 % 23).astype(np.int16)  # 12 MB: above the threading threshold
+    blob = zstd.compress_array(data, 9, threads=4)
+    assert blob[:4] == b"\x28\xb5\x2f\xfd"
+    assert zstd.decompress(blob) == data.tobytes()
+    one = zstd.compress_array(data, 9)
+    assert abs(len(blob) - len(one)) <= len(one) // 100
+    assert zstd.default_threads() >= 1 or "TEZIP_ZSTD_THREADS" in os.environ
+
+
 def test_load_images_rules(tmp_path):
     from PIL import Image
     d = tmp_path / "imgs"

@@ -169,9 +169,9 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
         key_frame = np.zeros_like(origine_img)
         key_frame[key] = origine_img[key]
         with open(os.path.join(OUTPUT_DIR, "key_frame.dat"), mode='wb') as f:
-            f.write(zstd.compress_array(key_frame, 9))
+            f.write(zstd.compress_array(key_frame, 9, zstd.default_threads()))
         stream = build_stream(payload, table if ENTROPY_RUN else None, (1, nt, H, W, 3), PREPROCESS)
         with open(os.path.join(OUTPUT_DIR, "entropy.dat"), mode='wb') as f:
-            f.write(zstd.compress_array(stream, 9))
+            f.write(zstd.compress_array(stream, 9, zstd.default_threads()))
     finally:
         ctx.close()
