@@ -1,6 +1,5 @@
-// PredNet predictor on MI355X: one LDS-tiled implicit-GEMM 3x3 convolution kernel on the
-// fp32 matrix cores (v_mfma_f32_16x16x4_f32), with the ConvLSTM / error-unit / max-pool
-// epilogues fused, and the host-side model driver.
+// PredNet predictor on MI355X: the host-side model driver (weight packing, prepare-time
+// constants, per-frame launch schedule).  The convolution kernels are in tz_conv_kernels.hip.h.
 //
 // What is computed (reference: /root/reference/src/prednet.py:235-308, used through
 // Model.predict on a 2-step sequence from zero state, compress.py:224-229):
@@ -17,1024 +16,13 @@
 // source are the 9 (ky, kx); an upsampled source up(r_{l+1}) is read at HALF resolution with 4
 // collapsed taps (dy, dx) whose weights are the float32 sums of the 3x3 taps that land on the
 // same half-resolution pixel for the output pixel's parity (2.25x fewer MACs for that source).
-// The MFMA k-loop below walks exactly that order; out-of-image taps and channel padding
+// The MFMA k-loops walk exactly that order; out-of-image taps and channel padding
 // contribute fmaf(0, w, acc) = acc.  No split-K, no atomics: results do not depend on batch
 // size, grid shape or device.
 //
-// Tiling: workgroup = 8 waves = 16x16 output pixels (256 GEMM rows) x NT*16 output columns;
-// each wave owns 32 rows x NT*16 columns = 2 x NT MFMA tiles (acc in registers).  For every
-// block of 16 input channels the 18x18 halo patch is staged in LDS ONCE and all 9 taps read
-// their shifted A fragments from it (the first version re-staged A per tap and was bound by
-// L2/Infinity-Cache traffic: 53 % L2 hit rate, profiles/r01); the per-tap 16 x (NT*16) weight
-// chunk is double-buffered in LDS, one barrier per tap.  The next patch is prefetched into
-// registers during the 9 taps.  LDS row strides (18 / NT*16[+16] floats) keep fragment reads
-// conflict free.  33-44 KB LDS, <=100 VGPRs, 512 threads => 3 workgroups (24 waves) per CU.
 #include <algorithm>
-#include <type_traits>
 
-#include "tz_internal.h"
-#include "tz_math.hip.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-enum { EPI_RAW = 0, EPI_RELU = 1, EPI_LSTM = 2, EPI_LSTM_PACKED = 3, EPI_POOL_ERR = 4 };
-
-struct ConvSrc {
-    const float* p;
-    long long nstride;  // elements between batch items (0 = broadcast constant)
-    int C;              // channels
-    int pstride;        // floats between pixels (>= C; level-0 error maps are stored 8 wide)
-    int up;             // 1: stored at half resolution, nearest x2 on read (prednet.py:264)
-    int cpt;            // 16-channel blocks of this source = ceil(C/16)
-};
-
-struct ConvArgs {
-    ConvSrc src[2];
-    int nsrc;
-    int H, W, tiles_x, tiles_y, ncb;
-    const float* Wp;    // [weight slots * 16][ncols], slot order = the K-loop order (see pack_conv)
-    const float* Wimg;  // the same weights in LDS image order for k_conv16 (see pack_conv), or null
-    const float* Wblk;  // block-step image for k_conv16b (see pack_block_image), or null
-    const float* zero;  // >= 16 bytes of zeros: LDS-DMA source of out-of-image patch pixels
-    int ncols;
-    const float* bias;  // [ncols]
-    const float* init;  // [H*W][ncols] accumulator start (G0), or null -> bias
-    int Cout;
-    const float* aux;   // LSTM: previous cell state [H*W][R] or null; POOL_ERR: Ahat(t0) of level l+1
-    float* out0;
-    long long out0_nstride;
-    float* out1;        // LSTM: cell state out (or null)
-    long long out1_nstride;
-    const int* out_idx; // optional: frame slot of batch item n in out0
-    int clip1;          // EPI_RELU: min(.,1)  (prednet.py:270)
-    int R;              // EPI_LSTM_PACKED: channels per gate
-};
-
-static constexpr int SA = 18;    // LDS row stride of one patch pixel (16 channels + 2 pad floats)
-static constexpr int PW = 18;    // same-resolution halo patch: PW x PW pixels around the 16x16 tile
-static constexpr int PPIX = PW * PW;
-static constexpr int LW = 10;    // half-resolution patch of an upsampled source: LW x LW pixels
-static constexpr int LPIX = LW * LW;
-static constexpr int NTHR = 512;                         // 8 waves, each owns two 16-row MFMA tiles
-static constexpr int MT = 2;
-static constexpr int A_ITEMS = PPIX * 4;                 // float4 items of one patch channel block
-static constexpr int A_PER_THREAD = (A_ITEMS + NTHR - 1) / NTHR;  // 3
-
-enum { MAP_LINEAR = 0, MAP_POOL = 1, MAP_PARITY = 2 };
-
-// GEMM row m (0..255) of the workgroup -> pixel (py, px) of its 16x16 output tile.
-//  LINEAR: wave w = rows 2w, 2w+1 of the tile.
-//  POOL:   the 4 accumulator registers of a lane form one 2x2 pooling window.
-//  PARITY: every 16-row MFMA tile holds pixels of ONE parity class (py&1, px&1), so that the
-//          parity-specific collapsed weights of an upsampled source can be its B operand.
-// Tile shapes and patch strides were chosen by exhaustive search so that every ds_read_b32 of
-// an A fragment (16 rows x 2 k per 32-lane group) is bank-conflict free at stride 18 for LINEAR
-// and POOL (PARITY keeps a 2-way conflict, see below; LDS is not the critical path).
-template <int MAP>
-__device__ __forceinline__ void row_to_patch(int m, int& py, int& px) {
-    int w = m >> 5, mt = (m >> 4) & 1, r16 = m & 15;
-    if (MAP == MAP_POOL) {
-        // M-tile = 8 rows x 2 columns = four stacked 2x2 windows (conflict-free at stride 18)
-        int T = 2 * w + mt;
-        py = 8 * (T >> 3) + 2 * (r16 >> 2) + ((r16 & 3) >> 1);
-        px = 2 * (T & 7) + (r16 & 1);
-    } else if (MAP == MAP_PARITY) {
-        // M-tile = two rows x 8 columns of the 8x8 grid of one parity class (2-way conflicts on its
-        // A reads; the conflict-free alternative -- rows (sub, sub+4) at stride 17 -- needs 4-byte
-        // patch stores and measured 2.5 % slower)
-        int T = 2 * w + mt, pc = T >> 2, sub = T & 3;
-        py = 2 * (2 * sub + (r16 >> 3)) + (pc >> 1);
-        px = 2 * (r16 & 7) + (pc & 1);
-    } else {
-        py = 2 * w + mt;
-        px = r16;
-    }
-}
-
-// XCD-aware block order: blocks b and b+8 share an XCD (round-robin dispatch), so give every
-// XCD a contiguous range of logical ids: the column blocks of one pixel tile and neighbouring
-// tiles then share one L2.  Bijective for any grid size; only speed depends on it.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-
-// Fused epilogues on the accumulator tiles of one wave (shared by both convolution kernels):
-// acc[mt][nt], element r <-> GEMM row (lane>>4)*4 + r of M-tile mt, column lane&15 of N-tile nt.
-template <int NT, int EPI, int MAP>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int n, int cb, int ty0, int tx0,
-                                              int wv, int lane, float* scratch) {
-    constexpr int NTC = NT * 16;
-    const int col0 = cb * NTC + (lane & 15);
-    auto out_pix = [&](int mt, int r, int& y, int& x) {
-        int py, px;
-        row_to_patch<MAP>(wv * 32 + mt * 16 + (lane >> 4) * 4 + r, py, px);
-        y = ty0 + py;
-        x = tx0 + px;
-    };
-    const int j = lane & 15;
-    if (EPI == EPI_RAW) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int y, x;
-                out_pix(mt, r, y, x);
-                if (y >= a.H || x >= a.W) continue;
-                long long pix = (long long)y * a.W + x;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) a.out0[pix * a.ncols + col0 + nt * 16] = acc[mt][nt][r];
-            }
-    } else if (EPI == EPI_RELU) {
-        float* o = a.out0 + (long long)(a.out_idx ? a.out_idx[n] : n) * a.out0_nstride;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int y, x;
-                out_pix(mt, r, y, x);
-                if (y >= a.H || x >= a.W) continue;
-                long long pix = (long long)y * a.W + x;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    int ch = col0 + nt * 16;
-                    if (ch < a.Cout) {
-                        float v = tz_relu(acc[mt][nt][r]);
-                        if (a.clip1 && v > 1.0f) v = 1.0f;
-                        o[pix * a.Cout + ch] = v;
-                    }
-                }
-            }
-    } else if (EPI == EPI_LSTM) {
-        // columns of this block: [i | f | g | o] x 16 channels of channel group cb
-        // prednet.py:255-259: c = f*c_prev + i*g ; r = o*tanh(c)
-        // All c_prev loads are issued first, from clamped (always valid) addresses: a load inside
-        // the per-pixel bounds branch costs one memory round trip per pixel (8 per wave).
-        const int ch = cb * 16 + j, R = a.Cout;
-        float* o0 = a.out0 + (long long)n * a.out0_nstride;
-        float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
-        long long pix[MT][4];
-        bool ok[MT][4];
-        float cp[MT][4];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int y, x;
-                out_pix(mt, r, y, x);
-                ok[mt][r] = y < a.H && x < a.W;
-                pix[mt][r] = ok[mt][r] ? (long long)y * a.W + x : 0;
-                cp[mt][r] = a.aux ? a.aux[pix[mt][r] * R + ch] : 0.0f;
-            }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float gi = tz_hard_sigmoid(acc[mt][0 % NT][r]);
-                float gf = tz_hard_sigmoid(acc[mt][1 % NT][r]);
-                float gg = tz_tanh(acc[mt][2 % NT][r]);
-                float go = tz_hard_sigmoid(acc[mt][3 % NT][r]);
-                float t1 = gf * cp[mt][r];
-                float t2 = gi * gg;
-                float c = t1 + t2;
-                float rr = go * tz_tanh(c);
-                if (ok[mt][r]) {
-                    o0[pix[mt][r] * R + ch] = rr;
-                    if (o1) o1[pix[mt][r] * R + ch] = c;
-                }
-            }
-    } else if (EPI == EPI_LSTM_PACKED) {
-        // one 16-column tile holds [i(R) f(R) g(R) o(R)], R <= 4.  Only R of 16 lanes of the
-        // accumulator layout own a channel, so the LSTM update (two tanh per item) is re-distributed:
-        // the wave's 32 x 16 tile goes through its private LDS scratch and every lane takes
-        // (pixel, channel) items lane, lane + 64 of the 32 * R -- 4x less VALU than 8 masked rows per
-        // lane (the level-0 gate launch was VALU-bound in this epilogue).
-        const int R = a.R;
-        float* o0 = a.out0 + (long long)n * a.out0_nstride;
-        float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
-        float* t = scratch + wv * (32 * 17);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[(mt * 16 + (lane >> 4) * 4 + r) * 17 + j] = acc[mt][0][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int row[2], c[2];
-        long long pix[2];
-        bool ok[2];
-        float cp[2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int item = lane + 64 * it;
-            row[it] = item / R;
-            c[it] = item - row[it] * R;
-            int py, px;
-            row_to_patch<MAP>(wv * 32 + (row[it] & 31), py, px);
-            const int y = ty0 + py, x = tx0 + px;
-            ok[it] = item < 32 * R && y < a.H && x < a.W;
-            pix[it] = ok[it] ? ((long long)y * a.W + x) * R + c[it] : 0;
-            cp[it] = a.aux ? a.aux[pix[it]] : 0.0f;
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const float* tr = t + (row[it] & 31) * 17 + c[it];
-            float gi = tz_hard_sigmoid(tr[0]), gf = tz_hard_sigmoid(tr[R]), gg = tz_tanh(tr[2 * R]), go = tz_hard_sigmoid(tr[3 * R]);
-            float t1 = gf * cp[it];
-            float t2 = gi * gg;
-            float cc = t1 + t2;
-            float rr = go * tz_tanh(cc);
-            if (ok[it]) {
-                o0[pix[it]] = rr;
-                if (o1) o1[pix[it]] = cc;
-            }
-        }
-    } else if (EPI == EPI_POOL_ERR) {
-        // prednet.py:289-291 then 274-277 of the next level: A = maxpool2x2(relu(conv));
-        // e = [relu(Ahat0 - A), relu(A - Ahat0)] written at the pooled resolution.
-        const int H2 = a.H >> 1, W2 = a.W >> 1, C = a.Cout;
-        float* o = a.out0 + (long long)n * a.out0_nstride;
-        long long pp[MT];
-        bool ok[MT][NT];
-        float h[MT][NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            int y, x;
-            out_pix(mt, 0, y, x);
-            const int yp = y >> 1, xp = x >> 1;
-            const bool okp = yp < H2 && xp < W2;
-            pp[mt] = okp ? (long long)yp * W2 + xp : 0;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int ch = col0 + nt * 16;
-                ok[mt][nt] = okp && ch < C;
-                h[mt][nt] = a.aux[ok[mt][nt] ? pp[mt] * C + ch : 0];
-            }
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int ch = col0 + nt * 16;
-                float m = tz_relu(acc[mt][nt][0]);
-#pragma unroll
-                for (int r = 1; r < 4; ++r) {
-                    float t = tz_relu(acc[mt][nt][r]);
-                    if (t > m) m = t;
-                }
-                float d1 = h[mt][nt] - m, d2 = m - h[mt][nt];
-                if (ok[mt][nt]) {
-                    o[pp[mt] * 2 * C + ch] = tz_relu(d1);
-                    o[pp[mt] * 2 * C + C + ch] = tz_relu(d2);
-                }
-            }
-    }
-}
-
-// FULLK: every source has a multiple of 16 channels, so every same-resolution step runs all four
-// k-steps (lets the compiler schedule the 32 MFMAs of a step as one straight-line block).
-template <int NT, int EPI, bool UPS, bool FULLK>
-__global__ __launch_bounds__(NTHR, NT == 1 ? 8 : 6) void k_conv3x3(const ConvArgs a) {
-    // parity tiles only where an upsampled source needs them (the top level has none)
-    constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
-    constexpr int SAH = SA;                           // floats per pixel of the same-resolution patch
-    constexpr int SAL = SA;                           // ... of the half-resolution patch
-    constexpr int NTC = NT * 16;
-    constexpr int SB = NTC + ((NTC % 32) == 0 ? 16 : 0);
-    constexpr int QPR = NTC / 4;                     // float4 items per weight row
-    constexpr int BVEC = 16 * QPR;                   // items of a same-resolution chunk (16 k-rows)
-    constexpr int UPH = NT == 4 ? 8 : 16;            // k-rows of an upsampled-source step (per class)
-    constexpr int UPN = 16 / UPH;                    // steps per collapsed tap
-    constexpr int BUF = (UPS ? 4 * UPH : 16) * SB;   // floats per weight buffer (up: 4 classes x UPH rows)
-    static_assert((!UPS || 4 * UPH * QPR <= NTHR) && BVEC <= NTHR, "one weight item per thread");
-    __shared__ float sA[PPIX * SA];
-    __shared__ float sB[2 * BUF];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int cb = bid % a.ncb;
-    bid /= a.ncb;
-    const int ntiles = a.tiles_x * a.tiles_y;
-    const int tile = bid % ntiles, n = bid / ntiles;
-    const int ty0 = (tile / a.tiles_x) * 16, tx0 = (tile % a.tiles_x) * 16;
-
-    // ---- A staging roles.  Same-resolution source: 18x18x16 halo patch = 1296 float4 items,
-    // item i -> patch pixel i>>2, channel quad i&3.  Upsampled source: 10x10x16 = 400 items of
-    // the half-resolution map (item i = tid).
-    const int aq = tid & 3;
-
-    float4 ra[A_PER_THREAD];
-    float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    const int nb0 = a.nsrc > 0 ? a.src[0].cpt : 0;
-    const int nblk = nb0 + (a.nsrc > 1 ? a.src[1].cpt : 0);
-
-    auto load_quad = [&](const ConvSrc& s, const float* ptr, int c0) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((s.C & 3) == 0 && (s.pstride & 3) == 0) {
-            v = *(const float4*)ptr;
-        } else {
-            v.x = ptr[0];
-            if (c0 + 1 < s.C) v.y = ptr[1];
-            if (c0 + 2 < s.C) v.z = ptr[2];
-            if (c0 + 3 < s.C) v.w = ptr[3];
-        }
-        return v;
-    };
-    auto load_patch = [&](int blk) {
-        const ConvSrc& s = blk >= nb0 ? a.src[1] : a.src[0];
-        const int c0 = (blk >= nb0 ? blk - nb0 : blk) * 16 + 4 * aq;
-        const float* base = s.p + (long long)n * s.nstride;
-        // (pixel coordinates are recomputed per block rather than kept in registers)
-        if (UPS && s.up) {
-            const int pp = tid >> 2;
-            const int ly = (ty0 >> 1) - 1 + pp / LW, lx = (tx0 >> 1) - 1 + pp % LW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pp < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1) && c0 < s.C)
-                v = load_quad(s, base + ((long long)ly * (a.W >> 1) + lx) * s.pstride + c0, c0);
-            ra[0] = v;
-        } else {
-#pragma unroll
-            for (int j = 0; j < A_PER_THREAD; ++j) {
-                const int i = tid + NTHR * j, pp = i >> 2;
-                const int yy = ty0 - 1 + pp / PW, xx = tx0 - 1 + pp % PW;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < A_ITEMS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && c0 < s.C)
-                    v = load_quad(s, base + ((long long)yy * a.W + xx) * s.pstride + c0, c0);
-                ra[j] = v;
-            }
-        }
-    };
-    auto store_patch = [&](bool up) {
-#pragma unroll
-        for (int j = 0; j < A_PER_THREAD; ++j) {
-            int i = tid + NTHR * j;
-            if (up ? (j == 0 && i < LPIX * 4) : (i < A_ITEMS)) {
-                if (up || (SAH & 1) == 0) {
-                    float* d = sA + (i >> 2) * (up ? SAL : SAH) + 4 * aq;
-                    *(float2*)d = make_float2(ra[j].x, ra[j].y);
-                    *(float2*)(d + 2) = make_float2(ra[j].z, ra[j].w);
-                } else {  // odd stride: only 4-byte alignment
-                    float* d = sA + (i >> 2) * SAH + 4 * aq;
-                    d[0] = ra[j].x;
-                    d[1] = ra[j].y;
-                    d[2] = ra[j].z;
-                    d[3] = ra[j].w;
-                }
-            }
-        }
-    };
-    // Weight staging, one float4 per thread and step.  Same-resolution step: the 16 k-rows of
-    // one (block, tap).  Upsampled step: UPH k-rows (part `hf` of the block) of one collapsed tap
-    // for each of the 4 parity classes; the packed file keeps 16 rows per (tap, class) slot.
-    auto load_b = [&](int slot, bool up, int hf) {
-        if (UPS && up) {
-            int cls = tid / (UPH * QPR), r = tid - cls * (UPH * QPR);
-            if (tid < 4 * UPH * QPR)
-                rb = *(const float4*)(a.Wp + ((long long)(slot + cls) * 16 + UPH * hf + r / QPR) * a.ncols + cb * NTC + 4 * (r % QPR));
-        } else if (tid < BVEC) {
-            rb = *(const float4*)(a.Wp + ((long long)slot * 16 + tid / QPR) * a.ncols + cb * NTC + 4 * (tid % QPR));
-        }
-    };
-    auto store_b = [&](int buf, bool up) {
-        if (UPS && up) {
-            if (tid < 4 * UPH * QPR) *(float4*)(sB + buf * BUF + (tid / QPR) * SB + 4 * (tid % QPR)) = rb;  // row = cls*UPH + r
-        } else if (tid < BVEC) {
-            *(float4*)(sB + buf * BUF + (tid / QPR) * SB + 4 * (tid % QPR)) = rb;
-        }
-    };
-
-    // ---- accumulators: acc[mt][nt], element r <-> GEMM row (lane>>4)*4 + r, column lane&15
-    f32x4 acc[MT][NT];
-    const int col0 = cb * NTC + (lane & 15);
-    auto out_pix = [&](int mt, int r, int& y, int& x) {
-        int py, px;
-        row_to_patch<MAP>(wv * 32 + mt * 16 + (lane >> 4) * 4 + r, py, px);
-        y = ty0 + py;
-        x = tx0 + px;
-    };
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (a.init) {
-                // (clamped address instead of a bounds branch: rows outside the image are never stored)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int y, x;
-                    out_pix(mt, r, y, x);
-                    const long long pix = (y < a.H && x < a.W) ? (long long)y * a.W + x : 0;
-                    acc[mt][nt][r] = a.init[pix * a.ncols + col0 + nt * 16];
-                }
-            } else {
-                float b = a.bias[col0 + nt * 16];
-                acc[mt][nt] = (f32x4){b, b, b, b};
-            }
-        }
-
-    // ---- K loop: blocks of 16 input channels (patch staged once per block).  A same-resolution
-    // source runs 9 steps per block (one tap each, 2 or 4 k-steps of 4 channels); an upsampled
-    // source runs 4*UPN steps (4 collapsed taps x UPN parts of UPH channels; the weights of the 3x3
-    // taps that hit the same half-resolution pixel were summed at pack time, per parity class).
-    // Every step: prefetch next weights -> MFMAs from LDS -> store next weights -> one barrier.
-    if (nblk > 0) {
-        int arow_hi[MT], arow_lo[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            int py, px;
-            row_to_patch<MAP>(wv * 32 + mt * 16 + (lane & 15), py, px);
-            arow_hi[mt] = (py * PW + px) * SAH + (lane >> 4);
-            arow_lo[mt] = (((py >> 1) + (py & 1)) * LW + (px >> 1) + (px & 1)) * SAL + (lane >> 4);
-        }
-        const int wcls = MAP == MAP_PARITY ? (wv >> 1) : 0;  // parity class of this wave's rows
-        const int boff = (lane >> 4) * SB + (lane & 15);
-        bool up = UPS && a.src[nb0 > 0 ? 0 : 1].up != 0;
-        load_patch(0);
-        load_b(0, up, 0);
-        store_patch(up);
-        store_b(0, up);
-        __syncthreads();
-        int cur = 0, slot0 = 0;
-        for (int blk = 0; blk < nblk; ++blk) {
-            const ConvSrc& s = blk >= nb0 ? a.src[1] : a.src[0];
-            up = UPS && s.up != 0;
-            const int nsteps = up ? 4 * UPN : 9;
-            const int cw = s.C - (blk >= nb0 ? blk - nb0 : blk) * 16;
-            const bool more_blk = blk + 1 < nblk;
-            const bool up_next = UPS && more_blk && (blk + 1 >= nb0 ? a.src[1].up : a.src[0].up) != 0;
-#pragma unroll 1
-            for (int st = 0; st < nsteps; ++st) {
-                const bool last = st == nsteps - 1;
-                if (!last) load_b(up ? slot0 + 4 * ((st + 1) / UPN) : slot0 + st + 1, up, (st + 1) % UPN);
-                else if (more_blk) load_b(slot0 + (up ? 16 : 9), up_next, 0);
-                // The next block's patch gather is issued AFTER this step's weight load: vmcnt
-                // retires in order, so the end-of-step wait for the (older) weight load leaves the
-                // patch loads in flight for one more step instead of forcing them after one.
-                if (st == 0 && more_blk) load_patch(blk + 1);
-                // one compute body for both kinds of step: the first pair of k-steps always runs,
-                // the second pair only when the step holds more than 8 channels
-                const int tap = up ? st / UPN : st;
-                const int toff = up ? ((tap >> 1) * LW + (tap & 1)) * SAL : ((tap / 3) * PW + (tap % 3)) * SAH;
-                const bool second = up ? (UPH == 16) : (FULLK || cw > 8);
-                const float* pa = sA + toff + (up ? UPH * (st % UPN) : 0);
-                const float* pb = sB + cur * BUF + boff + (up ? wcls * UPH * SB : 0);
-                int ar[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) ar[mt] = up ? arow_lo[mt] : arow_hi[mt];
-                // (kept as ONE loop nest: duplicating the MFMA body per k-step count made hipcc
-                // spill accumulators inside the loop under the 80-VGPR budget, 4x slower)
-#pragma unroll
-                for (int pair = 0; pair < 2; ++pair) {
-                    if (pair == 0 || second) {
-#pragma unroll
-                        for (int k2 = 0; k2 < 2; ++k2) {
-                            const int kk = 2 * pair + k2;
-                            float fa[MT], fb[NT];
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) fa[mt] = pa[ar[mt] + 4 * kk];
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) fb[nt] = pb[4 * kk * SB + nt * 16];
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt)
-                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
-                        }
-                    }
-                }
-                if (!last) store_b(cur ^ 1, up);
-                else if (more_blk) store_b(cur ^ 1, up_next);
-                __syncthreads();
-                cur ^= 1;
-            }
-            slot0 += up ? 16 : 9;
-            if (more_blk) {
-                store_patch(up_next);
-                __syncthreads();
-            }
-        }
-    }
-    if (EPI == EPI_LSTM_PACKED) __syncthreads();  // the patch buffer becomes the epilogue's scratch
-    static_assert(8 * 32 * 17 <= PPIX * SA, "epilogue scratch fits the patch buffer");
-    conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane, sA);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_conv16: the same implicit GEMM (same tiles, same fmaf-chain order, same epilogues) for
-// convolutions whose sources all have a multiple of 16 channels -- every hot launch of levels >= 1.
-// All staging is LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, so the
-// K loop holds only accumulators, fragments and addresses (k_conv3x3 keeps a register-staged
-// prefetch of the next patch and weight chunk alive across its steps: 22 spilled VGPRs and a
-// vmcnt(0) in front of every use at the 80-VGPR budget; MFMA pipe 68-80 % busy at 2.39 GHz).
-//
-// An LDS-DMA writes wave-uniform base + lane*16 B, so both LDS images are lane-linear and the
-// layout work moves to the SOURCE address:
-//  * weights are packed on the host in image order [slot][column block][k-step][lane][4]: lane
-//    (g = lane>>4, j = lane&15) of k-step kk holds W[4kk+g][16nt+j], nt = 0..3 -- one
-//    ds_read_b128 per k-step gives the B fragments of all four column tiles, conflict free;
-//    a (slot, column block) chunk is 4 KB = four 1 KB wave-instructions;
-//  * the halo patch is QUAD-PLANAR: the 16-byte item (slot, channel quad q) sits at item index
-//    q * NP + slot (NP = 336 slots per plane for the 18x18 patch, 112 for the 10x10 one; 4 planes =
-//    exactly 21 / 7 wave-instructions).  An A fragment address is then lane base + tap offset +
-//    k-step offset with the last two uniform (a scalar add and an instruction immediate): the K
-//    loop carries almost no address arithmetic, which measured as the largest single loss of the
-//    DMA'd loop (scripts/microbench/conv_skeleton.hip: 133 -> 140 TFLOP/s; 8-way LDS conflicts on
-//    the same reads cost nothing measurable).  A ds_read_b32 of 16 rows x 2 k is 2-way conflicted
-//    at best in any 16-byte-granular image (lanes 0-31 only touch elements 0,1 of a quad); the
-//    plane layout reaches that for all three row maps, with the columns of a parity-tile patch
-//    stored evens first (x -> (x>>1) + 9*(x&1)) so that one parity class is contiguous.
-//    Out-of-image pixels read a zero page.
-// Protocol per step: issue the DMA of the next step's weights into the other weight buffer, MFMAs
-// of this step, s_waitcnt vmcnt(0), s_barrier.  The NEXT block's patch is issued into the other
-// patch buffer ahead of a block's first step and retires with that step's wait, one whole step of
-// MFMAs later: waves do not stall for a patch.
-// LDS = 50 pieces of 1 KB (3 workgroups per CU).  Same-resolution phase: patches P0 = [0,21),
-// P1 = [21,42), weight buffers 42 + 4*buf.  The upsampled source's steps (one collapsed tap each:
-// 4 k-steps x 4 parity classes = 16 pieces of weights, 32 MFMAs per wave and barrier) use
-// 7-piece patches [0,7), [7,14) and weight buffers 14 + 16*buf; the switch between the two
-// layouts happens once per workgroup behind a barrier, with an un-overlapped first load.
-static constexpr int P16_PIECES = 21;                   // 1 KB pieces of an 18x18 patch (324 px -> 20.25)
-static constexpr int U16_PIECES = 7;                    // ... of a 10x10 half-resolution patch
-static constexpr int NP16 = P16_PIECES * 16, NPU16 = U16_PIECES * 16;  // slots per quad plane (336 / 112)
-static constexpr int C16_LDS_PIECES = 2 * P16_PIECES + 8;   // >= 2 * U16_PIECES + 32
-
-__device__ __forceinline__ void glds16(const float* g, float* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-
-// waits for all of this wave's vector-memory operations (LDS-DMA included)
-__device__ __forceinline__ void wait_vm(int = 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void wg_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-template <int NT, int EPI, bool UPS>
-__global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
-    constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
-    __shared__ __attribute__((aligned(16))) float smem[C16_LDS_PIECES * 256];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id, scalar
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int cb = bid % a.ncb;
-    bid /= a.ncb;
-    const int ntiles = a.tiles_x * a.tiles_y;
-    const int tile = bid % ntiles, n = bid / ntiles;
-    const int ty0 = (tile / a.tiles_x) * 16, tx0 = (tile % a.tiles_x) * 16;
-    const int nb0 = a.src[0].cpt;
-    const int nblk = nb0 + (a.nsrc > 1 ? a.src[1].cpt : 0);
-    const int g = lane >> 4;
-    // src[] is ordered same-resolution first (or holds only the upsampled source)
-    const bool up0 = UPS && a.src[0].up != 0;
-    const int nbe = up0 ? 0 : (UPS && a.nsrc > 1 && a.src[1].up ? nb0 : nblk);  // same-resolution blocks
-
-    // ---- LDS-DMA issue.  Item i = piece * 64 + lane of a patch = quad plane i / NP, slot i % NP.
-    auto issue_patch = [&](int blk, int piece0) {
-        const bool s1 = blk >= nb0;
-        const ConvSrc& s = s1 ? a.src[1] : a.src[0];
-        const int c0 = (s1 ? blk - nb0 : blk) * 16;
-        const float* base = s.p + (long long)n * s.nstride;
-        float* dst = smem + piece0 * 256;
-        // the patch geometry is recomputed per call (once per block): kept live across the K loop
-        // it costs ~12 VGPRs and spills
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        if (UPS && blk >= nbe) {
-            if (wv >= U16_PIECES) return;
-            const int i = wv * 64 + ln, q = i / NPU16, slot = i - q * NPU16;
-            const int Y = slot / LW, X = slot - Y * LW;
-            const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
-            const bool ok = slot < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
-            glds16(ok ? base + ((long long)ly * (a.W >> 1) + lx) * s.pstride + c0 + 4 * q : a.zero, dst + wv * 256);
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < (P16_PIECES + 7) / 8; ++j) {
-            const int piece = wv + 8 * j;
-            if (piece < P16_PIECES) {
-                const int i = piece * 64 + ln, q = i / NP16, slot = i - q * NP16;
-                const int y = slot / PW, xs = slot - y * PW;
-                const int x = MAP == MAP_PARITY ? (xs < PW / 2 ? 2 * xs : 2 * (xs - PW / 2) + 1) : xs;
-                const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
-                const bool ok = slot < PPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-                glds16(ok ? base + ((long long)yy * a.W + xx) * s.pstride + c0 + 4 * q : a.zero, dst + piece * 256);
-            }
-        }
-    };
-    // weights of one step into the pieces starting at piece0.  Same-resolution step: the 4 k-steps
-    // of (block, tap), one piece each from the waves of half `half` of the workgroup.  Upsampled
-    // step: the 4 k-steps of one collapsed tap for each of the 4 parity classes, piece index
-    // class * 4 + k-step; wave w fetches k-steps 2(w&1), 2(w&1)+1 of class w>>1.
-    auto issue_w = [&](int slot, bool up, int piece0, int half) {
-        if (UPS && up) {
-            const float* src = a.Wimg + (((long long)(slot + (wv >> 1)) * a.ncb + cb) * 4 + 2 * (wv & 1)) * 256 + lane * 4;
-            float* dst = smem + (piece0 + 2 * wv) * 256;
-            glds16(src, dst);
-            glds16(src + 256, dst + 256);
-        } else if ((wv >> 2) == half) {
-            glds16(a.Wimg + (((long long)slot * a.ncb + cb) * 4 + (wv & 3)) * 256 + lane * 4,
-                   smem + (piece0 + (wv & 3)) * 256);
-        }
-    };
-
-    // ---- accumulators (as in k_conv3x3)
-    f32x4 acc[MT][NT];
-    {
-        const int col0 = cb * (NT * 16) + (lane & 15);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if (a.init) {
-                    // (clamped address instead of a bounds branch: rows outside the image are never stored)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int py, px;
-                        row_to_patch<MAP>(wv * 32 + mt * 16 + g * 4 + r, py, px);
-                        const int y = ty0 + py, x = tx0 + px;
-                        const long long pix = (y < a.H && x < a.W) ? (long long)y * a.W + x : 0;
-                        acc[mt][nt][r] = a.init[pix * a.ncols + col0 + nt * 16];
-                    }
-                } else {
-                    const float b = a.bias[col0 + nt * 16];
-                    acc[mt][nt] = (f32x4){b, b, b, b};
-                }
-            }
-    }
-
-    // float index of this lane's A row (tile pixel of GEMM row lane&15, element g of the quad) in
-    // plane 0 of each patch image, for tap (0,0)
-    int abase[MT], abase_lo[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int py, px;
-        row_to_patch<MAP>(wv * 32 + mt * 16 + (lane & 15), py, px);
-        abase[mt] = 4 * (py * PW + (MAP == MAP_PARITY ? (px >> 1) + (PW / 2) * (px & 1) : px)) + g;
-        abase_lo[mt] = 4 * (((py >> 1) + (py & 1)) * LW + (px >> 1) + (px & 1)) + g;
-    }
-    const int wcls = MAP == MAP_PARITY ? (wv >> 1) : 0;  // parity class (py&1, px&1) of this wave's rows
-
-    // The K loop is two loop nests in sequence -- the blocks of the same-resolution sources, then
-    // the blocks of the upsampled source -- each with ONE MFMA body: with both kinds of step in one
-    // loop body hipcc moves the accumulators between register sets per branch and spills them.
-    int slot0 = 0;
-    auto run_phase = [&](auto upc, int b0, int b1) {
-        constexpr bool UP = decltype(upc)::value;
-        constexpr int nsteps = UP ? 4 : 9, bslots = UP ? 16 : 9, WP = UP ? 16 : 4;
-        constexpr int pA0 = 0, pA1 = UP ? U16_PIECES : P16_PIECES;   // patch buffers
-        constexpr int wA = 2 * pA1;                                  // weight buffers
-        if (b0 >= b1) return;
-        // first patch and first weights of the phase (nothing of the previous phase is live)
-        issue_patch(b0, pA0);
-        issue_w(slot0, UP, wA, 0);
-        wait_vm(0);
-        wg_barrier();
-        int pi = 0, cur = 0;
-#pragma unroll 1
-        for (int blk = b0; blk < b1; ++blk) {
-            const bool more_blk = blk + 1 < b1;
-            // the next block's patch goes into the other patch buffer while this block computes; it
-            // is retired together with the first step's weight DMA (a whole step later)
-            if (more_blk) issue_patch(blk + 1, pi ? pA0 : pA1);
-#pragma unroll 1
-            for (int st = 0; st < nsteps; ++st) {
-                if (st + 1 < nsteps) issue_w(UP ? slot0 + 4 * (st + 1) : slot0 + st + 1, UP, wA + WP * (cur ^ 1), cur ^ 1);
-                else if (more_blk) issue_w(slot0 + bslots, UP, wA + WP * (cur ^ 1), cur ^ 1);
-                const float* pa = smem + (pi ? pA1 : pA0) * 256;
-                const float* wb = smem + (wA + WP * cur + (UP ? 4 * wcls : 0)) * 256 + lane * 4;
-                // tap offset in slots.  Same resolution: dy rows of 18; a parity-tile patch stores its
-                // columns evens first, so one step in x is +9 / -8 from an even / odd column and two
-                // steps are +1.  Upsampled: the 2x2 collapsed taps of the 10-wide half-resolution patch.
-                int toff;
-                if (UP) {
-                    toff = 4 * ((st >> 1) * LW + (st & 1));
-                } else {
-                    const int dy = st / 3, dx = st - 3 * dy;
-                    const int xo = MAP == MAP_PARITY ? (dx == 1 ? ((wcls & 1) ? 1 - PW / 2 : PW / 2) : (dx >> 1)) : dx;
-                    toff = 4 * (dy * PW + xo);
-                }
-                constexpr int KOFF = 4 * (UP ? NPU16 : NP16);  // floats between the quad planes
-                float fa[MT][4];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[(UP ? abase_lo[mt] : abase[mt]) + toff + kk * KOFF];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const f32x4 fb = *(const f32x4*)(wb + kk * 256);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][kk], fb[nt], acc[mt][nt], 0, 0, 0);
-                }
-                wait_vm(0);
-                wg_barrier();
-                cur ^= 1;
-            }
-            slot0 += bslots;
-            pi ^= 1;
-        }
-    };
-    // waves in the K loop outrank the waves of other workgroups that are in their prologue or
-    // epilogue (VALU-dense, and older): the matrix pipe is issued first
-    __builtin_amdgcn_s_setprio(1);
-    run_phase(std::false_type{}, 0, nbe);
-    if (UPS) run_phase(std::true_type{}, nbe, nblk);
-    __builtin_amdgcn_s_setprio(0);
-    conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane, smem);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_conv16b: the level-0 convolutions -- A_0 (e_0: 6 channels -> 48 columns) and the level-0
-// gates ([e_0 (6), up(r_1) (48)] -> 16 columns) -- as BLOCK STEPS.  With 3..16 useful columns a
-// tap step holds 4-12 MFMAs per wave, and k_conv3x3 spends the launch in the latency of 9-21
-// barrier-separated staging steps (35-45 % matrix pipe use).  Here everything a block of input
-// channels needs -- its patch and the weights of ALL its taps (and parity classes) -- is one
-// LDS-DMA batch: one barrier pair per block, 32-108 MFMAs per wave between them, the next
-// block's batch in flight meanwhile.  Same tiles, fmaf-chain order and epilogues as k_conv16.
-//   block 0: the same-resolution source, stored 8 floats per pixel (6 real channels + 2 zeros):
-//            2 quad planes = 11 pieces, 9 taps x 2 k-steps;
-//   blocks 1..: 16 channels of the upsampled source: 7 pieces, 4 taps x 4 classes x 4 k-steps.
-// Weight image per block: [tap][(class)][k-step][lane][NTI], NTI = 1 float per lane for one
-// column tile (ds_read_b32), 4 otherwise (ds_read_b128).
-static constexpr int E8_PIECES = 11;
-
-__device__ __forceinline__ void wait_vm_n(int n) {  // wave-uniform n: leave the n youngest operations in flight
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    }
-}
-
-template <int NT>
-struct C16b {
-    static constexpr int NTI = NT == 1 ? 1 : 4;
-    static constexpr int W8 = (18 * 64 * NTI * 4 + 1023) / 1024;  // weight pieces of block 0
-    static constexpr int WU = 16 * NTI;                           // ... of an upsampled block
-    static constexpr int bufp(bool ups) {
-        return !ups ? E8_PIECES + W8 : (E8_PIECES + W8 > U16_PIECES + WU ? E8_PIECES + W8 : U16_PIECES + WU);
-    }
-};
-
-template <int NT, int EPI, bool UPS>
-__global__ __launch_bounds__(NTHR, 6) void k_conv16b(const ConvArgs a) {
-    constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
-    constexpr int NTI = C16b<NT>::NTI, W8 = C16b<NT>::W8, WU = C16b<NT>::WU, BUFP = C16b<NT>::bufp(UPS);
-    constexpr int NBUF = UPS ? 2 : 1;
-    constexpr int SCRATCH = EPI == EPI_LSTM_PACKED ? 8 * 32 * 17 : 0;  // epilogue scratch (re-uses the buffers)
-    __shared__ __attribute__((aligned(16))) float smem[NBUF * BUFP * 256 > SCRATCH ? NBUF * BUFP * 256 : SCRATCH];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int cb = bid % a.ncb;
-    bid /= a.ncb;
-    const int ntiles = a.tiles_x * a.tiles_y;
-    const int tile = bid % ntiles, n = bid / ntiles;
-    const int ty0 = (tile / a.tiles_x) * 16, tx0 = (tile % a.tiles_x) * 16;
-    const int nblk = 1 + (UPS ? a.src[1].cpt : 0);
-    const int g = lane >> 4;
-
-    // one LDS-DMA batch = patch pieces then weight pieces of block b, dealt round-robin to the
-    // waves; returns how many this wave issued
-    auto issue_block = [&](int b, int buf) -> int {
-        float* dst = smem + buf * BUFP * 256;
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int P = b == 0 ? E8_PIECES : U16_PIECES, T = P + (b == 0 ? W8 : WU);
-        const float* wsrc = b == 0 ? a.Wblk + (long long)cb * W8 * 256
-                                   : a.Wblk + ((long long)a.ncb * W8 + ((long long)(b - 1) * a.ncb + cb) * WU) * 256;
-        int cnt = 0;
-        for (int piece = wv; piece < T; piece += 8, ++cnt) {
-            if (piece >= P) {
-                glds16(wsrc + (piece - P) * 256 + ln * 4, dst + piece * 256);
-            } else if (b == 0) {
-                const ConvSrc& s = a.src[0];
-                const int i = piece * 64 + ln, q = i / NP16, slot = i - q * NP16;
-                const int y = slot / PW, xs = slot - y * PW;
-                const int x = MAP == MAP_PARITY ? (xs < PW / 2 ? 2 * xs : 2 * (xs - PW / 2) + 1) : xs;
-                const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
-                const bool ok = q < 2 && slot < PPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-                glds16(ok ? s.p + (long long)n * s.nstride + ((long long)yy * a.W + xx) * s.pstride + 4 * q : a.zero, dst + piece * 256);
-            } else {
-                const ConvSrc& s = a.src[1];
-                const int i = piece * 64 + ln, q = i / NPU16, slot = i - q * NPU16;
-                const int Y = slot / LW, X = slot - Y * LW;
-                const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
-                const bool ok = slot < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
-                glds16(ok ? s.p + (long long)n * s.nstride + ((long long)ly * (a.W >> 1) + lx) * s.pstride + (b - 1) * 16 + 4 * q : a.zero,
-                       dst + piece * 256);
-            }
-        }
-        return cnt;
-    };
-
-    issue_block(0, 0);
-
-    // ---- accumulators (as in k_conv16; the loads overlap the first DMA batch)
-    f32x4 acc[MT][NT];
-    {
-        const int col0 = cb * (NT * 16) + (lane & 15);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if (a.init) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int py, px;
-                        row_to_patch<MAP>(wv * 32 + mt * 16 + g * 4 + r, py, px);
-                        const int y = ty0 + py, x = tx0 + px;
-                        const long long pix = (y < a.H && x < a.W) ? (long long)y * a.W + x : 0;
-                        acc[mt][nt][r] = a.init[pix * a.ncols + col0 + nt * 16];
-                    }
-                } else {
-                    const float b = a.bias[col0 + nt * 16];
-                    acc[mt][nt] = (f32x4){b, b, b, b};
-                }
-            }
-    }
-    int abase[MT], abase_lo[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int py, px;
-        row_to_patch<MAP>(wv * 32 + mt * 16 + (lane & 15), py, px);
-        abase[mt] = 4 * (py * PW + (MAP == MAP_PARITY ? (px >> 1) + (PW / 2) * (px & 1) : px)) + g;
-        abase_lo[mt] = 4 * (((py >> 1) + (py & 1)) * LW + (px >> 1) + (px & 1)) + g;
-    }
-    const int wcls = MAP == MAP_PARITY ? (wv >> 1) : 0;
-    int inflight = 0;
-    if (nblk > 1) inflight = issue_block(1, 1);  // younger than everything block 0 waits for
-
-    auto mfma_step = [&](const float (&fa)[MT], const float* wp) {
-        float fb[4];
-        if (NTI == 1) {
-            fb[0] = wp[0];
-        } else {
-            const f32x4 t = *(const f32x4*)wp;
-            fb[0] = t[0]; fb[1] = t[1]; fb[2] = t[2]; fb[3] = t[3];
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
-    };
-
-    __builtin_amdgcn_s_setprio(1);
-    // ---- block 0: 9 taps x 2 k-steps of the 8-wide same-resolution source
-    wait_vm_n(inflight);
-    wg_barrier();
-    {
-        const float* pa = smem;
-        const float* wb = smem + E8_PIECES * 256 + lane * NTI;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
-            const int xo = MAP == MAP_PARITY ? (dx == 1 ? ((wcls & 1) ? 1 - PW / 2 : PW / 2) : (dx >> 1)) : dx;
-            const int toff = 4 * (dy * PW + xo);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                float fa[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) fa[mt] = pa[abase[mt] + toff + kk * 4 * NP16];
-                mfma_step(fa, wb + (tap * 2 + kk) * 64 * NTI);
-            }
-        }
-    }
-    // ---- blocks 1..: 4 collapsed taps x 4 k-steps of 16 channels of the upsampled source
-    if (UPS) {
-#pragma unroll 1
-        for (int b = 1; b < nblk; ++b) {
-            if (b + 1 < nblk) {  // buffer (b+1)&1 was last read by block b-1
-                wg_barrier();
-                inflight = issue_block(b + 1, (b + 1) & 1);
-            } else {
-                inflight = 0;
-            }
-            wait_vm_n(inflight);
-            wg_barrier();
-            const float* pa = smem + (b & 1) * BUFP * 256;
-            const float* wb = pa + U16_PIECES * 256 + lane * NTI;
-#pragma unroll
-            for (int tap = 0; tap < 4; ++tap) {
-                const int toff = 4 * ((tap >> 1) * LW + (tap & 1));
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    float fa[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) fa[mt] = pa[abase_lo[mt] + toff + kk * 4 * NPU16];
-                    mfma_step(fa, wb + ((tap * 4 + wcls) * 4 + kk) * 64 * NTI);
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    if (EPI == EPI_LSTM_PACKED) wg_barrier();  // the staging buffers become the epilogue's scratch
-    conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane, smem);
-}
-
-// Level-0 prediction Ahat_0 = min(relu(conv3x3(r_0)), 1) (prednet.py:268-271) with CIN, COUT <= 4:
-// 81 fmaf per pixel do not need the matrix cores (the MFMA kernel pads K and N to 16 and spends
-// its time in 9 barrier-separated staging steps: 55 us per launch at 512^2 x 4).  One thread per
-// pixel, 18x18 halo tile in LDS, weights by scalar loads.  Same chain as the MFMA kernel and the
-// oracle: acc = bias; for tap (ky, kx) ascending; for ci ascending: acc = fmaf(x, w, acc), where a
-// tap outside the image multiplies a stored zero.
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_conv_small(const ConvArgs a) {
-    __shared__ float tile[PPIX * CIN];
-    const int tid = threadIdx.x;
-    const int ntiles = a.tiles_x * a.tiles_y;
-    const int tileid = blockIdx.x % ntiles, n = blockIdx.x / ntiles;
-    const int ty0 = (tileid / a.tiles_x) * 16, tx0 = (tileid % a.tiles_x) * 16;
-    const float* base = a.src[0].p + (long long)n * a.src[0].nstride;
-    for (int i = tid; i < PPIX * CIN; i += 256) {
-        const int pp = i / CIN, ci = i - pp * CIN;
-        const int yy = ty0 - 1 + pp / PW, xx = tx0 - 1 + pp % PW;
-        tile[i] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? base[((long long)yy * a.W + xx) * CIN + ci] : 0.0f;
-    }
-    __syncthreads();
-    const int py = tid >> 4, px = tid & 15;
-    float acc[COUT];
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = a.bias[co];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const float* x = tile + ((py + tap / 3) * PW + px + tap % 3) * CIN;
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[co] = __builtin_fmaf(x[ci], a.Wp[(tap * 16 + ci) * a.ncols + co], acc[co]);
-    }
-    const int y = ty0 + py, xq = tx0 + px;
-    if (y < a.H && xq < a.W) {
-        float* o = a.out0 + (long long)(a.out_idx ? a.out_idx[n] : n) * a.out0_nstride + ((long long)y * a.W + xq) * COUT;
-#pragma unroll
-        for (int co = 0; co < COUT; ++co) {
-            float v = tz_relu(acc[co]);
-            if (a.clip1 && v > 1.0f) v = 1.0f;
-            o[co] = v;
-        }
-    }
-}
-
-// level-0 error unit (prednet.py:274-277 with a = input frame, Ahat = Ahat_0(t0)):
-// input is either a key frame (uint8, unpadded; x = float32(k)/255, compress.py:138) or a
-// padded float32 frame of the prediction stack (compress.py:222).
-__global__ __launch_bounds__(256) void k_err0(const uint8_t* __restrict__ frames_u8, int H, int W,
-                                              const float* __restrict__ in_stack, const int* __restrict__ is_key,
-                                              const int* __restrict__ in_idx, const float* __restrict__ ahat0, int Hp,
-                                              int Wp, int C, int Cs, float* __restrict__ e0) {
-    int n = blockIdx.y;
-    long long npx = (long long)Hp * Wp;
-    const bool key = is_key[n] != 0;
-    const long long fi = in_idx[n];
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (long long)gridDim.x * blockDim.x) {
-        int y = (int)(p / Wp), x = (int)(p - (long long)y * Wp);
-        float* o = e0 + ((long long)n * npx + p) * Cs;
-        if (C == 3 && Cs == 8) {  // RGB frames (compress.py:114): one pixel = two 16-byte stores
-            float av[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                if (key) av[c] = (y < H && x < W) ? (float)frames_u8[(fi * H * W + (long long)y * W + x) * 3 + c] / 255.0f : 0.0f;
-                else av[c] = in_stack[(fi * npx + p) * 3 + c];
-            }
-            float d1[3], d2[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float h = ahat0[p * 3 + c];
-                d1[c] = h - av[c];
-                d2[c] = av[c] - h;
-            }
-            *(float4*)o = make_float4(tz_relu(d1[0]), tz_relu(d1[1]), tz_relu(d1[2]), tz_relu(d2[0]));
-            *(float4*)(o + 4) = make_float4(tz_relu(d2[1]), tz_relu(d2[2]), 0.0f, 0.0f);
-            continue;
-        }
-        for (int c = 0; c < C; ++c) {
-            float av;
-            if (key) {
-                av = 0.0f;
-                if (y < H && x < W) av = (float)frames_u8[(fi * H * W + (long long)y * W + x) * C + c] / 255.0f;
-            } else {
-                av = in_stack[(fi * npx + p) * C + c];
-            }
-            float h = ahat0[p * C + c];
-            float d1 = h - av, d2 = av - h;
-            o[c] = tz_relu(d1);
-            o[C + c] = tz_relu(d2);
-        }
-        for (int c = 2 * C; c < Cs; ++c) o[c] = 0.0f;  // stride padding reads as zero channels
-    }
-}
+#include "tz_conv_kernels.hip.h"
 
 // ------------------------------------------------------------------------------- host side
 struct Seg {
