@@ -42,6 +42,8 @@ struct ConvArgs {
     int ncols;
     const float* bias;  // [ncols]
     const float* init;  // [H*W][ncols] accumulator start (G0), or null -> bias
+    const float* initf; // the same values in accumulator-fragment order (k_to_fragments), or null
+    const float* auxf;  // EPI_LSTM: `aux` in fragment order, or null
     int Cout;
     const float* aux;   // LSTM: previous cell state [H*W][R] or null; POOL_ERR: Ahat(t0) of level l+1
     float* out0;
@@ -167,8 +169,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
                 out_pix(mt, r, y, x);
                 ok[mt][r] = y < a.H && x < a.W;
                 pix[mt][r] = ok[mt][r] ? (long long)y * a.W + x : 0;
-                cp[mt][r] = a.aux ? a.aux[pix[mt][r] * R + ch] : 0.0f;
+                if (!a.auxf) cp[mt][r] = a.aux ? a.aux[pix[mt][r] * R + ch] : 0.0f;
             }
+        if (a.auxf) {
+            const int tile = (ty0 >> 4) * a.tiles_x + (tx0 >> 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 t = *(const f32x4*)(a.auxf + ((((long long)tile * a.ncb + cb) * 8 + wv) * MT + mt) * 256 + lane * 4);
+                cp[mt][0] = t[0]; cp[mt][1] = t[1]; cp[mt][2] = t[2]; cp[mt][3] = t[3];
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -638,7 +648,11 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if (a.init) {
+                if (a.initf) {
+                    // one coalesced 16-byte load per tile (1 KB per wave-instruction) instead of four
+                    // 64-byte segments per element: the prologue's G0 read was 20+ us under load
+                    acc[mt][nt] = *(const f32x4*)(a.initf + (((((long long)tile * a.ncb + cb) * 8 + wv) * MT + mt) * NT + nt) * 256 + lane * 4);
+                } else if (a.init) {
                     // (clamped address instead of a bounds branch: rows outside the image are never stored)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -840,7 +854,9 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16b(const ConvArgs a) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if (a.init) {
+                if (a.initf) {
+                    acc[mt][nt] = *(const f32x4*)(a.initf + (((((long long)tile * a.ncb + cb) * 8 + wv) * MT + mt) * NT + nt) * 256 + lane * 4);
+                } else if (a.init) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         int py, px;
@@ -975,6 +991,29 @@ __global__ __launch_bounds__(256) void k_conv_small(const ConvArgs a) {
             if (a.clip1 && v > 1.0f) v = 1.0f;
             o[co] = v;
         }
+    }
+}
+
+// Prepare-time re-layout of a per-pixel constant image src[H*W][ncols] (G0 accumulator starts,
+// previous cell state) into the accumulator-fragment order of the MFMA kernels:
+// dst[tile][cb][wave][mt][nt][lane][r] = src[pixel of GEMM row (wave, mt, lane>>4, r)][cb*NT*16 + nt*16 + (lane&15)]
+// (rows outside the image hold 0 and are never stored).
+template <int MAP>
+__global__ __launch_bounds__(256) void k_to_fragments(const float* __restrict__ src, int H, int W, int tiles_x, int tiles_y,
+                                                      int ncols, int ncb, int NT, float* __restrict__ dst) {
+    const long long total = (long long)tiles_x * tiles_y * ncb * 8 * MT * NT * 256;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        long long q = i >> 8;
+        const int nt = (int)(q % NT); q /= NT;
+        const int mt = (int)(q % MT); q /= MT;
+        const int wv = (int)(q & 7); q >>= 3;
+        const int cb = (int)(q % ncb);
+        const int tile = (int)(q / ncb);
+        int py, px;
+        row_to_patch<MAP>(wv * 32 + mt * 16 + (lane >> 4) * 4 + r, py, px);
+        const int y = (tile / tiles_x) * 16 + py, x = (tile % tiles_x) * 16 + px;
+        dst[i] = (y < H && x < W) ? src[((long long)y * W + x) * ncols + cb * NT * 16 + nt * 16 + (lane & 15)] : 0.0f;
     }
 }
 

@@ -47,6 +47,7 @@ struct tz_model {
     int cap = 0;  // windows advanced together (<= maxB, the allocated batch)
     bool prepared = false;
     float *R0[TZ_MAX_LEVELS] = {0}, *C0[TZ_MAX_LEVELS] = {0}, *Ahat0[TZ_MAX_LEVELS] = {0}, *G0[TZ_MAX_LEVELS] = {0};
+    float *G0f[TZ_MAX_LEVELS] = {0}, *C0f[TZ_MAX_LEVELS] = {0};  // G0 / C0 in accumulator-fragment order (k_to_fragments)
     float *E[TZ_MAX_LEVELS] = {0}, *R1[TZ_MAX_LEVELS] = {0};
     PackedConv a_conv[TZ_MAX_LEVELS], gate_t1[TZ_MAX_LEVELS], ahat0_t1;
     float* d_zero = nullptr;  // zero page for LDS-DMA halo pixels
@@ -483,6 +484,23 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         std::vector<Seg> segs = {Seg{m->rstack[l], 2 * m->stack[l], 0}};
         if (l < L - 1) segs.push_back(Seg{m->rstack[l] + 2 * m->stack[l], m->rstack[l + 1], 1});
         TZ_TRY(pack_conv(ctx, m, segs, cols, NT, &m->gate_t1[l]));
+        // fragment-order copies for the LDS-DMA kernels' prologue / epilogue (row map of the t=1 launch)
+        {
+            const int tx = (wl(l) + 15) / 16, ty = (hl(l) + 15) / 16, ncb = pg.ncols / (16 * NT);
+            const bool parity = l < L - 1;  // an upsampled source => parity tiles
+            const size_t nf = (size_t)tx * ty * ncb * 8 * 2 * NT * 256;
+            TZ_TRY(dmalloc(ctx, m, (void**)&m->G0f[l], nf * 4));
+            if (parity) hipLaunchKernelGGL(k_to_fragments<MAP_PARITY>, dim3(1024), dim3(256), 0, ctx->stream, m->G0[l], hl(l), wl(l), tx, ty, pg.ncols, ncb, NT, m->G0f[l]);
+            else hipLaunchKernelGGL(k_to_fragments<MAP_LINEAR>, dim3(1024), dim3(256), 0, ctx->stream, m->G0[l], hl(l), wl(l), tx, ty, pg.ncols, ncb, NT, m->G0f[l]);
+            TZ_HIP(ctx, hipGetLastError());
+            if (NT == 4) {  // EPI_LSTM reads c_prev per (row, channel of the column block): ncols = R, 16 per block
+                const size_t nc = (size_t)tx * ty * ncb * 8 * 2 * 256;
+                TZ_TRY(dmalloc(ctx, m, (void**)&m->C0f[l], nc * 4));
+                if (parity) hipLaunchKernelGGL(k_to_fragments<MAP_PARITY>, dim3(1024), dim3(256), 0, ctx->stream, m->C0[l], hl(l), wl(l), tx, ty, m->rstack[l], ncb, 1, m->C0f[l]);
+                else hipLaunchKernelGGL(k_to_fragments<MAP_LINEAR>, dim3(1024), dim3(256), 0, ctx->stream, m->C0[l], hl(l), wl(l), tx, ty, m->rstack[l], ncb, 1, m->C0f[l]);
+                TZ_HIP(ctx, hipGetLastError());
+            }
+        }
     }
     // ---- A convs (prednet.py:290)
     for (int l = 0; l < L - 1; ++l) {
@@ -572,9 +590,11 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         fill_srcs(a, pc, ptrs, ns, ec);
         set_geom(a, hl(l), wl(l));
         a.init = m->G0[l];
+        a.initf = m->G0f[l];
         a.Cout = m->rstack[l];
         a.R = m->rstack[l];
         a.aux = m->C0[l];
+        a.auxf = m->C0f[l];
         a.out0 = m->R1[l];
         a.out0_nstride = npx(l) * m->rstack[l];
         TZ_TRY(launch_conv(ctx, pc.NT, pc.NT == 4 ? EPI_LSTM : EPI_LSTM_PACKED, a, n));

@@ -58,7 +58,9 @@ def _lib():
             ["libzstd.so.1", "libzstd.so", "/opt/conda/lib/libzstd.so.1", "/opt/conda/lib/libzstd.so"]
         for name in names:
             try:
-                L = C.CDLL(name)
+                # RTLD_DEEPBIND: a second libzstd may already be in the process (rocprofv3, other
+                # extensions); without it this library's internal calls bind to THAT one's symbols
+                L = C.CDLL(name, mode=os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0))
                 _bind(L)
             except (OSError, AttributeError) as e:
                 last = e
