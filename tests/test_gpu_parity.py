@@ -168,6 +168,38 @@ def test_prednet_bit_exact_vs_canonical_oracle(ctx, cfg, hp, wp, bias):
     np.testing.assert_array_equal(again[0], net.next(got[0]))
 
 
+SHAPES = [
+    # (stack_sizes, R_stack_sizes, hp, wp): which convolution kernels the predictor dispatches to
+    ((3, 16), None, 24, 40),                      # 2 levels: k_conv16b (A_0 NT=1, gates), k_conv16 top gates with one 16-block
+    ((3, 32, 64), (3, 48, 32), 40, 56),           # R != stack: NT=3 gate columns blocks, 32/48-channel sources (2-3 blocks)
+    ((3, 64, 16), (4, 16, 64), 32, 48),           # R_0 = 4 packed gates, NT=4 A_0 (64 columns), 16-column top level
+    ((3,), (3,), 16, 24),                         # single level: no upsampled source anywhere
+    ((3, 48, 96, 192), (16, 48, 96, 192), 32, 32),  # R_0 = 16: level-0 gates with a 6-channel source on the general kernel
+]
+
+
+@pytest.mark.parametrize("stack,rstack,hp,wp", SHAPES)
+def test_prednet_other_model_shapes_bit_exact(ctx, stack, rstack, hp, wp):
+    """Every dispatch path of the convolution kernels (k_conv16 / k_conv16b / k_conv_small and the
+    general k_conv3x3) against the canonical C oracle, and against each other."""
+    cfg = PredNetConfig(stack_sizes=stack, R_stack_sizes=rstack)
+    rng = np.random.default_rng(21)
+    w = cfg.init_weights(seed=13, bias_scale=0.25)
+    net = coracle.CPredNet(w, cfg.stack_sizes, cfg.R_stack_sizes, hp, wp)
+    ctx.load_model(cfg, w)
+    ctx.prepare(hp, wp, max_batch=3)
+    np.testing.assert_array_equal(ctx.predict_c0(), net.c0())
+    frames = rng.integers(0, 256, (4, hp, wp, 3)).astype(np.float32) / np.float32(255)
+    outs = []
+    for impl in (1, 0):
+        ctx.set_conv_impl(impl)
+        outs.append(ctx.predict_next(frames))
+    ctx.set_conv_impl(1)
+    np.testing.assert_array_equal(outs[0], outs[1])
+    for i in range(4):
+        np.testing.assert_array_equal(outs[0][i], net.next(frames[i]), err_msg="frame %d" % i)
+
+
 def test_prednet_matches_independent_numpy_restatement(ctx):
     from oracle import prednet_np
     cfg, hp, wp = SMALL, 16, 24
