@@ -220,10 +220,12 @@ tz_prof_scope::~tz_prof_scope() {
     if (!a || !b) return;
     (void)hipEventRecord(b, ctx->stream);
     ctx->prof[cls].pending.push_back({a, b});
+    ctx->prof[cls].pending_sub.push_back(sub);
 }
 
 static const char* kProfNames[TZP_COUNT] = {"conv3x3_mfma", "err0", "delta", "quant", "spatial_delta_hist",
-                                            "lut_remap", "undelta_scan", "reconstruct", "sse"};
+                                            "lut_remap", "undelta_scan", "reconstruct", "sse",
+                                            "conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general"};
 
 extern "C" int tz_prof_enable(tz_ctx* ctx, int on) {
     if (!ctx) return TZ_ERR_INVALID;
@@ -236,16 +238,23 @@ extern "C" const char* tz_prof_name(int i) { return (i >= 0 && i < TZP_COUNT) ? 
 static int prof_drain(tz_ctx* ctx) {
     TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& s : ctx->prof) {
-        for (auto& e : s.pending) {
+        for (size_t k = 0; k < s.pending.size(); ++k) {
+            auto& e = s.pending[k];
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
                 s.total_ms += ms;
                 s.launches += 1;
+                const int sub = s.pending_sub[k];
+                if (sub >= 0 && sub < TZP_COUNT) {
+                    ctx->prof[sub].total_ms += ms;
+                    ctx->prof[sub].launches += 1;
+                }
             }
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
         }
         s.pending.clear();
+        s.pending_sub.clear();
     }
     return TZ_OK;
 }

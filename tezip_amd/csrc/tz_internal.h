@@ -22,6 +22,11 @@ enum tz_prof_class {
     TZP_SCAN,       // inverse spatial delta (prefix scan)
     TZP_RECON,      // reconstruct
     TZP_SSE,        // window MSE partial sums
+    // sub-classes of TZP_CONV (a launch is counted in TZP_CONV and in exactly one of these)
+    TZP_CONV16,     // k_conv16: LDS-DMA kernel, sources with a multiple of 16 channels (levels >= 1)
+    TZP_CONV16B,    // k_conv16b: level-0 block-step kernel
+    TZP_CONV_SMALL, // k_conv_small: direct VALU 3 -> 3 convolution
+    TZP_CONV_GEN,   // k_conv3x3: general kernel
     TZP_COUNT
 };
 
@@ -31,6 +36,7 @@ struct tz_prof_slot {
     double total_ms = 0;
     long long launches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<int> pending_sub;  // parallel to `pending`: second class of the interval or -1
 };
 
 struct tz_ctx {
@@ -105,6 +111,7 @@ int tz_dev_out_finish(tz_ctx* ctx, std::vector<tz_out>& outs);  // D2H copies + 
 struct tz_prof_scope {
     tz_ctx* ctx;
     int cls;
+    int sub = -1;  // optional second class the same interval is added to (set before the scope ends)
     hipEvent_t a = nullptr, b = nullptr;
     tz_prof_scope(tz_ctx* c, int k);
     ~tz_prof_scope();

@@ -262,7 +262,9 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         ups = ups || a.src[s].up;
         fullk = fullk && (a.src[s].C % 16) == 0;
     }
+    ps.sub = TZP_CONV_GEN;
     if (epi == EPI_RELU && a.nsrc == 1 && !ups && a.src[0].C == 3 && a.Cout == 3 && ctx->conv_impl) {
+        ps.sub = TZP_CONV_SMALL;
         hipLaunchKernelGGL((k_conv_small<3, 3>), dim3(a.tiles_x * a.tiles_y * nbatch), dim3(256), 0, ctx->stream, a);
         TZ_HIP(ctx, hipGetLastError());
         return TZ_OK;
@@ -271,6 +273,7 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         const int blocks = a.ncb * a.tiles_x * a.tiles_y * nbatch;
 #define TZ_CASE16B(nt, e, u)                                                                                    \
     if (NT == nt && epi == e && ups == u) {                                                                     \
+        ps.sub = TZP_CONV16B;                                                                                   \
         hipLaunchKernelGGL((k_conv16b<nt, e, u>), dim3(blocks), dim3(NTHR), 0, ctx->stream, a);                 \
         TZ_HIP(ctx, hipGetLastError());                                                                         \
         return TZ_OK;                                                                                           \
@@ -282,6 +285,7 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
     if (a.Wimg && a.nsrc > 0 && fullk && ctx->conv_impl) {
 #define TZ_CASE16(nt, e, u)                          \
     if (NT == nt && epi == e && ups == u) {          \
+        ps.sub = TZP_CONV16;                         \
         launch_conv16_t<nt, e, u>(ctx, a, nbatch);   \
         TZ_HIP(ctx, hipGetLastError());              \
         return TZ_OK;                                \
