@@ -797,6 +797,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16b(const ConvArgs a) {
     constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
     constexpr int NTI = C16b<NT>::NTI, W8 = C16b<NT>::W8, WU = C16b<NT>::WU, BUFP = C16b<NT>::bufp(UPS);
     constexpr int NBUF = UPS ? 2 : 1;
+    static_assert((U16_PIECES + WU + 7) / 8 <= 9 && (E8_PIECES + W8 + 7) / 8 <= 9, "wait_vm_n covers at most 9 DMAs per wave in flight");
     constexpr int SCRATCH = EPI == EPI_LSTM_PACKED ? 8 * 32 * 17 : 0;  // epilogue scratch (re-uses the buffers)
     __shared__ __attribute__((aligned(16))) float smem[NBUF * BUFP * 256 > SCRATCH ? NBUF * BUFP * 256 : SCRATCH];
 
