@@ -282,38 +282,60 @@ __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ or
                 sl.heads[lane] = M;
             }
         } else if (wv == 0 && r > 0) {
+            // The walk over the chunks is the serial critical path of the whole kernel (the workers
+            // run 15 chunks in parallel, this wave one after the other), so nothing that does not
+            // depend on the carried (u, l) may sit on it: every LDS operand of chunk w+1 is loaded
+            // while chunk w resolves, and the lookups at the wave-uniform positions j0 / last are
+            // register reads (v_readlane), not LDS permutes.
+            struct Pre {
+                double pu, pl, cu, cl;
+                unsigned long long hd;
+                int nx;
+            };
+            auto load = [&](int w) {
+                const QSlot& sl = slots[(r - 1) & 1][w];
+                return Pre{sl.pu[lane], sl.pl[lane], sl.cu[lane], sl.cl[lane], sl.heads[lane], sl.nxt[lane]};
+            };
+            auto rl_d = [](double v, int src) {  // src is wave-uniform
+                const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+                return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            };
+            Pre cur = load(0), nx = cur;
             for (int w = 0; w < QW; ++w) {
                 const int ch = (r - 1) * QW + w;
                 if (ch >= nch) break;
-                const QSlot& sl = slots[(r - 1) & 1][w];
-                const double pu = sl.pu[lane], pl = sl.pl[lane];
+                if (w + 1 < QW && ch + 1 < nch) nx = load(w + 1);
                 // 4. where does the carried run break?
-                double eu = u < pu ? u : pu, el = l > pl ? l : pl;
-                unsigned long long brk = __ballot(eu - el < 0.0);
+                const double eu = u < cur.pu ? u : cur.pu, el = l > cur.pl ? l : cur.pl;
+                const unsigned long long brk = __ballot(eu - el < 0.0);
                 if (brk == 0ull) {
-                    u = shfl_d(eu, 63);
-                    l = shfl_d(el, 63);
+                    u = rl_d(eu, 63);
+                    l = rl_d(el, 63);
+                    cur = nx;
                     continue;
                 }
                 const int j0 = __ffsll((long long)brk) - 1;
                 {
                     double uc = u, lc = l;
                     if (j0 > 0) {
-                        uc = shfl_d(eu, j0 - 1);
-                        lc = shfl_d(el, j0 - 1);
+                        uc = rl_d(eu, j0 - 1);
+                        lc = rl_d(el, j0 - 1);
                     }
                     if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
                 }
-                const int nxt = sl.nxt[lane];
-                const unsigned long long heads = sl.heads[j0];
+                const unsigned long long heads =
+                    ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cur.hd >> 32), j0) << 32) |
+                    (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cur.hd, j0);
                 const int last = 63 - __clzll((long long)heads);
                 // 5. closed runs store their value at their head; the last head carries on
-                const double cu = sl.cu[lane], cl = sl.cl[lane];
-                if (((heads >> lane) & 1ull) && nxt < 64)
-                    t[(size_t)(ch * 64 + lane) * 3 + c] = (int16_t)(long long)((cu + cl) / 2);
-                u = shfl_d(cu, last);
-                l = shfl_d(cl, last);
+                if (((heads >> lane) & 1ull) && cur.nx < 64)
+                    t[(size_t)(ch * 64 + lane) * 3 + c] = (int16_t)(long long)((cur.cu + cur.cl) / 2);
+                u = rl_d(cur.cu, last);
+                l = rl_d(cur.cl, last);
                 chead = ch * 64 + last;
+                cur = nx;
             }
         }
         __syncthreads();
