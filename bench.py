@@ -107,12 +107,18 @@ def conv16_flops_per_px0(cfg):
 
 
 def main():
+    global NT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames", type=int, default=NT,
+                    help="frames per sequence (default 80 = the BASELINE.json configuration; other values are "
+                         "exploration only and are labelled as such in config.workload)")
     args = ap.parse_args()
+    explore = args.frames != NT
+    NT = args.frames
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,8 +242,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "512x512x3 synthetic turbulence stack, nt=80, SWP 20-frame windows, warm_up 0, "
-                                   "lossy rel 1e-3, entropy remap on; PredNet (3,48,96,192) glorot seed 123",
+            "config": {"workload": ("512x512x3 synthetic turbulence stack, nt=%d, SWP 20-frame windows, warm_up 0, "
+                                    "lossy rel 1e-3, entropy remap on; PredNet (3,48,96,192) glorot seed 123" % NT)
+                       + (" [EXPLORATION: not the BASELINE.json sequence length]" if explore else ""),
                        "frames_per_step": NT, "predicted_frames_per_step": n_pred, "sharding": "one sequence per GPU"},
             "compression_ratio": ratio,
             "pcie_inclusive_frames_per_s_rank0": pcie_fps,
