@@ -289,6 +289,87 @@ __global__ __launch_bounds__(512, 6) void k4(float* out, unsigned long long* sta
     }
 }
 
+// Variant: weights two steps ahead in THREE buffers with compile-time buffer indices (tap (dy,dx) lives
+// in buffer dx; the dx loop is unrolled), quad-planar A addressing, double-buffered 20.5-piece patches.
+// Waves 0-3 issue on even global steps, 4-7 on odd ones; a wave waits only for a piece it issued a
+// whole step earlier.  LDS 53 KB.
+__global__ __launch_bounds__(512, 6) void k6(float* out, unsigned long long* stamps, int nblk, const float* act, const float* wimg,
+                                             int W, int C) {
+    __shared__ __attribute__((aligned(16))) float smem[53 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4;
+    const int tile = blockIdx.x % 256, cb = blockIdx.x / 256 % 3;
+    const int ty0 = (tile / 16) * 16, tx0 = (tile % 16) * 16;
+    for (int i = tid; i < 53 * 256; i += 512) smem[i] = act[i & 4095];
+    __syncthreads();
+    f32x4 acc[2][4];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int abase[2] = {4 * ((2 * wv) * 18 + (lane & 15)) + g, 4 * ((2 * wv + 1) * 18 + (lane & 15)) + g};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int pi = 0, slot0 = 0;
+    const int half = wv >> 2;
+    for (int blk = 0; blk < nblk; ++blk) {
+        {
+            float* dst = smem + (pi ? 0 : 5248);   // 20.5 pieces = 5248 floats
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int piece = wv + 8 * j;
+                if (piece < 21) {
+                    const int i = piece * 64 + lane, q = i / 328, slot = i - q * 328;
+                    const int y = slot / 18, x = slot - y * 18;
+                    const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
+                    const bool ok = i < 1312 && slot < 324 && yy >= 0 && yy < W && xx >= 0 && xx < W;
+                    if (i < 1312) glds16(ok ? act + ((long long)yy * W + xx) * C + (blk % (C / 16)) * 16 + 4 * q : act, dst + piece * 256);
+                }
+            }
+        }
+        const float* pa = smem + (pi ? 5248 : 0);
+#pragma unroll 1
+        for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int sg = slot0 + 3 * dy + dx;   // global step; 9 per block so parity alternates across blocks too
+                if (half == (sg & 1))
+                    glds16(wimg + (((long long)(sg + 2) * 3 + cb) * 4 + (wv & 3)) * 256 + lane * 4,
+                           smem + (41 + 4 * ((dx + 2) % 3) + (wv & 3)) * 256);
+                const float* wb = smem + (41 + 4 * dx) * 256 + lane * 4;
+                const int toff = 4 * (dy * 18 + dx);
+                float fa[2][4];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = pa[abase[mt] + toff + kk * 1312];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const f32x4 fb = *(const f32x4*)(wb + kk * 256);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][kk], fb[nt], acc[mt][nt], 0, 0, 0);
+                }
+                if (half == (sg & 1)) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+        slot0 += 9;
+        pi ^= 1;
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+    if (tid == 0) {
+        stamps[2 * blockIdx.x] = t1 - t0;
+        stamps[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
 static float *g_out, *g_act, *g_w;
 static unsigned long long* g_st;
 typedef void (*kern_t)(float*, unsigned long long*, int, const float*, const float*, int, int);
@@ -341,6 +422,7 @@ int main() {
         run<F_BAR | F_PLANAR | F_WDMA | F_PDMA>("quad-planar patch image (offset-only A addr)", blocks, nblk);
         run<F_BAR | F_PLANAR | F_WDMA | F_PDMA | F_PREF>("quad-planar + fragment prefetch", blocks, nblk);
         run<F_BAR | F_PLANAR | F_WDMA | F_PDMA | F_W3>("quad-planar + weights 2 steps ahead (3 bufs)", blocks, nblk);
+        run<0>("3 weight buffers (compile-time), 2 steps ahead", blocks, nblk, k6);
         run<0>("up phase: 16 KB weights / step (k_conv16)", blocks, nblk, k4<2>);
         run<0>("up phase:  8 KB weights / step", blocks, nblk, k4<1>);
         run<0>("up phase: no weight DMA", blocks, nblk, k4<0>);
