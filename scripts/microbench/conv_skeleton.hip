@@ -370,11 +370,104 @@ __global__ __launch_bounds__(512, 6) void k6(float* out, unsigned long long* sta
     }
 }
 
+// Variant: 4 x 4 MFMA tiles per wave (64 pixels x 64 columns; workgroup = 32x16 pixels), so the B
+// fragments, the weight DMA and the barrier are amortised over 64 MFMAs per wave and step.
+// ~100 VGPRs -> 2 workgroups per CU; single 34x18 patch buffer (39 pieces) + 2 x 4 weight pieces.
+template <int DBUF>
+__global__ __launch_bounds__(512, 4) void k7(float* out, unsigned long long* stamps, int nblk, const float* act, const float* wimg,
+                                             int W, int C) {
+    __shared__ __attribute__((aligned(16))) float smem[(DBUF ? 78 : 39) * 256 + 8 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4;
+    const int tile = blockIdx.x % 128, cb = blockIdx.x / 128 % 3;
+    const int ty0 = (tile / 16) * 32, tx0 = (tile % 16) * 16;
+    for (int i = tid; i < 47 * 256; i += 512) smem[i] = act[i & 4095];
+    __syncthreads();
+    f32x4 acc[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int abase[4];
+    for (int mt = 0; mt < 4; ++mt) abase[mt] = 4 * ((4 * wv + mt) * 18 + (lane & 15)) + g;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int cur = 0, pi = 0, slot0 = 0;
+    constexpr int WOFF = (DBUF ? 78 : 39) * 256;
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (DBUF) {
+            float* dst = smem + (pi ? 0 : 39) * 256;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int piece = wv + 8 * j;
+                if (piece < 39) {
+                    const int i = piece * 64 + lane, q = i / 624, slot = i - q * 624;
+                    const int y = slot / 18, x = slot - y * 18;
+                    const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
+                    const bool ok = slot < 612 && yy >= 0 && yy < W && xx >= 0 && xx < W;
+                    glds16(ok ? act + ((long long)yy * W + xx) * C + (blk % (C / 16)) * 16 + 4 * q : act, dst + piece * 256);
+                }
+            }
+        }
+        const float* pa = smem + (DBUF && pi ? 39 : 0) * 256;
+#pragma unroll 1
+        for (int st = 0; st < 9; ++st) {
+            if ((wv >> 2) == (cur ^ 1))
+                glds16(wimg + (((long long)(slot0 + st + 1) * 3 + cb) * 4 + (wv & 3)) * 256 + lane * 4,
+                       smem + WOFF + (4 * (cur ^ 1) + (wv & 3)) * 256);
+            const float* wb = smem + WOFF + 4 * cur * 256 + lane * 4;
+            const int toff = 4 * ((st / 3) * 18 + st % 3);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const f32x4 fb = *(const f32x4*)(wb + kk * 256);
+                float fa[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) fa[mt] = pa[abase[mt] + toff + kk * 2496];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur ^= 1;
+        }
+        slot0 += 9;
+        pi ^= 1;
+        if (!DBUF) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int piece = wv + 8 * j;
+                if (piece < 39) {
+                    const int i = piece * 64 + lane, q = i / 624, slot = i - q * 624;
+                    const int y = slot / 18, x = slot - y * 18;
+                    const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
+                    const bool ok = slot < 612 && yy >= 0 && yy < W && xx >= 0 && xx < W;
+                    glds16(ok ? act + ((long long)yy * W + xx) * C + (blk % (C / 16)) * 16 + 4 * q : act, smem + piece * 256);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+    if (tid == 0) {
+        stamps[2 * blockIdx.x] = t1 - t0;
+        stamps[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
 static float *g_out, *g_act, *g_w;
 static unsigned long long* g_st;
 typedef void (*kern_t)(float*, unsigned long long*, int, const float*, const float*, int, int);
 template <int F>
-static void run(const char* name, int blocks, int nblk, kern_t kf = nullptr) {
+static void run(const char* name, int blocks, int nblk, kern_t kf = nullptr, double mt_scale = 1.0) {
     if (!kf) kf = k<F>;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
@@ -394,7 +487,7 @@ static void run(const char* name, int blocks, int nblk, kern_t kf = nullptr) {
     double clk = 0;
     for (int i = 0; i < blocks; ++i) clk += (double)h[2 * i] / (double)h[2 * i + 1] * 100.0;
     clk /= blocks;
-    double flops = (double)blocks * 8 * nblk * 9 * 32.0 * 2048.0;
+    double flops = (double)blocks * 8 * nblk * 9 * 32.0 * 2048.0 * mt_scale;
     printf("%-44s %7.3f ms  %6.1f TFLOP/s  clock %.0f MHz  pipe busy %.1f %%\n", name, ms, flops / (ms * 1e-3) / 1e12, clk,
            100.0 * (flops / (ms * 1e-3)) / (256.0 * 4 * 64 * clk * 1e6));
     free(h);
@@ -423,6 +516,8 @@ int main() {
         run<F_BAR | F_PLANAR | F_WDMA | F_PDMA | F_PREF>("quad-planar + fragment prefetch", blocks, nblk);
         run<F_BAR | F_PLANAR | F_WDMA | F_PDMA | F_W3>("quad-planar + weights 2 steps ahead (3 bufs)", blocks, nblk);
         run<0>("3 weight buffers (compile-time), 2 steps ahead", blocks, nblk, k6);
+        run<0>("4x4 tiles per wave, 2 WG/CU, single patch buf", blocks / 2, nblk, k7<0>, 2.0);
+        run<0>("4x4 tiles per wave, 1 WG/CU, double patch buf", blocks / 2, nblk, k7<1>, 2.0);
         run<0>("up phase: 16 KB weights / step (k_conv16)", blocks, nblk, k4<2>);
         run<0>("up phase:  8 KB weights / step", blocks, nblk, k4<1>);
         run<0>("up phase: no weight DMA", blocks, nblk, k4<0>);
