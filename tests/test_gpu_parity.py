@@ -175,6 +175,8 @@ SHAPES = [
     ((3, 64, 16), (4, 16, 64), 32, 48),           # R_0 = 4 packed gates, NT=4 A_0 (64 columns), 16-column top level
     ((3,), (3,), 16, 24),                         # single level: no upsampled source anywhere
     ((3, 48, 96, 192), (16, 48, 96, 192), 32, 32),  # R_0 = 16: level-0 gates with a 6-channel source on the general kernel
+    ((3, 48, 96, 192), None, 8, 8),               # the smallest legal frame: the top level is one pixel, every tile mostly halo
+    ((3, 48, 96, 192), None, 8, 40),              # one-tile-high strip
 ]
 
 
