@@ -463,6 +463,79 @@ __global__ __launch_bounds__(512, 4) void k7(float* out, unsigned long long* sta
     }
 }
 
+// Variant: the k_conv16 K loop at 4 workgroups per CU (8 waves/SIMD): <= 64 VGPRs, single patch
+// buffer (21 + 8 = 29 pieces), patch refilled between blocks behind one extra barrier.
+__global__ __launch_bounds__(512, 8) void k8(float* out, unsigned long long* stamps, int nblk, const float* act, const float* wimg,
+                                             int W, int C) {
+    __shared__ __attribute__((aligned(16))) float smem[29 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4;
+    const int tile = blockIdx.x % 256, cb = blockIdx.x / 256 % 3;
+    const int ty0 = (tile / 16) * 16, tx0 = (tile % 16) * 16;
+    for (int i = tid; i < 29 * 256; i += 512) smem[i] = act[i & 4095];
+    __syncthreads();
+    f32x4 acc[2][4];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int abase[2] = {4 * ((2 * wv) * 18 + (lane & 15)) + g, 4 * ((2 * wv + 1) * 18 + (lane & 15)) + g};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int cur = 0, slot0 = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll 1
+        for (int st = 0; st < 9; ++st) {
+            if ((wv >> 2) == (cur ^ 1))
+                glds16(wimg + (((long long)(slot0 + st + 1) * 3 + cb) * 4 + (wv & 3)) * 256 + lane * 4,
+                       smem + (21 + 4 * (cur ^ 1) + (wv & 3)) * 256);
+            const float* wb = smem + (21 + 4 * cur) * 256 + lane * 4;
+            const int toff = 4 * ((st / 3) * 18 + st % 3);
+            float fa[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) fa[mt][kk] = smem[abase[mt] + toff + kk * 1344];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const f32x4 fb = *(const f32x4*)(wb + kk * 256);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][kk], fb[nt], acc[mt][nt], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur ^= 1;
+        }
+        slot0 += 9;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int piece = wv + 8 * j;
+            if (piece < 21) {
+                const int i = piece * 64 + lane, q = i / 336, slot = i - q * 336;
+                const int y = slot / 18, x = slot - y * 18;
+                const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
+                const bool ok = slot < 324 && yy >= 0 && yy < W && xx >= 0 && xx < W;
+                glds16(ok ? act + ((long long)yy * W + xx) * C + (blk % (C / 16)) * 16 + 4 * q : act, smem + piece * 256);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+    if (tid == 0) {
+        stamps[2 * blockIdx.x] = t1 - t0;
+        stamps[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
 static float *g_out, *g_act, *g_w;
 static unsigned long long* g_st;
 typedef void (*kern_t)(float*, unsigned long long*, int, const float*, const float*, int, int);
@@ -516,6 +589,7 @@ int main() {
         run<F_BAR | F_PLANAR | F_WDMA | F_PDMA | F_PREF>("quad-planar + fragment prefetch", blocks, nblk);
         run<F_BAR | F_PLANAR | F_WDMA | F_PDMA | F_W3>("quad-planar + weights 2 steps ahead (3 bufs)", blocks, nblk);
         run<0>("3 weight buffers (compile-time), 2 steps ahead", blocks, nblk, k6);
+        run<0>("4 WG/CU (<=64 VGPR), single patch buffer", 1024 * 3, nblk, k8);
         run<0>("4x4 tiles per wave, 2 WG/CU, single patch buf", blocks / 2, nblk, k7<0>, 2.0);
         run<0>("4x4 tiles per wave, 1 WG/CU, double patch buf", blocks / 2, nblk, k7<1>, 2.0);
         run<0>("up phase: 16 KB weights / step (k_conv16)", blocks, nblk, k4<2>);
