@@ -3,21 +3,35 @@
 
 metric : frames/sec (predict + delta-encode, whole job over all ranks), 512x512x3 sequences
 step   : one pass of the hot path over one synthetic sequence that is already resident in HBM:
-         tz_rollout (PredNet rollout, SWP) + tz_encode (delta, error-bound quantise, spatial
-         delta, histogram, rank table, remap) -> int16 payload in HBM + rank table on host.
-workload (BASELINE.json configs[2]): 512x512x3 synthetic turbulence stack, nt=80, 20-frame
-         windows, lossy `rel 1e-3`, synthetic glorot weights (seed 123) of the reference model.
-N>1    : one process per GPU (torch.distributed/RCCL only for the barrier and the max over
-         ranks); every rank compresses its own sequence (windows shard with no data-path
-         collective) => weak scaling.
+         PredNet rollout (SWP) + delta, error-bound quantise, spatial delta, histogram, rank
+         table, remap -> int16 payload in (rank 0's) HBM + rank table on the host.
+workload (BASELINE.json configs[2]): 512x512x3 synthetic turbulence stack, 80 frames per GPU,
+         20-frame windows, lossy `rel 1e-3`, synthetic glorot weights (seed 123) of the reference
+         model.
+N>1    : one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (a
+         torch.distributed.run child, before anything touches the GPU); under torchrun
+         (WORLD_SIZE set) it is one of the ranks.  The job is ONE sequence of 80*N frames whose
+         windows are sharded over the ranks (tezip_amd/dist.py: no data-path collective; one small
+         all_gather for the shard-boundary carries, an all-reduce of 2111 histogram counters, and
+         the payload shards sent point to point to rank 0) => weak scaling, 4 windows per GPU.
+         The sharded result is checked byte-identical to a single-GPU run of the same sequence
+         (untimed).  `--mode replicas` (every rank its own 80-frame sequence, nothing exchanged)
+         is kept and is reported as an extra key of the same line.
 
 Extra objects on the JSON line: "roofline" (dominant kernel = MFMA convolution),
 "roofline_delta" (the HBM-bound delta kernel named by the north star), "cpu_baseline"
-(the C oracle = a port of the same path, timed on this box's host cores, rank 0, N=1 only).
+(the C oracle = a port of the same path, timed on this box's host cores, rank 0, N=1 only),
+"host_to_host" (SURVEY.md §8d's wall-clock definition: uint8 stack in host memory -> int16
+payload + table in host memory, PCIe included, pinned and pageable buffers), "lossy_abs2" (the
+same step with `abs 2`, real merges in the quantiser), "cfg4_sharded" (BASELINE configs[3]:
+ONE 320-frame 1024x1024 sequence, 40-frame windows, `abs 2`, windows sharded over the ranks:
+strong scaling).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,7 +42,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 H = W = 512
-NT = 80
+NT = 80            # frames per GPU
 WINDOW = 20
 WARM_UP = 0
 MODE, BOUND = "rel", [1e-3]
@@ -36,13 +50,13 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
 
 
-def turbulence_cuda(nt, h, w, seed, device):
+# ------------------------------------------------------------------------------ synthetic data
+def _turb_terms(h, w, seed, device):
     """Same construction as tezip_amd.synth.turbulence, evaluated on the GPU."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     yy, xx = torch.meshgrid(torch.arange(h, device=device, dtype=torch.float32),
                             torch.arange(w, device=device, dtype=torch.float32), indexing="ij")
-    ts = torch.arange(nt, device=device, dtype=torch.float32)
-    out = torch.zeros((nt, h, w, 3), device=device, dtype=torch.float32)
+    terms = []
     for c in range(3):
         for o in range(6):
             r = torch.rand(4, generator=g).tolist()
@@ -50,14 +64,63 @@ def turbulence_cuda(nt, h, w, seed, device):
             th, ph = r[0] * 2 * np.pi, r[1] * 2 * np.pi
             vx, vy = r[2] * 3 - 1.5, r[3] * 3 - 1.5
             kx, ky = f * np.cos(th), f * np.sin(th)
-            amp = 1.0 / (1.5 ** o)
-            base = kx * xx + ky * yy + ph
-            om = (kx * vx + ky * vy) * ts
-            out[..., c] += amp * torch.sin(base[None] - om[:, None, None])
-    out = (out - out.min()) / (out.max() - out.min()) * 255
-    return out.round().clamp(0, 255).to(torch.uint8).contiguous()
+            terms.append((c, 1.0 / (1.5 ** o), kx * xx + ky * yy + ph, kx * vx + ky * vy))
+    return terms
 
 
+def _turb_raw(terms, t0, t1, h, w, device):
+    ts = torch.arange(t0, t1, device=device, dtype=torch.float32)
+    out = torch.zeros((t1 - t0, h, w, 3), device=device, dtype=torch.float32)
+    for c, amp, base, om in terms:
+        out[..., c] += amp * torch.sin(base[None] - (om * ts)[:, None, None])
+    return out
+
+
+def turbulence_cuda(nt_total, t0, t1, h, w, seed, device):
+    """Frames [t0, t1) of the nt_total-frame turbulence sequence (normalised over the WHOLE
+    sequence, so a shard is exactly a slice of the full stack)."""
+    terms = _turb_terms(h, w, seed, device)
+    lo, hi = float("inf"), float("-inf")
+    for a in range(0, nt_total, 40):
+        raw = _turb_raw(terms, a, min(a + 40, nt_total), h, w, device)
+        lo, hi = min(lo, float(raw.min())), max(hi, float(raw.max()))
+    out = torch.empty((t1 - t0, h, w, 3), dtype=torch.uint8, device=device)
+    for a in range(t0, t1, 40):
+        b = min(a + 40, t1)
+        raw = (_turb_raw(terms, a, b, h, w, device) - lo) / (hi - lo) * 255
+        out[a - t0: b - t0] = raw.round().clamp(0, 255).to(torch.uint8)
+    return out.contiguous()
+
+
+def detector_cuda(t0, t1, h, w, seed, device):
+    """Frames [t0, t1) of a cfg4-style XFEL detector sequence (tezip_amd.synth.detector's
+    construction on the GPU): Poisson background (lambda 3) + 50 slowly drifting Gaussian peaks,
+    grayscale expanded to 3 channels as the reference does (compress.py:114).  Every frame is
+    seeded by its index, so a shard is exactly a slice of the full stack."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    npk = 50
+    pos = torch.rand(npk, 2, generator=g) * torch.tensor([h, w], dtype=torch.float32)
+    vel = torch.randn(npk, 2, generator=g) * 0.3
+    amp = (40 + 180 * torch.rand(npk, generator=g)).to(device)
+    sig = (1.5 + 2.5 * torch.rand(npk, generator=g)).to(device)
+    pos, vel = pos.to(device), vel.to(device)
+    yy, xx = torch.meshgrid(torch.arange(h, device=device, dtype=torch.float32),
+                            torch.arange(w, device=device, dtype=torch.float32), indexing="ij")
+    out = torch.empty((t1 - t0, h, w, 3), dtype=torch.uint8, device=device)
+    gd = torch.Generator(device=device)
+    for t in range(t0, t1):
+        gd.manual_seed(seed * 1000003 + t)
+        img = torch.poisson(torch.full((h, w), 3.0, device=device), generator=gd)
+        p = pos + vel * t
+        for k0 in range(0, npk, 10):
+            k1 = min(k0 + 10, npk)
+            d2 = (yy[None] - p[k0:k1, 0, None, None]) ** 2 + (xx[None] - p[k0:k1, 1, None, None]) ** 2
+            img += (amp[k0:k1, None, None] * torch.exp(-d2 / (2 * sig[k0:k1, None, None] ** 2))).sum(0)
+        out[t - t0] = img.clamp(0, 255).to(torch.uint8)[..., None]
+    return out.contiguous()
+
+
+# ------------------------------------------------------------------------------ accounting
 def measured_traffic(prefix):
     """Per-launch HBM bytes of the kernels whose name starts with `prefix`, from the committed
     rocprofv3 PMC summary of this same bench command (profiles/CURRENT -> traffic.json, made by
@@ -106,29 +169,123 @@ def conv16_flops_per_px0(cfg):
     return 2 * mac
 
 
+# ------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without torchrun: start the N ranks as a torch.distributed.run
+    child.  Nothing in THIS process has touched the GPU (device_count() does not initialise it),
+    and the child is a fresh process, not an exec of this one."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    have = torch.cuda.device_count()
+    if have < n:  # rehearsal on a smaller box: all ranks share GPU 0, gloo carries the exchange
+        print("bench.py: %d GPU(s) visible for --gpus %d: rehearsing with all ranks on GPU 0 over gloo" % (have, n),
+              file=sys.stderr)
+        env["TEZIP_BENCH_SINGLE_DEVICE"] = "1"
+        env.setdefault("TEZIP_BENCH_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------ timing helper
+class Job:
+    def __init__(self, rank, world, dist, dev):
+        self.rank, self.world, self.dist, self.dev = rank, world, dist, dev
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, step, steps, warmup):
+        """W untimed + K timed steps between barrier + synchronize; MAX over ranks (seconds)."""
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.dist:
+            t = torch.tensor([elapsed], dtype=torch.float64,
+                             device=self.dev if self.dist.get_backend() == "nccl" else "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+
+def sharded_step_fn(job, ctx, engine, fetch, nt_total, warm_up, window, mode, bound, state):
+    """One whole-job step: windows sharded over the ranks (rank 0 ends with the payload in HBM)."""
+    from tezip_amd import dist as tzdist
+    if job.world == 1:
+        def step():
+            frames = fetch(0, nt_total)
+            key, _ = ctx.rollout(frames, warm_up, window)
+            _, table, _ = ctx.encode(mode, bound, True, payload=state["payload"])
+            state["key"], state["table"] = key, table
+    else:
+        def step():
+            res = tzdist.compress_sharded(engine, fetch, warm_up, window, mode, bound, True, nt=nt_total, to_host=False)
+            if res is not None:
+                state["payload"], state["table"], state["key"] = res
+    return step
+
+
+def verify_against_one_gpu(ctx, frames_full, warm_up, window, mode, bound, state, max_batch, hp, wp):
+    """Rank 0, untimed: the sharded payload / table / key mask must equal a single-GPU run."""
+    ctx.prepare(hp, wp, max_batch)
+    ref = torch.empty(frames_full.numel(), dtype=torch.int16, device=frames_full.device)
+    key, _ = ctx.rollout(frames_full, warm_up, window)
+    _, table, _ = ctx.encode(mode, bound, True, payload=ref)
+    ctx.synchronize()
+    pl = state["payload"]
+    if isinstance(pl, np.ndarray):  # gloo rehearsal: the gathered payload lives on the host
+        pl = torch.from_numpy(pl).to(ref.device)
+    state = dict(state, payload=pl)
+    ok = bool((key == state["key"]).all()) and len(table) == len(state["table"]) and bool((table == state["table"]).all()) \
+        and bool(torch.equal(ref, state["payload"]))
+    return "byte-identical to the 1-GPU result" if ok else "MISMATCH vs the 1-GPU result"
+
+
 def main():
-    global NT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded",
+                    help="N>1: shard the windows of ONE 80*N-frame sequence (default) or one 80-frame sequence per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip host_to_host / lossy_abs2 / cfg4_sharded / the other mode")
     ap.add_argument("--frames", type=int, default=NT,
-                    help="frames per sequence (default 80 = the BASELINE.json configuration; other values are "
+                    help="frames per GPU (default 80 = the BASELINE.json configuration; other values are "
                          "exploration only and are labelled as such in config.workload)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     explore = args.frames != NT
-    NT = args.frames
+    nt_rank = args.frames
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback)")
-    if os.environ.get("TEZIP_BENCH_SINGLE_DEVICE"):  # rehearsal of N>1 on a one-GPU box
+    single_dev = bool(os.environ.get("TEZIP_BENCH_SINGLE_DEVICE"))  # rehearsal of N>1 on a one-GPU box
+    if single_dev:
         local = 0
     torch.cuda.set_device(local)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("TEZIP_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
@@ -140,51 +297,67 @@ def main():
     from tezip_amd import _lib, build
     if not os.path.exists(_lib.LIB_PATH):
         build.build()
+    from tezip_amd import dist as tzdist
     from tezip_amd.prednet import PredNetConfig
 
     dev = torch.device("cuda", local)
+    job = Job(rank, world, dist, dev)
     ctx = _lib.Context(local, stream=torch.cuda.current_stream().cuda_stream)
+    engine = tzdist.HipEngine(ctx, local)
     cfg = PredNetConfig()
     ctx.load_model(cfg, cfg.init_weights(seed=123))
-    nwin = (NT - WARM_UP + WINDOW - 1) // WINDOW
+    nwin = (nt_rank - WARM_UP + WINDOW - 1) // WINDOW
     ctx.prepare(H, W, max_batch=nwin)
-    frames = turbulence_cuda(NT, H, W, 3 + rank, dev)
-    payload = torch.empty(NT * H * W * 3, dtype=torch.int16, device=dev)
-    torch.cuda.synchronize()
 
-    state = {}
+    # ---------------------------------------------------------------- primary line (cfg3)
+    sharded = args.mode == "sharded"
+    nt_total = nt_rank * world if sharded else nt_rank
+    if sharded:
+        f0, f1 = tzdist.plan_shards(nt_total, WARM_UP, WINDOW, world)[rank] if world > 1 else (0, nt_total)
+        frames = turbulence_cuda(nt_total, f0, f1, H, W, 3, dev)
+    else:
+        f0, f1 = 0, nt_rank
+        frames = turbulence_cuda(nt_rank, 0, nt_rank, H, W, 3 + rank, dev)
+    state = {"payload": torch.empty(nt_total * H * W * 3, dtype=torch.int16, device=dev) if world == 1 or not sharded else None}
 
-    def step():
-        key, _ = ctx.rollout(frames, WARM_UP, WINDOW)
-        _, table, _ = ctx.encode(MODE, BOUND, True, payload=payload)
-        state["key"], state["table"] = key, table
+    def fetch(a, b):
+        assert (a, b) == (f0, f1), "a rank only holds its own shard"
+        return frames
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    if sharded:
+        step = sharded_step_fn(job, ctx, engine, fetch, nt_total, WARM_UP, WINDOW, MODE, BOUND, state)
+    else:
+        def step():
+            key, _ = ctx.rollout(frames, WARM_UP, WINDOW)
+            _, table, _ = ctx.encode(MODE, BOUND, True, payload=state["payload"])
+            state["key"], state["table"] = key, table
+    elapsed = job.timed(step, args.steps, args.warmup)
+    total_frames = (nt_total if sharded else nt_rank * world) * args.steps
+    value = total_frames / elapsed
+
+    check = None
+    if sharded and world > 1 and rank == 0:
+        full = turbulence_cuda(nt_total, 0, nt_total, H, W, 3, dev)
+        check = verify_against_one_gpu(ctx, full, WARM_UP, WINDOW, MODE, BOUND, state, nwin * world, H, W)
+        del full
+        ctx.prepare(H, W, max_batch=nwin)
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # ---- per-kernel device time (HIP events on the launch stream), one extra untimed step
+    # ---------------------------------------------------------------- per-kernel device time (rank 0's shard)
+    own_state = {"payload": torch.empty(frames.shape[0] * H * W * 3, dtype=torch.int16, device=dev)}
+
+    def own_step(mode=MODE, bound=BOUND):
+        key, _ = ctx.rollout(frames, WARM_UP if rank == 0 or not sharded else 0, WINDOW)
+        _, table, _ = ctx.encode(mode, bound, True, payload=own_state["payload"])
+        own_state["key"], own_state["table"] = key, table
+
     ctx.prof_enable(True)
     ctx.prof_reset()
-    step()
+    own_step()
     prof = ctx.prof_get()
     ctx.prof_enable(False)
-    n_pred = NT - int(state["key"].sum())
+    n_pred = frames.shape[0] - int(own_state["key"].sum())
     conv_ms, conv_n = prof["conv3x3_mfma"]
     flops_step = live_flops_per_px0(cfg) * H * W * n_pred
     conv_tflops = flops_step / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -194,44 +367,99 @@ def main():
     c16_flops = conv16_flops_per_px0(cfg) * H * W * n_pred
     c16_tflops = c16_flops / (c16_ms * 1e-3) / 1e12 if c16_ms > 0 else 0.0
     delta_ms, delta_n = prof["delta"]
-    delta_bytes = 7.0 * NT * H * W * 3  # f32 pred + u8 orig in, i16 out
+    delta_bytes = 7.0 * frames.shape[0] * H * W * 3  # f32 pred + u8 orig in, i16 out
     delta_gbs = delta_bytes / (delta_ms * 1e-3) / 1e9 if delta_ms > 0 else 0.0
 
-    # ---- host-buffer (PCIe-inclusive) rate of the same step: informational, never `value`
-    host_frames = frames.cpu().numpy()
-    host_payload = np.empty(NT * H * W * 3, np.int16)
-    t1 = time.perf_counter()
-    ctx.rollout(host_frames, WARM_UP, WINDOW)
-    ctx.encode(MODE, BOUND, True, payload=host_payload)
-    pcie_fps = NT / (time.perf_counter() - t1)
-
-    # ---- compression ratio (untimed; same libzstd for both files, level 9 as the reference)
+    extras = {}
     ratio = None
-    if rank == 0:
+    if not args.no_extras:
+        # ------------------------------------------------------------ host -> host (SURVEY.md §8d wall-clock definition)
+        if world == 1:
+            hsteps = max(3, min(args.steps, 10))
+            h2h = {}
+            for kind in ("pinned", "pageable"):
+                if kind == "pinned":
+                    hf = _lib.pinned_copy(frames.cpu().numpy())
+                    hp_ = _lib.pinned_empty(frames.shape[0] * H * W * 3, np.int16)
+                else:
+                    hf = frames.cpu().numpy()
+                    hp_ = np.empty(frames.shape[0] * H * W * 3, np.int16)
+
+                def hstep():
+                    ctx.rollout(hf, WARM_UP, WINDOW)
+                    ctx.encode(MODE, BOUND, True, payload=hp_)
+                el = job.timed(hstep, hsteps, 1)
+                h2h[kind + "_frames_per_s"] = frames.shape[0] * hsteps / el
+                h2h[kind + "_ms_per_step"] = el / hsteps * 1e3
+                same = bool((hp_ == state["payload"].cpu().numpy()).all())
+                h2h[kind + "_payload_equals_device_resident"] = same
+                del hf, hp_
+            h2h["steps"] = hsteps
+            h2h["note"] = ("uint8 stack in host memory -> int16 payload + table in host memory, PCIe both ways inside the "
+                           "timed region; pinned = tz_host_alloc buffers (key frames go first, the rest of the stack and the "
+                           "payload chunks cross PCIe on a copy stream under the kernels), pageable = plain numpy arrays "
+                           "(pipelined through the context's pinned staging buffers)")
+            h2h["fraction_of_device_resident"] = h2h["pinned_frames_per_s"] / value
+            extras["host_to_host"] = h2h
+
+            # -------------------------------------------------------- the lossy path with real merges
+            el = job.timed(lambda: own_step("abs", [2.0]), max(3, min(args.steps, 10)), 1)
+            ctx.prof_enable(True)
+            ctx.prof_reset()
+            own_step("abs", [2.0])
+            q = ctx.prof_get()["quant"]
+            ctx.prof_enable(False)
+            extras["lossy_abs2"] = {"frames_per_s": frames.shape[0] * max(3, min(args.steps, 10)) / el,
+                                    "quantiser_ms_per_step": q[0], "table_symbols": len(own_state["table"])}
+            own_step()
+
+        # ------------------------------------------------------------ compression ratio (untimed; libzstd level 9 as the reference)
+        if rank == 0:
+            try:
+                from tezip_amd import zstd
+                host_payload = own_state["payload"].cpu().numpy()
+                tb = own_state["table"]
+                n_own = frames.shape[0]
+                trailer = np.concatenate([tb.astype(np.int64), [len(tb)], [1, n_own, H, W, 3], [WARM_UP]]).astype(np.int16)
+                ent = zstd.compress_array(np.concatenate([host_payload, trailer]), 9, zstd.default_threads())
+                fr = frames.cpu().numpy()
+                kf = np.zeros_like(fr)
+                kf[own_state["key"]] = fr[own_state["key"]]
+                keyb = zstd.compress_array(kf, 9, zstd.default_threads())
+                ratio = fr.nbytes / float(len(ent) + len(keyb) + 8 * n_own)
+            except Exception as e:  # ratio is informational
+                print("ratio unavailable:", e, file=sys.stderr)
+
+        # ------------------------------------------------------------ the other N>1 mode
+        if world > 1:
+            if sharded:
+                rf = turbulence_cuda(nt_rank, 0, nt_rank, H, W, 3 + rank, dev)
+                rp = torch.empty(nt_rank * H * W * 3, dtype=torch.int16, device=dev)
+
+                def rstep():
+                    ctx.rollout(rf, WARM_UP, WINDOW)
+                    ctx.encode(MODE, BOUND, True, payload=rp)
+                el = job.timed(rstep, args.steps, 1)
+                extras["replicas"] = {"frames_per_s": nt_rank * world * args.steps / el,
+                                      "note": "one 80-frame sequence per GPU, nothing exchanged (round 1's N>1 mode)"}
+                del rf, rp
+
+        # ------------------------------------------------------------ cfg4: ONE 1024x1024 sequence, windows sharded (strong scaling)
         try:
-            from tezip_amd import zstd
-            host_payload = payload.cpu().numpy()
-            tb = state["table"]
-            trailer = np.concatenate([tb.astype(np.int64), [len(tb)], [1, NT, H, W, 3], [WARM_UP]]).astype(np.int16)
-            ent = zstd.compress_array(np.concatenate([host_payload, trailer]), 9)
-            fr = frames.cpu().numpy()
-            kf = np.zeros_like(fr)
-            kf[state["key"]] = fr[state["key"]]
-            keyb = zstd.compress_array(kf, 9)
-            ratio = fr.nbytes / float(len(ent) + len(keyb) + 8 * NT)
-        except Exception as e:  # ratio is informational
-            ratio = None
-            print("ratio unavailable:", e, file=sys.stderr)
+            extras["cfg4_sharded"] = cfg4_sharded(job, ctx, engine, cfg, rank, world, dev)
+        except Exception as e:
+            extras["cfg4_sharded"] = {"error": repr(e)}
+            if dist:
+                raise
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, frames[:8].cpu().numpy())
 
     if rank == 0:
-        total_frames = NT * args.steps * world
         line = {
             "metric": "frames/sec (predict+delta-encode), 512x512 seq",
-            "value": total_frames / elapsed,
+            "value": value,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -242,12 +470,17 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("512x512x3 synthetic turbulence stack, nt=%d, SWP 20-frame windows, warm_up 0, "
-                                    "lossy rel 1e-3, entropy remap on; PredNet (3,48,96,192) glorot seed 123" % NT)
+            "config": {"workload": ("512x512x3 synthetic turbulence stack, %d frames per GPU (ONE %d-frame sequence), SWP 20-frame "
+                                    "windows, warm_up 0, lossy rel 1e-3, entropy remap on; PredNet (3,48,96,192) glorot seed 123"
+                                    % (nt_rank, nt_total))
                        + (" [EXPLORATION: not the BASELINE.json sequence length]" if explore else ""),
-                       "frames_per_step": NT, "predicted_frames_per_step": n_pred, "sharding": "one sequence per GPU"},
+                       "frames_per_step": nt_total if sharded else nt_rank * world,
+                       "predicted_frames_per_step_rank0": n_pred,
+                       "sharding": ("windows of one sequence over the ranks (dist.compress_sharded), payload gathered on rank 0"
+                                    if sharded else "replicas: one sequence per GPU"),
+                       "backend": backend, "ranks_share_one_gpu": single_dev if world > 1 else False},
+            "sharded_check": check,
             "compression_ratio": ratio,
-            "pcie_inclusive_frames_per_s_rank0": pcie_fps,
             "roofline": {"kernel": "k_conv16 (fp32 MFMA implicit GEMM staged by LDS-DMA: every convolution of levels >= 1, "
                                    "%.0f %% of the step's device time)" % (100.0 * c16_ms / max(step_dev_ms, 1e-9)),
                          "bound": "mfma", "achieved": c16_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -266,10 +499,41 @@ def main():
             "kernel_ms_per_step": {k: v[0] for k, v in prof.items()},
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        line.update(extras)
+        print(json.dumps(line), flush=True)
     ctx.close()
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def cfg4_sharded(job, ctx, engine, cfg, rank, world, dev):
+    """BASELINE.json configs[3]: ONE 320-frame 1024x1024 detector sequence, 40-frame windows, lossy
+    `abs 2`; the 8 windows are sharded over the ranks (strong scaling: total work fixed)."""
+    from tezip_amd import dist as tzdist
+    h = w = 1024
+    nt, window, mode, bound = 320, 40, "abs", [2.0]
+    shards = tzdist.plan_shards(nt, 0, window, world) if world > 1 else [(0, nt)]
+    f0, f1 = shards[rank]
+    frames = detector_cuda(f0, f1, h, w, 4, dev) if f1 > f0 else None
+    ctx.prepare(h, w, max_batch=max(1, (f1 - f0 + window - 1) // window))
+    state = {"payload": torch.empty(nt * h * w * 3, dtype=torch.int16, device=dev) if world == 1 else None}
+
+    def fetch(a, b):
+        return frames
+
+    step = sharded_step_fn(job, ctx, engine, fetch, nt, 0, window, mode, bound, state)
+    steps = 2
+    el = job.timed(step, steps, 1)
+    out = {"workload": "ONE 1024x1024x1(->3) detector sequence, 320 frames, SWP 40-frame windows, lossy abs 2, "
+                       "windows sharded over %d rank(s)" % world,
+           "frames_per_s": nt * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "scaling": "strong"}
+    if world > 1 and rank == 0:
+        full = detector_cuda(0, nt, h, w, 4, dev)
+        out["check"] = verify_against_one_gpu(ctx, full, 0, window, mode, bound, state, nt // window, h, w)
+    if job.dist:
+        job.dist.barrier()
+    return out
 
 
 def host_cores():

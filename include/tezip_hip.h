@@ -58,6 +58,13 @@ int tz_ctx_create(int device, void* hip_stream, tz_ctx** out);
 int tz_ctx_destroy(tz_ctx* ctx);
 int tz_ctx_synchronize(tz_ctx* ctx);
 void* tz_ctx_stream(tz_ctx* ctx);
+/* Pinned (page-locked) host memory for frame stacks and payloads: the reference builds its
+ * stacks with np.array / np.hstack (compress.py:116-122, 329-333); a caller that decodes its images
+ * into such a buffer lets the library DMA it directly and overlap the transfer with the
+ * predictor (key frames first).  Pageable pointers are accepted everywhere too; they are
+ * pipelined through pinned staging buffers inside the context. */
+int tz_host_alloc(size_t bytes, void** out);
+int tz_host_free(void* p);
 
 /* ---- predictor (prednet.py:24-325 used through Model.predict, compress.py:155-173,227) ----
  * weights: the Keras weight list of the PredNet layer (prednet.py:210-227): for key in
@@ -109,8 +116,9 @@ int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t*
  * (tz_spatial_delta with has_carry, tz_build_table, tz_remap). */
 int tz_encode_delta(tz_ctx* ctx, int mode, double b0, double b1, int16_t* delta_out);
 /* ---- decoder back half (decompress.py:203-256): payload (+table) -> nt*H*W*3 uint8 frames,
- * using the prediction stack of the last tz_rollout_decode. */
-int tz_decode(tz_ctx* ctx, const int16_t* payload, const int16_t* table, int table_len,
+ * using the prediction stack of the last tz_rollout_decode.  payload_len (elements) must be
+ * nt*H*W*3 of that rollout: the reference fails at its reshape otherwise (decompress.py:240). */
+int tz_decode(tz_ctx* ctx, const int16_t* payload, size_t payload_len, const int16_t* table, int table_len,
               uint8_t* frames_out);
 /* Last stage of tz_decode only (decompress.py:252-256): reconstruct from an already decoded
  * int16 delta stack (sharded decoding: the inverse scan carry comes from the previous shard). */

@@ -26,6 +26,29 @@ def test_plan_shards_cuts_at_window_starts():
         tzdist.plan_shards(10, 0, None, 2)
 
 
+def test_plan_shards_never_cuts_a_shard_tz_rollout_would_reject():
+    # window = 1 makes one-frame windows: they must be grouped (tz_rollout needs warm_up + 2 frames)
+    assert tzdist.plan_shards(4, 0, 1, 2) == [(0, 2), (2, 4)]
+    for nt, p, w, n in [(4, 0, 1, 2), (12, 0, 1, 8), (5, 1, 1, 4), (7, 2, 1, 3), (3, 1, 1, 2), (2, 0, 1, 2), (9, 3, 2, 4)]:
+        sh = tzdist.plan_shards(nt, p, w, n)
+        assert len(sh) == n and sh[0][0] == 0 and max(b for _, b in sh) == nt
+        for r, (a, b) in enumerate(sh):
+            assert b == a == nt or b - a >= (p + 2 if r == 0 else 2), (nt, p, w, n, sh)
+            assert a == 0 or a == nt or (a - p) % w == 0
+        used = [x for x in sh if x[1] > x[0]]
+        assert all(x[1] == y[0] for x, y in zip(used, used[1:]))
+    with pytest.raises(ValueError):
+        tzdist.plan_shards(3, 2, 1, 2)  # nt < warm_up + 2: the reference breaks there too
+
+
+def test_plan_decode_shards_cut_at_key_frames():
+    assert tzdist.plan_decode_shards([0, 4, 8, 12], 14, 0, 2) == [(0, 8), (8, 14)]
+    assert tzdist.plan_decode_shards([0, 1, 2, 6, 10], 14, 2, 3) == [(0, 6), (6, 10), (10, 14)]
+    assert tzdist.plan_decode_shards([0, 1, 2, 3], 4, 0, 2) == [(0, 2), (2, 4)]
+    with pytest.raises(ValueError):
+        tzdist.plan_decode_shards([1, 5], 9, 0, 2)
+
+
 class OracleEngine:
     """Per-rank compute done by the CPU oracle (test double for dist.HipEngine)."""
 
@@ -115,6 +138,36 @@ def _worker(rank, world, port, p, window, mode, bound, entropy):
         dist.destroy_process_group()
 
 
+def _failing_worker(rank, world, port):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), os.path.join(here, "golden")]
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        frames, pred = _case()
+        eng = OracleEngine(pred)
+        if rank == 1:
+            def boom(*a, **k):
+                raise MemoryError("injected failure on rank 1")
+            eng.encode_delta = boom
+        try:
+            tzdist.compress_sharded(eng, frames, 0, 4, "abs", [0.0], True)
+        except MemoryError:
+            assert rank == 1
+        except RuntimeError as e:  # the healthy rank learns of it instead of hanging in a collective
+            assert rank == 0 and "rank(s) [1]" in str(e)
+        else:
+            raise AssertionError("a failed rank went unnoticed")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_stops_every_rank():
+    import torch.multiprocessing as mp
+    mp.spawn(_failing_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -128,6 +181,7 @@ def _free_port():
     (2, 2, 3, "abs", [3.0], True),
     (3, 0, 5, "rel", [0.02], False),
     (3, 1, 2, "pwrel", [0.05], True),
+    (3, 0, 1, "abs", [1.0], True),     # one-frame windows: shards are groups of them
 ])
 def test_sharded_equals_single_process(world, p, window, mode, bound, entropy):
     import torch.multiprocessing as mp

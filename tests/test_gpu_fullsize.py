@@ -146,3 +146,43 @@ def test_lds_dma_kernels_agree_with_the_general_kernel_at_full_size(ctx, h, w, b
     ctx.set_conv_impl(1)
     assert np.array_equal(preds[0], preds[1])
     assert preds[0].std() > 0  # not trivially equal
+
+
+def test_host_buffers_pinned_pageable_and_device_give_the_same_bytes(ctx):
+    """The copy engine (key frames first, rest of the stack under the predictor, payload leaving in
+    chunks behind the remap kernel; pageable memory pipelined through the pinned staging buffers)
+    must not change a byte: pinned host, pageable host and device-resident runs agree."""
+    import torch
+    from tezip_amd import _lib
+    frames = synth.turbulence(24, 512, 512, seed=11)
+    n = frames.size
+    ctx.prepare(512, 512, max_batch=4)
+    res = {}
+    for kind in ("pageable", "pinned", "device"):
+        if kind == "pageable":
+            f, pay, out = frames, np.empty(n, np.int16), np.empty(frames.shape, np.uint8)
+        elif kind == "pinned":
+            f, pay, out = _lib.pinned_copy(frames), _lib.pinned_empty(n, np.int16), _lib.pinned_empty(frames.shape, np.uint8)
+        else:
+            dev = torch.device("cuda", 0)
+            f = torch.from_numpy(frames).to(dev)
+            pay = torch.empty(n, dtype=torch.int16, device=dev)
+            out = torch.empty(frames.shape, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+        key, mse = ctx.rollout(f, 0, 6, want_mse=(kind == "pinned"))
+        _, table, _ = ctx.encode("abs", [2.0], True, payload=pay)
+        ctx.synchronize()
+        ks = np.zeros_like(frames)
+        ks[key] = frames[key]
+        if kind == "device":
+            ks = torch.from_numpy(ks).to(dev)
+            torch.cuda.synchronize()  # the context runs on its own stream
+        ctx.rollout_decode(ks, 0)
+        ctx.decode(pay, table, out=out)
+        ctx.synchronize()
+        res[kind] = (key, table, pay.cpu().numpy() if kind == "device" else np.array(pay),
+                     out.cpu().numpy() if kind == "device" else np.array(out))
+    for kind in ("pinned", "device"):
+        for a, b in zip(res["pageable"], res[kind]):
+            assert np.array_equal(a, b), kind
+    assert int(np.abs(res["pinned"][3].astype(np.int16) - frames.astype(np.int16)).max()) <= 3

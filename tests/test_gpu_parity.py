@@ -267,9 +267,18 @@ def test_compress_decompress_matches_oracle(ctx, nt, h, w, p, window, thr, mode,
         for j, pr in enumerate(preds):
             if j > 0 or start < p:
                 np.testing.assert_array_equal(stack[start + j], pr, err_msg="prediction of frame %d" % (start + j))
-    if window is None:  # DWP decisions come from the MSE: same order of summation => same bits
-        got_mse = [m for m in mse[p + 1:]]
-        np.testing.assert_allclose(got_mse, ref["mse"], rtol=1e-12)
+    # DWP decisions come from the MSE; with SWP it is the -v log (compress.py:245-247), boundary
+    # frames included (the prediction the reference makes there and then drops)
+    got_mse = [m for m in mse[p + 1:]]
+    np.testing.assert_allclose(got_mse, ref["mse"], rtol=1e-12)
+    if window is not None:  # the log must not change what is encoded: same stack without it
+        key_q, _ = ctx.rollout(frames, p, window, thr)
+        np.testing.assert_array_equal(key_q, key)
+        quiet = ctx.get_predictions()
+        for start, preds in ref["rollout"]["groups"]:
+            for j, pr in enumerate(preds):
+                if j > 0 or start < p:
+                    np.testing.assert_array_equal(quiet[start + j], pr)
     payload, table, delta = ctx.encode(mode, bound, entropy, want_delta=True)
     np.testing.assert_array_equal(delta, ref["delta"])
     # without the delta tap the lossless case takes the fused delta+spatial-delta+histogram kernel

@@ -146,3 +146,31 @@ def test_reads_the_reference_hdf5_checkpoint_without_h5py():
     assert "/model_weights/time_distributed_1/time_distributed_1/kernel:0" in every
     with pytest.raises(ValueError):
         h5lite.H5File(os.path.join(GOLDEN, "ref_runs.npz"))
+
+
+def test_corrupt_or_truncated_streams_are_rejected_before_the_native_call():
+    """The trailer comes from a file: a truncated payload, a one-channel trailer or a key stack
+    of another size must raise a ValueError (the reference fails at its reshape,
+    decompress.py:115,240) instead of handing a short buffer to the library."""
+    payload = np.arange(2 * 4 * 5 * 3, dtype=np.int16)
+    table = np.array([1600, 1599], np.int16)
+    stream = compress.build_stream(payload, table, (1, 2, 4, 5, 3), 0)
+    p, t, shape, warm = decompress.parse_stream(stream.tobytes())
+    decompress.check_stream(shape, warm, p.size, 2 * 4 * 5 * 3)  # consistent: passes
+    with pytest.raises(ValueError, match="truncated"):
+        decompress.check_stream(shape, warm, p.size - 7, 2 * 4 * 5 * 3)
+    with pytest.raises(ValueError, match="key_frame.dat"):
+        decompress.check_stream(shape, warm, p.size, 2 * 4 * 5 * 3 - 1)
+    with pytest.raises(ValueError, match="shape"):
+        decompress.check_stream((1, 2, 4, 5, 1), warm, 2 * 4 * 5, 2 * 4 * 5)
+    with pytest.raises(ValueError, match="shape"):
+        decompress.check_stream((2, 2, 4, 5, 3), warm, p.size, p.size)
+    with pytest.raises(ValueError, match="warm-up"):
+        decompress.check_stream(shape, 2, p.size, p.size)
+    with pytest.raises(ValueError, match="warm-up"):
+        decompress.check_stream(shape, -1, p.size, p.size)
+    # a stream cut in the middle of the payload: the trailer is then garbage or inconsistent
+    cut = stream[: stream.size - 30].tobytes()
+    with pytest.raises(ValueError):
+        p2, t2, shape2, warm2 = decompress.parse_stream(cut)
+        decompress.check_stream(shape2, warm2, p2.size, 2 * 4 * 5 * 3)

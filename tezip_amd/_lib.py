@@ -42,7 +42,9 @@ _SIGS = {
     "tz_get_predictions": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tz_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                             C.POINTER(C.c_int), C.c_void_p]),
-    "tz_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "tz_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
+    "tz_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "tz_host_free": (C.c_int, [C.c_void_p]),
     "tz_encode_delta": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]),
     "tz_decode_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "tz_delta_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -92,6 +94,44 @@ def load():
 
 def pad8(v):
     return (v + 7) // 8 * 8
+
+
+def _numel(x):
+    return int(x.numel()) if hasattr(x, "numel") else int(np.asarray(x).size)
+
+
+class _Pinned:
+    """Owner of one tz_host_alloc block (freed when the last numpy view goes away)."""
+
+    def __init__(self, lib, ptr, nbytes):
+        self.lib, self.ptr = lib, ptr
+        self.__array_interface__ = {"data": (ptr, False), "shape": (nbytes,), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        try:
+            self.lib.tz_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in page-locked host memory (tz_host_alloc): the library DMAs such buffers
+    directly and overlaps the transfers with the predictor.  Needs a GPU (raises otherwise)."""
+    lib = load()
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    p = C.c_void_p()
+    rc = lib.tz_host_alloc(max(nbytes, 16), C.byref(p))
+    if rc != TZ_OK:
+        raise TezipError(rc, lib.tz_strerror(rc).decode() + " (tz_host_alloc)")
+    owner = _Pinned(lib, p.value, max(nbytes, 16))
+    return np.asarray(owner)[:nbytes].view(dtype).reshape(shape)
+
+
+def pinned_copy(arr):
+    out = pinned_empty(arr.shape, arr.dtype)
+    out[...] = arr
+    return out
 
 
 def _ptr(x, dtype=None):
@@ -178,7 +218,13 @@ class Context:
         self._ck(self.lib.tz_set_conv_impl(self.h, int(bool(lds_dma))))
 
     # ---- rollout + encode / decode
+    @staticmethod
+    def _check_stack(x, what):
+        if len(x.shape) != 4 or x.shape[3] != 3:  # compress.py:114: grayscale is expanded to 3 channels first
+            raise ValueError("%s must be a (nt, H, W, 3) uint8 stack, got shape %r" % (what, tuple(x.shape)))
+
     def rollout(self, frames, warm_up, window, threshold=0.0, want_mse=False):
+        self._check_stack(frames, "frames")
         nt, h, w = frames.shape[:3]
         key = np.zeros(nt, np.uint8)
         mse = np.zeros(nt, np.float64) if want_mse else None
@@ -188,6 +234,7 @@ class Context:
         return key.astype(bool), mse
 
     def rollout_decode(self, key_frames, warm_up):
+        self._check_stack(key_frames, "key_frames")
         nt, h, w = key_frames.shape[:3]
         key = np.zeros(nt, np.uint8)
         self._ck(self.lib.tz_rollout_decode(self.h, _ptr(key_frames, np.uint8), nt, h, w, warm_up, key.ctypes.data))
@@ -224,6 +271,8 @@ class Context:
 
     def decode_delta(self, delta, out=None):
         nt, h, w = self._shape
+        if _numel(delta) != nt * h * w * 3:  # decompress.py:240: the reference's reshape raises
+            raise ValueError("delta stack holds %d elements, expected %d" % (_numel(delta), nt * h * w * 3))
         if out is None:
             out = np.empty((nt, h, w, 3), np.uint8)
         self._ck(self.lib.tz_decode_delta(self.h, _ptr(delta), _ptr(out)))
@@ -231,11 +280,13 @@ class Context:
 
     def decode(self, payload, table, out=None):
         nt, h, w = self._shape
+        if _numel(payload) != nt * h * w * 3:  # decompress.py:240: the reference's reshape raises
+            raise ValueError("payload holds %d elements, expected %d" % (_numel(payload), nt * h * w * 3))
         if out is None:
             out = np.empty((nt, h, w, 3), np.uint8)
         tl = -1 if table is None else len(table)
         tb = None if table is None else np.ascontiguousarray(table, np.int16)
-        self._ck(self.lib.tz_decode(self.h, _ptr(payload), _ptr(tb), tl, _ptr(out)))
+        self._ck(self.lib.tz_decode(self.h, _ptr(payload), _numel(payload), _ptr(tb), tl, _ptr(out)))
         return out
 
     # ---- operator seams

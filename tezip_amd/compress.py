@@ -141,8 +141,8 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
     try:
         if job:
             # frame windows sharded over the ranks (tezip_amd/dist.py); rank 0 writes the files
-            res = tzdist.compress_sharded(tzdist.HipEngine(ctx), origine_img, PREPROCESS, WINDOW_SIZE, MODE, BOUND_VALUE,
-                                          ENTROPY_RUN)
+            res = tzdist.compress_sharded(tzdist.HipEngine(ctx, device), origine_img, PREPROCESS, WINDOW_SIZE, MODE,
+                                          BOUND_VALUE, ENTROPY_RUN)
             if res is None:
                 return
             payload, table, key = res

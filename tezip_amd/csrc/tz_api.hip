@@ -60,6 +60,13 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
     }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
+    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_keys, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_frames, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_compute, hipEventDisableTiming) != hipSuccess) {
+        tz_ctx_destroy(ctx);
+        return TZ_ERR_HIP;
+    }
     ctx->ring_size = 1 << 20;
     if (hipHostMalloc((void**)&ctx->ring, ctx->ring_size, hipHostMallocDefault) != hipSuccess) {
         ctx->ring = nullptr;
@@ -85,6 +92,18 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
             (void)hipEventDestroy(e.second);
         }
     if (ctx->ring) (void)hipHostFree(ctx->ring);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    for (int i = 0; i < tz_ctx::kStages; ++i) {
+        if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
+        if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
+    }
+    for (auto e : ctx->chunk_ev) (void)hipEventDestroy(e);
+    if (ctx->ev_keys) (void)hipEventDestroy(ctx->ev_keys);
+    if (ctx->ev_frames) (void)hipEventDestroy(ctx->ev_frames);
+    if (ctx->ev_compute) (void)hipEventDestroy(ctx->ev_compute);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -101,14 +120,103 @@ extern "C" int tz_ctx_synchronize(tz_ctx* ctx) {
 extern "C" void* tz_ctx_stream(tz_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 // ---------------------------------------------------------------------- memory helpers
-bool tz_is_device_ptr(const void* p) {
+int tz_ptr_kind(const void* p) {
     hipPointerAttribute_t attr;
     hipError_t e = hipPointerGetAttributes(&attr, p);
     if (e != hipSuccess) {
         (void)hipGetLastError();  // unregistered host memory: clear the sticky error
-        return false;
+        return 0;
     }
-    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+    if (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) return 2;
+    return attr.type == hipMemoryTypeHost ? 1 : 0;
+}
+
+bool tz_is_device_ptr(const void* p) { return tz_ptr_kind(p) == 2; }
+
+extern "C" int tz_host_alloc(size_t bytes, void** out) {
+    if (!out) return TZ_ERR_INVALID;
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? TZ_ERR_NO_DEVICE : TZ_ERR_NOMEM;
+    }
+    return TZ_OK;
+}
+
+extern "C" int tz_host_free(void* p) {
+    if (!p) return TZ_OK;
+    return hipHostFree(p) == hipSuccess ? TZ_OK : TZ_ERR_HIP;
+}
+
+// one pinned staging buffer, free to be overwritten (its previous DMA has completed)
+static int stage_acquire(tz_ctx* ctx, int* idx) {
+    const int i = ctx->stage_next;
+    ctx->stage_next = (i + 1) % tz_ctx::kStages;
+    if (!ctx->stage[i]) {
+        hipError_t e = hipHostMalloc((void**)&ctx->stage[i], tz_ctx::kStageBytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) return tz_fail(ctx, TZ_ERR_NOMEM, "pinned staging buffer: %s", hipGetErrorString(e));
+    }
+    if (ctx->stage_busy[i]) {
+        TZ_HIP(ctx, hipEventSynchronize(ctx->stage_ev[i]));
+        ctx->stage_busy[i] = false;
+    }
+    *idx = i;
+    return TZ_OK;
+}
+
+int tz_h2d(tz_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return TZ_OK;
+    if (tz_ptr_kind(src) != 0) {
+        TZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s));
+        return TZ_OK;
+    }
+    // pageable: memcpy of chunk k+1 into a pinned buffer overlaps the DMA of chunk k
+    for (size_t off = 0; off < bytes; off += tz_ctx::kStageBytes) {
+        const size_t n = std::min(tz_ctx::kStageBytes, bytes - off);
+        int i;
+        TZ_TRY(stage_acquire(ctx, &i));
+        memcpy(ctx->stage[i], (const uint8_t*)src + off, n);
+        TZ_HIP(ctx, hipMemcpyAsync((uint8_t*)dst + off, ctx->stage[i], n, hipMemcpyHostToDevice, s));
+        TZ_HIP(ctx, hipEventRecord(ctx->stage_ev[i], s));
+        ctx->stage_busy[i] = true;
+    }
+    return TZ_OK;
+}
+
+int tz_d2h(tz_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return TZ_OK;
+    if (tz_ptr_kind(dst) != 0) {
+        TZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s));
+        return TZ_OK;
+    }
+    // pageable: the DMA of chunk k+1 into a pinned buffer overlaps the memcpy of chunk k out of one
+    int prev = -1;
+    size_t prev_off = 0, prev_n = 0;
+    for (size_t off = 0; off < bytes; off += tz_ctx::kStageBytes) {
+        const size_t n = std::min(tz_ctx::kStageBytes, bytes - off);
+        int i;
+        TZ_TRY(stage_acquire(ctx, &i));
+        TZ_HIP(ctx, hipMemcpyAsync(ctx->stage[i], (const uint8_t*)src + off, n, hipMemcpyDeviceToHost, s));
+        TZ_HIP(ctx, hipEventRecord(ctx->stage_ev[i], s));
+        ctx->stage_busy[i] = true;
+        if (prev >= 0) {
+            TZ_HIP(ctx, hipEventSynchronize(ctx->stage_ev[prev]));
+            ctx->stage_busy[prev] = false;
+            memcpy((uint8_t*)dst + prev_off, ctx->stage[prev], prev_n);
+        }
+        prev = i;
+        prev_off = off;
+        prev_n = n;
+    }
+    if (prev >= 0) {
+        TZ_HIP(ctx, hipEventSynchronize(ctx->stage_ev[prev]));
+        ctx->stage_busy[prev] = false;
+        memcpy((uint8_t*)dst + prev_off, ctx->stage[prev], prev_n);
+    }
+    return TZ_OK;
 }
 
 static constexpr size_t kPoolUsed = (size_t)1 << 63;  // top bit of the size marks "handed out"
@@ -156,9 +264,9 @@ int tz_ensure(tz_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
 int tz_upload(tz_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return TZ_OK;
     size_t need = (bytes + 63) & ~(size_t)63;
-    if (!ctx->ring || need > ctx->ring_size / 4) {  // large or no ring: blocking copy
-        TZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-        TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->ring || need > ctx->ring_size / 4) {  // large or no ring: the caller's block is free on return
+        TZ_TRY(tz_h2d(ctx, dst, src, bytes, ctx->stream));
+        if (tz_ptr_kind(src) != 0) TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return TZ_OK;
     }
     if (ctx->ring_pos + need > ctx->ring_size) {  // wrap: everything queued so far must have left the ring
@@ -179,8 +287,8 @@ int tz_dev_in(tz_ctx* ctx, const void* p, size_t bytes, const void** dev) {
     }
     void* d;
     TZ_TRY(tz_pool_alloc(ctx, bytes, &d));
-    TZ_HIP(ctx, hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream));
-    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's host buffer is free again on return
+    TZ_TRY(tz_h2d(ctx, d, p, bytes, ctx->stream));
+    if (tz_ptr_kind(p) != 0) TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffer is free again on return
     *dev = d;
     return TZ_OK;
 }
@@ -199,8 +307,8 @@ int tz_dev_out(tz_ctx* ctx, void* p, size_t bytes, tz_out* o) {
 int tz_dev_out_finish(tz_ctx* ctx, std::vector<tz_out>& outs) {
     bool any = false;
     for (auto& o : outs)
-        if (o.host && o.bytes) {
-            TZ_HIP(ctx, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (o.host && o.bytes && !o.done) {
+            TZ_TRY(tz_d2h(ctx, o.host, o.dev, o.bytes, ctx->stream));
             any = true;
         }
     if (any) TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -311,7 +419,12 @@ __global__ void k_bcast_frame(const float* __restrict__ src, size_t fe, const in
         dst[i] = src[i];
 }
 
-static int rollout_setup(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int W, int warm_up) {
+// Host frames travel on the copy stream: the frames in `first` (the key frames the rollout
+// reads) go ahead and the compute stream waits for them only; rollout_finish_upload sends the rest
+// once the predictor launches are queued, so that the bulk of the stack (needed by the delta stage
+// only) crosses PCIe while the predictor runs.
+static int rollout_setup(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int W, int warm_up,
+                         const std::vector<int>* first = nullptr) {
     if (!ctx->model) return tz_fail(ctx, TZ_ERR_STATE, "no model loaded");
     if (nt < 1 || H < 1 || W < 1 || warm_up < 0 || nt > 32767 || H > 32767 || W > 32767)
         return tz_fail(ctx, TZ_ERR_INVALID, "bad sequence shape nt=%d H=%d W=%d warm_up=%d (int16 trailer limits)", nt, H, W, warm_up);
@@ -328,10 +441,56 @@ static int rollout_setup(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int 
     ctx->Wp = Wp;
     ctx->warm_up = warm_up;
     ctx->have_rollout = false;
-    size_t fb = (size_t)nt * H * W * 3, pb = (size_t)nt * Hp * Wp * 3 * 4;
+    ctx->pending_src = nullptr;
+    ctx->pending_sent.clear();
+    const size_t fsz = (size_t)H * W * 3;
+    size_t fb = (size_t)nt * fsz, pb = (size_t)nt * Hp * Wp * 3 * 4;
     TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_frames, &ctx->cap_frames, fb));
     TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_pred, &ctx->cap_pred, pb));
-    TZ_HIP(ctx, hipMemcpyAsync(ctx->d_frames, frames, fb, hipMemcpyDefault, ctx->stream));
+    if (tz_is_device_ptr(frames)) {
+        TZ_HIP(ctx, hipMemcpyAsync(ctx->d_frames, frames, fb, hipMemcpyDeviceToDevice, ctx->stream));
+        return TZ_OK;
+    }
+    // earlier work queued on the compute stream may still read d_frames
+    TZ_HIP(ctx, hipEventRecord(ctx->ev_compute, ctx->stream));
+    TZ_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compute, 0));
+    if (first && !first->empty() && (int)first->size() < nt) {
+        ctx->pending_sent.assign(nt, 0);
+        for (int f : *first) {
+            if (f < 0 || f >= nt || ctx->pending_sent[f]) continue;
+            TZ_TRY(tz_h2d(ctx, ctx->d_frames + (size_t)f * fsz, frames + (size_t)f * fsz, fsz, ctx->copy_stream));
+            ctx->pending_sent[f] = 1;
+        }
+        TZ_HIP(ctx, hipEventRecord(ctx->ev_keys, ctx->copy_stream));
+        TZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_keys, 0));
+        ctx->pending_src = frames;
+        return TZ_OK;
+    }
+    TZ_TRY(tz_h2d(ctx, ctx->d_frames, frames, fb, ctx->copy_stream));
+    TZ_HIP(ctx, hipEventRecord(ctx->ev_frames, ctx->copy_stream));
+    TZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_frames, 0));
+    return TZ_OK;
+}
+
+// second half of a split upload: every frame not sent by rollout_setup, in contiguous runs; the
+// compute stream continues (delta stage, window MSE) only after they have landed
+static int rollout_finish_upload(tz_ctx* ctx) {
+    if (!ctx->pending_src) return TZ_OK;
+    const size_t fsz = (size_t)ctx->H * ctx->W * 3;
+    const uint8_t* src = ctx->pending_src;
+    ctx->pending_src = nullptr;
+    for (int f = 0; f < ctx->nt;) {
+        if (ctx->pending_sent[f]) {
+            ++f;
+            continue;
+        }
+        int g = f;
+        while (g < ctx->nt && !ctx->pending_sent[g]) ++g;
+        TZ_TRY(tz_h2d(ctx, ctx->d_frames + (size_t)f * fsz, src + (size_t)f * fsz, (size_t)(g - f) * fsz, ctx->copy_stream));
+        f = g;
+    }
+    TZ_HIP(ctx, hipEventRecord(ctx->ev_frames, ctx->copy_stream));
+    TZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_frames, 0));
     return TZ_OK;
 }
 
@@ -396,10 +555,16 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
     if (window < 0) return tz_fail(ctx, TZ_ERR_INVALID, "window must be >= 0");
     if (nt < warm_up + 2)  // the reference breaks here
         return tz_fail(ctx, TZ_ERR_INVALID, "need at least warm_up+2 frames (nt=%d, warm_up=%d)", nt, warm_up);
-    int rc = rollout_setup(ctx, frames, nt, H, W, warm_up);
-    if (rc != TZ_OK) return rc;
     const int p = warm_up;
     const bool dwp = window == 0;
+    std::vector<int> first;  // SWP reads exactly the frames that start a window (compress.py:218-220)
+    if (!dwp)
+        for (int f = p; f < nt; f += window) first.push_back(f);
+    int rc = rollout_setup(ctx, frames, nt, H, W, warm_up, dwp ? nullptr : &first);
+    if (rc != TZ_OK) {
+        tz_pool_release_all(ctx);
+        return rc;
+    }
     const bool want_mse = dwp || mse_log != nullptr;
     std::vector<uint8_t> key(nt, 0), gfirst(nt, 0), qskip(nt, 0);
     std::vector<double> mse(nt, 0.0);
@@ -420,41 +585,44 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
     const size_t fe_pad = (size_t)ctx->Hp * ctx->Wp * 3;
     if (!dwp) {
         // SWP: window boundaries are known up front (compress.py:249: (idx-p) % w == 0), so all
-        // windows advance together; the prediction dropped at a boundary (251-253) is never made.
+        // windows advance together.  The prediction the reference makes and drops at a boundary
+        // (251-253) is only evaluated when the MSE log is wanted (-v prints it, 245-247).
         std::vector<PredItem> items;
+        std::vector<int> dropped;
         int key_idx = p + 1;
         for (int idx = p + 1; idx < nt; ++idx) {
             bool from_key = idx == key_idx;
             if (from_key) key[idx - 1] = 1;
             bool trig = (idx - p) % window == 0;
-            if (trig) {
-                gfirst[idx] = 1;
+            if (trig) gfirst[idx] = 1;
+            if (trig && !want_mse) {
                 c0_slots.push_back(idx);
-                if (idx == nt - 1) key[idx] = 1;  // compress.py:260-262
-                key_idx = idx + 1;
             } else {
                 items.push_back(PredItem{idx, from_key ? 1 : 0, idx - 1, idx - (key_idx - 1)});
+                if (trig && idx != nt - 1) dropped.push_back(idx);  // the last frame keeps it (260-262)
+            }
+            if (trig) {
+                if (idx == nt - 1) key[idx] = 1;  // compress.py:260-262
+                key_idx = idx + 1;
             }
         }
         rc = fill_c0(ctx, c0_slots);
         if (rc == TZ_OK) rc = run_schedule(ctx, items);
+        if (rc == TZ_OK) rc = rollout_finish_upload(ctx);
         if (rc == TZ_OK && want_mse) {
-            // verbose-only in the reference (compress.py:245-247); note the reference's value at
-            // a boundary frame includes the dropped prediction, which SWP never evaluates here:
-            // those entries are reported as 0.
             std::vector<double> sse(nt, 0.0);
             rc = tzk_sse(ctx, ctx->d_frames, ctx->d_pred, nt, H, W, ctx->Hp, ctx->Wp, sse.data());
             int k0 = p + 1;
             double run = 0.0;
             for (int idx = p + 1; idx < nt && rc == TZ_OK; ++idx) {
+                run = run + sse[idx];
+                mse[idx] = run / (double)((size_t)(idx - k0 + 1) * fe_pad);
                 if (gfirst[idx]) {
                     k0 = idx + 1;
                     run = 0.0;
-                    continue;
                 }
-                run = run + sse[idx];
-                mse[idx] = run / (double)((size_t)(idx - k0 + 1) * fe_pad);
             }
+            if (rc == TZ_OK) rc = fill_c0(ctx, dropped);  // slot 0 of the next group holds C0 (258)
         }
     } else {
         // DWP: boundaries depend on the window MSE of the padded frames (compress.py:245-249)
@@ -620,6 +788,34 @@ static void build_dec_lut(const int16_t* table, int T, int apply_offset, std::ve
 }
 
 // ------------------------------------------------------------------------ encode / decode
+// Last stage of tz_encode: rank remap (compress.py:369).  A host payload leaves chunk by chunk on
+// the copy stream behind the remap kernel, so that the device -> host transfer overlaps it.
+static int remap_out(tz_ctx* ctx, const int16_t* d_sd, size_t N, const int16_t* lut, tz_out* o) {
+    constexpr int kChunks = 8;
+    if (!o->host || N < ((size_t)1 << 22)) return tzk_lut(ctx, d_sd, N, lut, 0, (int16_t*)o->dev);
+    const size_t per = ((N + kChunks - 1) / kChunks + 7) & ~(size_t)7;
+    while (ctx->chunk_ev.size() < (size_t)kChunks) {
+        hipEvent_t e;
+        TZ_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->chunk_ev.push_back(e);
+    }
+    int k = 0;
+    for (size_t off = 0; off < N; off += per, ++k) {
+        const size_t n = std::min(per, N - off);
+        TZ_TRY(tzk_lut(ctx, d_sd + off, n, lut, 0, (int16_t*)o->dev + off));
+        TZ_HIP(ctx, hipEventRecord(ctx->chunk_ev[k], ctx->stream));
+    }
+    k = 0;
+    for (size_t off = 0; off < N; off += per, ++k) {
+        const size_t n = std::min(per, N - off);
+        TZ_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_ev[k], 0));
+        TZ_TRY(tz_d2h(ctx, (int16_t*)o->host + off, (const int16_t*)o->dev + off, n * 2, ctx->copy_stream));
+    }
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    o->done = true;
+    return TZ_OK;
+}
+
 extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t* payload, int16_t* table,
                          int* table_len, int16_t* delta_out) {
     if (!ctx || !payload || !table_len || (entropy && !table)) return TZ_ERR_INVALID;
@@ -631,7 +827,6 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
     tz_out o_pay, o_delta;
     void *d_delta = nullptr, *d_mask = nullptr, *d_hist = nullptr, *d_sd = nullptr;
     int rc = tz_dev_out(ctx, payload, N * 2, &o_pay);
-    if (rc == TZ_OK) outs.push_back(o_pay);
     if (rc == TZ_OK && delta_out) {
         rc = tz_dev_out(ctx, delta_out, N * 2, &o_delta);
         if (rc == TZ_OK) {
@@ -679,8 +874,9 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
         std::vector<int16_t> lut;
         if (rc == TZ_OK) rc = tz_build_table(hist.data(), TZ_NBINS, table, table_len);  // 356-361
         if (rc == TZ_OK) rc = build_enc_lut(ctx, table, *table_len, &lut);
-        if (rc == TZ_OK) rc = tzk_lut(ctx, (const int16_t*)d_sd, N, lut.data(), 0, (int16_t*)o_pay.dev);  // 369
+        if (rc == TZ_OK) rc = remap_out(ctx, (const int16_t*)d_sd, N, lut.data(), &o_pay);  // 369
     }
+    outs.push_back(o_pay);
     if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
     tz_pool_release_all(ctx);
     return rc;
@@ -727,12 +923,15 @@ extern "C" int tz_decode_delta(tz_ctx* ctx, const int16_t* delta, uint8_t* frame
     return rc;
 }
 
-extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, const int16_t* table, int table_len, uint8_t* frames_out) {
+extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, size_t payload_len, const int16_t* table, int table_len,
+                         uint8_t* frames_out) {
     if (!ctx || !payload || !frames_out) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || !ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_decode needs a tz_rollout_decode first");
     if (table_len > TZ_NBINS || (table_len >= 0 && !table && table_len > 0)) return tz_fail(ctx, TZ_ERR_INVALID, "bad table");
     const int nt = ctx->nt, H = ctx->H, W = ctx->W;
     const size_t N = (size_t)nt * H * W * 3;
+    if (payload_len != N)  // decompress.py:240: the reshape raises
+        return tz_fail(ctx, TZ_ERR_INVALID, "payload holds %zu elements, the key-frame stack implies %zu", payload_len, N);
     std::vector<tz_out> outs;
     tz_out o;
     const void* d_pay = nullptr;

@@ -66,6 +66,21 @@ struct tz_ctx {
     // index table of the static rollout schedule (SWP encoder / decoder replay): [batches][3][stride]
     int* d_sched = nullptr;
     size_t cap_sched = 0;
+    // copy engine: host<->device transfers of the frame stack and the payload run on their own
+    // stream so that they overlap the predictor (key frames go first, the rest follows while the
+    // rollout computes; the payload leaves chunk by chunk behind the remap kernel).  Pinned host
+    // memory (tz_host_alloc) is DMA'd directly; pageable memory is pipelined through `stage`.
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_keys = nullptr, ev_frames = nullptr, ev_compute = nullptr;
+    static constexpr int kStages = 4;
+    static constexpr size_t kStageBytes = (size_t)8 << 20;
+    uint8_t* stage[kStages] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t stage_ev[kStages] = {nullptr, nullptr, nullptr, nullptr};
+    bool stage_busy[kStages] = {false, false, false, false};
+    int stage_next = 0;
+    const uint8_t* pending_src = nullptr;  // host frame stack whose non-key frames are still to be sent
+    std::vector<uint8_t> pending_sent;     // nt: 1 = already on its way
+    std::vector<hipEvent_t> chunk_ev;  // payload chunk hand-over events (compute -> copy stream)
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool prof_on = false;
@@ -96,6 +111,15 @@ int tz_ensure(tz_ctx* ctx, void** buf, size_t* cap, size_t bytes);  // persisten
 // Stream-ordered upload of a small host block to `dst` (device) through the pinned ring.
 int tz_upload(tz_ctx* ctx, void* dst, const void* src, size_t bytes);
 
+// 0 = pageable host, 1 = pinned / registered host, 2 = device
+int tz_ptr_kind(const void* p);
+// Stream-ordered host -> device copy on stream `s`.  Pinned source: one asynchronous DMA (the
+// source must stay valid until `s` reaches it).  Pageable source: pipelined through the pinned
+// staging buffers; the source is free again when the call returns.
+int tz_h2d(tz_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s);
+// Device -> host copy on stream `s`.  Pinned destination: asynchronous (complete when `s` is
+// synchronised).  Pageable destination: pipelined through the staging buffers, complete on return.
+int tz_d2h(tz_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s);
 // Input argument: returns a device pointer holding `bytes` of *p (staging if host).
 int tz_dev_in(tz_ctx* ctx, const void* p, size_t bytes, const void** dev);
 // Output argument: returns a device pointer to write; tz_dev_out_finish copies back if host.
@@ -103,6 +127,7 @@ struct tz_out {
     void* host = nullptr;
     void* dev = nullptr;
     size_t bytes = 0;
+    bool done = false;  // already copied back (chunked hand-over on the copy stream)
 };
 int tz_dev_out(tz_ctx* ctx, void* p, size_t bytes, tz_out* o);
 int tz_dev_out_finish(tz_ctx* ctx, std::vector<tz_out>& outs);  // D2H copies + stream sync if any host

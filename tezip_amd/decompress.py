@@ -28,6 +28,23 @@ def parse_stream(data):
     return s[: -7 - tlen], s[-7 - tlen: -7], shape, warm_up
 
 
+def check_stream(shape, warm_up, payload_len, key_len):
+    """The trailer is data from a file: cross-check it before any pointer derived from it reaches
+    the native library.  The reference fails with a ValueError at its reshapes
+    (decompress.py:115,240) for the same inconsistencies."""
+    one, nt, H, W, C = shape
+    if one != 1 or C != 3 or nt < 1 or H < 1 or W < 1:
+        raise ValueError("entropy.dat: unsupported stack shape %r (expected (1, nt, H, W, 3))" % (tuple(shape),))
+    n = nt * H * W * C
+    if payload_len != n:
+        raise ValueError("entropy.dat: payload holds %d elements, the trailer says %d (truncated or corrupt file)"
+                         % (payload_len, n))
+    if key_len != n:
+        raise ValueError("key_frame.dat holds %d bytes, entropy.dat's trailer implies %d" % (key_len, n))
+    if not 0 <= warm_up < nt:
+        raise ValueError("entropy.dat: warm-up count %d outside [0, %d)" % (warm_up, nt))
+
+
 def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
     if not GPU_FLAG:
         print("ERROR: this build runs the decompression path on an AMD MI355X only (no CPU path).")
@@ -59,6 +76,7 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
 
     key_bytes = read("key_frame.dat")
     payload, table, shape, warm_up = parse_stream(read("entropy.dat"))
+    check_stream(shape, warm_up, payload.size, len(key_bytes))
     _, nt, H, W, C = shape
     key_frames = np.frombuffer(key_bytes, dtype=np.uint8).reshape(nt, H, W, C)
     hp, wp = padding_shape(H, W)
@@ -79,7 +97,7 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
     try:
         if job:
             # key intervals sharded over the ranks (tezip_amd/dist.py); rank 0 saves the images
-            frames = tzdist.decompress_sharded(tzdist.HipEngine(ctx), key_frames, payload, table, warm_up)
+            frames = tzdist.decompress_sharded(tzdist.HipEngine(ctx, device), key_frames, payload, table, warm_up)
             if frames is None:
                 return
         else:

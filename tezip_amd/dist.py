@@ -2,19 +2,24 @@
 
 Windows (a key frame + its predicted frames) are independent through prediction, delta and
 quantisation (compress.py:218-220,256-263): each rank runs them on a contiguous range of
-windows with NO data-path collective.  Only three tiny things cross shard boundaries
+windows with NO data-path collective.  Only three things cross shard boundaries
 (SURVEY.md §8e), exchanged through torch.distributed (RCCL on GPUs, gloo in CPU tests):
   1. the spatial delta runs over the whole flattened stack (compress.py:339): a shard needs the
-     last delta element of the previous shard (one int16 `carry`);
+     last delta element of the previous shard (one int16 `carry`; it travels in one small
+     all_gather together with the shard's key mask and an error flag);
   2. the rank table is built from the global histogram (compress.py:354-361): all-reduce of
      2111 counters, the table is then rebuilt identically on every rank;
-  3. rank 0 collects the payload shards, key masks (and decoded frames).
+  3. rank 0 receives the payload shards point to point, straight into their place in the
+     full payload buffer (peers `send`, rank 0 `irecv`s into slices: nothing lands on a rank
+     that does not use it).
 The decoder shards the same way; its inverse scan needs the prefix of per-shard sums.
 
-DWP (-t) discovers window boundaries sequentially and does not shard: replicas only.
+Everything between the frames and the payload stays in the rank's HBM: the per-rank `engine`
+hands out engine-native buffers (HipEngine: torch CUDA tensors whose pointers go through the C
+ABI; the oracle engine of the CPU tests: numpy arrays) and only turns them into communication
+tensors (`comm_tensor`) for step 3.
 
-The per-rank compute is behind a small `engine` interface so that the protocol can be
-exercised on CPU ranks (tests plug the oracle in); production uses HipEngine.
+DWP (-t) discovers window boundaries sequentially and does not shard: replicas only.
 """
 import numpy as np
 
@@ -22,54 +27,113 @@ NBINS = 2111
 
 
 class HipEngine:
-    """Per-rank compute on the MI355X through the C ABI (tezip_amd._lib.Context)."""
+    """Per-rank compute on the MI355X through the C ABI (tezip_amd._lib.Context).  Buffers are
+    torch CUDA tensors on the context's device; host data only enters as the frame shard and
+    leaves as the few scalars the protocol exchanges."""
 
-    def __init__(self, ctx):
-        self.ctx = ctx
+    def __init__(self, ctx, device=None):
+        import torch
+        self.ctx, self.torch = ctx, torch
+        self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+
+    def _new(self, n, dtype):
+        return self.torch.empty(int(n), dtype=dtype, device=self.dev)
+
+    def _sync(self):
+        # the context launches on its own stream: torch / RCCL consume the buffers afterwards
+        self.ctx.synchronize()
+
+    def _buf(self, x):
+        """numpy (host) and torch tensors are both accepted by the C ABI."""
+        return np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x.contiguous()
 
     # encoder
     def encode_delta(self, frames, warm_up, window, mode, bound):
-        key, _ = self.ctx.rollout(np.ascontiguousarray(frames), warm_up, window)
-        return key, self.ctx.encode_delta(mode, bound).reshape(-1)
+        frames = self._buf(frames)
+        nt, h, w = frames.shape[:3]
+        key, _ = self.ctx.rollout(frames, warm_up, window)
+        d = self._new(nt * h * w * 3, self.torch.int16)
+        self.ctx.encode_delta(mode, bound, out=d)
+        self._sync()
+        return key, d
+
+    def last(self, buf):
+        return int(buf[-1].item())
 
     def spatial_delta(self, d, carry, offset):
         hist = np.zeros(NBINS, np.uint64) if offset else None
-        y = self.ctx.spatial_delta(np.ascontiguousarray(d), offset, carry=carry, hist=hist)
+        y = self._new(d.numel(), self.torch.int16)
+        self.ctx.spatial_delta(d, offset, carry=carry, hist=hist, out=y)
+        self._sync()
         return y, hist
 
     def build_table(self, hist):
         return self.ctx.build_table(hist)
 
     def remap(self, y, table):
-        return self.ctx.remap(y, table)
+        out = self._new(y.numel(), self.torch.int16)
+        self.ctx.remap(y, table, out=out)
+        self._sync()
+        return out
 
     # decoder
     def decode_prepare(self, key_frames, warm_up):
-        return self.ctx.rollout_decode(np.ascontiguousarray(key_frames), warm_up)
+        return self.ctx.rollout_decode(self._buf(key_frames), warm_up)
 
     def unmap(self, payload, table):
-        return self.ctx.unmap(np.ascontiguousarray(payload), table, offset=True)
+        payload = self._buf(payload)
+        n = payload.size if isinstance(payload, np.ndarray) else payload.numel()
+        out = self._new(n, self.torch.int16)
+        self.ctx.unmap(payload, table, offset=True, out=out)
+        self._sync()
+        return out
+
+    def upload(self, arr):
+        return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.dev)
 
     def undelta(self, sd, carry):
-        return self.ctx.spatial_undelta(np.ascontiguousarray(sd), carry=carry)
+        out = self._new(sd.numel(), self.torch.int16)
+        self.ctx.spatial_undelta(sd, carry=carry, out=out)
+        self._sync()
+        return out
 
     def reconstruct(self, delta):
-        return self.ctx.decode_delta(np.ascontiguousarray(delta))
+        nt, h, w = self.ctx._shape
+        out = self._new(nt * h * w * 3, self.torch.uint8)
+        self.ctx.decode_delta(delta, out=out)
+        self._sync()
+        return out
+
+    # communication views
+    def comm_tensor(self, buf, dev):
+        t = buf.reshape(-1).view(self.torch.uint8)
+        return t if dev.type == "cuda" else t.cpu()
+
+    def host(self, buf):
+        return buf.cpu().numpy() if hasattr(buf, "cpu") else np.asarray(buf)
 
 
 def plan_shards(nt, warm_up, window, world):
     """Contiguous frame ranges [f0, f1) per rank, cut at SWP window starts warm_up + k*window
-    (frames [0, warm_up) stay with rank 0).  Every non-empty shard has >= 2 frames; ranks beyond
-    the number of usable windows get empty shards (f0 == f1)."""
+    (frames [0, warm_up) stay with rank 0).  Every non-empty shard has >= 2 frames (rank 0:
+    >= warm_up + 2, what tz_rollout needs); ranks beyond the number of usable shards get empty
+    ones (f0 == f1)."""
     if window is None or window < 1:
         raise ValueError("only SWP (-w) shards; DWP (-t) finds its windows sequentially")
-    starts = list(range(warm_up, nt, window))
-    if starts and nt - starts[-1] < 2 and len(starts) > 1:
-        starts.pop()  # a trailing single-frame group joins the previous shard
-    g = len(starts)
+    if nt < warm_up + 2:
+        raise ValueError("need at least warm_up+2 frames (nt=%d, warm_up=%d)" % (nt, warm_up))
+    # candidate cut points: window starts that leave >= 2 frames on both sides of the cut
+    # (window == 1 makes one-frame windows: they are grouped)
+    starts = [s for s in range(warm_up + window, nt, window) if s >= warm_up + 2 and nt - s >= 2]
+    kept, prev = [], 0
+    for s in starts:
+        if s - prev >= (warm_up + 2 if prev == 0 else 2):
+            kept.append(s)
+            prev = s
+    g = len(kept) + 1
     used = max(1, min(world, g))
-    cuts = [starts[(i * g) // used] for i in range(used)] + [nt]
-    cuts[0] = 0
+    bounds = [0] + kept
+    cuts = [bounds[(i * g) // used] for i in range(used)] + [nt]
     shards = [(cuts[i], cuts[i + 1]) for i in range(used)]
     shards += [(nt, nt)] * (world - used)
     return shards
@@ -128,109 +192,182 @@ def _all_gather_i64(vals, dist):
     return [o.cpu().numpy() for o in out]
 
 
-def _gather_var(arr, dist, dst=0):
-    """Gather variable-length 1-D arrays on `dst` (padded all_gather of raw bytes: gloo has no
-    int16 tensors; fine for shard-sized data)."""
+def _comm_tensor(engine, buf, dev):
+    """uint8 view of an engine buffer on the communication device (neither NCCL nor gloo has
+    int16 tensors)."""
     import torch
-    dev = _device(dist)
-    arr = np.ascontiguousarray(arr).reshape(-1)
-    raw = arr.view(np.uint8)
-    sizes = [int(v[0]) for v in _all_gather_i64([raw.size], dist)]
-    m = max(max(sizes), 1)
-    buf = np.zeros(m, dtype=np.uint8)
-    buf[: raw.size] = raw
-    t = torch.from_numpy(buf).to(dev)
-    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, t)
-    if dist.get_rank() != dst:
+    if hasattr(engine, "comm_tensor"):
+        return engine.comm_tensor(buf, dev)
+    return torch.from_numpy(np.ascontiguousarray(buf).reshape(-1).view(np.uint8))
+
+
+def _gather_shards(engine, buf, nbytes, dist, dst=0):
+    """Point-to-point gather of the per-rank byte shards (sizes `nbytes`, known to everyone from
+    the shard plan) into one buffer on `dst`: peers send, `dst` receives each shard straight into
+    its slice.  Returns a uint8 tensor on the communication device (dst) / None (others)."""
+    import torch
+    rank, dev = dist.get_rank(), _device(dist)
+    mine = _comm_tensor(engine, buf, dev) if nbytes[rank] else None
+    if rank != dst:
+        if nbytes[rank]:
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, dst)]):
+                q.wait()
         return None
-    return np.concatenate([o.cpu().numpy()[:s] for o, s in zip(out, sizes)]).view(arr.dtype)
+    offs = np.concatenate([[0], np.cumsum(nbytes)]).astype(np.int64)
+    full = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)
+    # ONE group of receives: the shards arrive concurrently over their own xGMI links
+    ops = [dist.P2POp(dist.irecv, full[int(offs[r]): int(offs[r + 1])], r)
+           for r in range(dist.get_world_size()) if r != dst and nbytes[r]]
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if nbytes[rank]:
+        full[int(offs[rank]): int(offs[rank + 1])].copy_(mine)
+    for q in reqs:
+        q.wait()
+    return full
 
 
-def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True):
-    """Every rank passes the same arguments (`frames` may be the full stack or any object whose
-    [f0:f1] slice yields this rank's frames).  Returns (payload, table|None, key_mask) on rank 0,
-    None elsewhere.  The result is byte-identical to a single-GPU tz_rollout + tz_encode."""
+def _typed(full_u8, dtype, to_host):
+    """uint8 gather result -> typed buffer: numpy when it lives on the host (or to_host), else a
+    torch device tensor."""
+    import torch
+    if full_u8.device.type == "cpu":
+        return full_u8.numpy().view(dtype)
+    t = full_u8.view({np.dtype(np.int16): torch.int16, np.dtype(np.uint8): torch.uint8}[np.dtype(dtype)])
+    return t.cpu().numpy() if to_host else t
+
+
+def _raise_if_any_failed(oks, what):
+    bad = [r for r, ok in enumerate(oks) if not ok]
+    if bad:
+        raise RuntimeError("%s failed on rank(s) %s (see that rank's log)" % (what, bad))
+
+
+def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True, nt=None, to_host=True):
+    """Every rank passes the same arguments.  `frames` is the full (nt,H,W,3) stack (anything whose
+    [f0:f1] slice yields frames) or, with `nt` given, a callable (f0, f1) -> this rank's frames
+    (a rank then never sees the others' frames).  Returns (payload, table|None, key_mask) on rank
+    0, None elsewhere; the payload is a numpy array (to_host) or stays in rank 0's HBM.  The result
+    is byte-identical to a single-GPU tz_rollout + tz_encode."""
     import torch
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
-    nt = frames.shape[0]
-    f0, f1 = plan_shards(nt, warm_up, window, world)[rank]
-    if f1 > f0:
-        key, d = engine.encode_delta(np.asarray(frames[f0:f1]), warm_up if rank == 0 else 0, window, mode, bound)
-        d = np.ascontiguousarray(d, np.int16)
-        last = [1, int(d[-1])]
+    if nt is None:
+        nt = frames.shape[0]
+        fetch = lambda a, b: frames[a:b]  # noqa: E731
     else:
-        key, d, last = np.zeros(0, bool), np.zeros(0, np.int16), [0, 0]
-    lasts = _all_gather_i64(last, dist)
+        fetch = frames
+    shards = plan_shards(nt, warm_up, window, world)
+    f0, f1 = shards[rank]
+    klen = max(b - a for a, b in shards)
+    ok, err, key, d, fe = 1, None, np.zeros(0, bool), None, 0
+    try:
+        if f1 > f0:
+            mine = fetch(f0, f1)
+            fe = int(np.prod(mine.shape[1:]))
+            key, d = engine.encode_delta(mine, warm_up if rank == 0 else 0, window, mode, bound)
+    except Exception as e:  # the other ranks are about to enter a collective: tell them
+        ok, err = 0, e
+    head = [ok, int(f1 > f0 and ok), engine_last(engine, d) if (f1 > f0 and ok) else 0, fe]
+    kpad = np.zeros(klen, np.int64)
+    kpad[: len(key)] = np.asarray(key, np.int64)
+    infos = _all_gather_i64(head + kpad.tolist(), dist)
+    if err is not None:
+        raise err
+    _raise_if_any_failed([int(i[0]) for i in infos], "window-sharded encode")
+    fe = max(int(i[3]) for i in infos)
     carry = None
     for r in range(rank - 1, -1, -1):
-        if lasts[r][0]:
-            carry = int(lasts[r][1])
+        if infos[r][1]:
+            carry = int(infos[r][2])
             break
+    hist = np.zeros(NBINS, np.uint64) if entropy else None
+    y = None
     if f1 > f0:
         y, hist = engine.spatial_delta(d, carry, 1 if entropy else 0)
-    else:
-        y, hist = np.zeros(0, np.int16), (np.zeros(NBINS, np.uint64) if entropy else None)
     table = None
     if entropy:
-        dev = _device(dist)
-        h = torch.from_numpy(hist.astype(np.int64)).to(dev)
+        h = torch.from_numpy(np.asarray(hist).astype(np.int64)).to(_device(dist))
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
         table = engine.build_table(h.cpu().numpy().astype(np.uint64))
-        payload = engine.remap(y, table) if f1 > f0 else y
-    else:
-        payload = y
-    full = _gather_var(np.asarray(payload, np.int16), dist)
-    keys = _gather_var(np.asarray(key, np.uint8), dist)
+        if f1 > f0:
+            y = engine.remap(y, table)
+    full = _gather_shards(engine, y, [(b - a) * fe * 2 for a, b in shards], dist)
     if rank != 0:
         return None
-    return full, table, keys.astype(bool)
+    keys = np.concatenate([np.asarray(i[4: 4 + (b - a)]) for i, (a, b) in zip(infos, shards)]).astype(bool)
+    return _typed(full, np.int16, to_host), table, keys
 
 
-def decompress_sharded(engine, key_frames, payload, table, warm_up):
+def engine_last(engine, buf):
+    return engine.last(buf) if hasattr(engine, "last") else int(np.asarray(buf).reshape(-1)[-1])
+
+
+def plan_decode_shards(keys, nt, warm_up, world):
+    """Decoder shards: cut at key frames (decompress.py:123-129), every non-empty shard >= 2 frames."""
+    starts = [k for k in keys if k >= warm_up]
+    if not starts or starts[0] != warm_up:
+        raise ValueError("key frames do not cover the sequence")
+    kept, prev = [], 0
+    for s in starts[1:]:
+        if s - prev >= (warm_up + 2 if prev == 0 else 2) and nt - s >= 2:
+            kept.append(s)
+            prev = s
+    g = len(kept) + 1
+    used = max(1, min(world, g))
+    bounds = [0] + kept
+    cuts = [bounds[(i * g) // used] for i in range(used)] + [nt]
+    return [(cuts[i], cuts[i + 1]) for i in range(used)] + [(nt, nt)] * (world - used)
+
+
+def decompress_sharded(engine, key_frames, payload, table, warm_up, to_host=True):
     """Sharded decode: every rank passes the same key-frame stack, payload and table; rank 0
     gets the (nt, H, W, 3) uint8 frames, other ranks None."""
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
     nt, H, W, C = key_frames.shape
     fe = H * W * C
+    if np.asarray(payload).size != nt * fe:  # decompress.py:240: the reference's reshape raises
+        raise ValueError("payload holds %d elements, the key-frame stack implies %d" % (np.asarray(payload).size, nt * fe))
     # decompress.py:123-129: key frames are the frames with a non-zero sample
     keys = [i for i in range(nt) if np.asarray(key_frames[i]).any()]
-    starts = [k for k in keys if k >= warm_up]
-    if not starts or starts[0] != warm_up:
-        raise ValueError("key frames do not cover the sequence")
-    g = len(starts)
-    used = max(1, min(world, g))
-    cuts = [starts[(i * g) // used] for i in range(used)] + [nt]
-    cuts[0] = 0
-    shards = [(cuts[i], cuts[i + 1]) for i in range(used)] + [(nt, nt)] * (world - used)
+    shards = plan_decode_shards(keys, nt, warm_up, world)
     f0, f1 = shards[rank]
     payload = np.asarray(payload, np.int16).reshape(-1)
-    info = [0, 0, 0]
-    sd = None
-    if f1 > f0:
-        engine.decode_prepare(np.asarray(key_frames[f0:f1]), warm_up if rank == 0 else 0)
-        part = payload[f0 * fe: f1 * fe]
-        sd = engine.unmap(part, table) if table is not None else np.ascontiguousarray(part)
-        if rank == 0:
-            delta = engine.undelta(sd, None)
-            info = [1, int(delta[-1]), 0]            # decoded value at the end of shard 0
-        else:
-            probe = engine.undelta(sd, 0)            # x = 0 - prefix sums  =>  last = -(shard sum)
-            info = [1, 0, (-int(probe[-1])) & 0xFFFF]
+    info, sd, delta, err = [1, 0, 0, 0], None, None, None
+    try:
+        if f1 > f0:
+            engine.decode_prepare(np.asarray(key_frames[f0:f1]), warm_up if rank == 0 else 0)
+            part = payload[f0 * fe: f1 * fe]
+            if table is not None:
+                sd = engine.unmap(part, table)
+            else:
+                sd = engine.upload(part) if hasattr(engine, "upload") else np.ascontiguousarray(part)
+            if rank == 0:
+                delta = engine.undelta(sd, None)
+                info = [1, 1, engine_last(engine, delta), 0]   # decoded value at the end of shard 0
+            else:
+                probe = engine.undelta(sd, 0)                   # x = 0 - prefix sums  =>  last = -(shard sum)
+                info = [1, 1, 0, (-engine_last(engine, probe)) & 0xFFFF]
+    except Exception as e:
+        info, err = [0, 0, 0, 0], e
     infos = _all_gather_i64(info, dist)
-    frames = np.zeros((0, H, W, C), np.uint8)
+    if err is not None:
+        raise err
+    _raise_if_any_failed([int(i[0]) for i in infos], "window-sharded decode")
+    frames = None
     if f1 > f0:
         if rank > 0:
-            x_end = int(infos[0][1])
+            x_end = int(infos[0][2])
             for r in range(1, rank):
-                if infos[r][0]:
-                    x_end = (x_end - int(infos[r][2])) & 0xFFFF
+                if infos[r][1]:
+                    x_end = (x_end - int(infos[r][3])) & 0xFFFF
             carry = x_end - 65536 if x_end >= 32768 else x_end
             delta = engine.undelta(sd, carry)
-        frames = engine.reconstruct(np.asarray(delta, np.int16).reshape(f1 - f0, H, W, C))
-    out = _gather_var(np.asarray(frames, np.uint8), dist)
+        if isinstance(delta, np.ndarray):
+            delta = delta.reshape(f1 - f0, H, W, C)
+        frames = engine.reconstruct(delta)
+    full = _gather_shards(engine, frames, [(b - a) * fe for a, b in shards], dist)
     if rank != 0:
         return None
+    out = _typed(full, np.uint8, to_host)
     return out.reshape(nt, H, W, C)
