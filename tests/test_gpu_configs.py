@@ -1,0 +1,177 @@
+"""Every BASELINE.json configuration as a WORKLOAD on the MI355X, with the FULL reference model
+(PredNet (3,48,96,192), train.py:51-55; glorot weights seed 123 -- the reference ships none):
+
+  cfg1  64x64 'L' moving blobs, nt=40, -p 0 -w 20, lossless     end to end against the C oracle
+  cfg2  128x160 RGB KITTI-like, nt=40, -p 0 -w 10, lossless     end to end against the C oracle
+  cfg3  512x512 RGB turbulence, nt=80, -w 20, `rel 1e-3`/`abs 2` round trip + a depth-19 prediction,
+                                                                 a quantised frame and the stream head vs the oracle
+  cfg5  512x512, lossless: DWP with a threshold that gives 5..40-frame windows, and the SWP sweep
+        -w in {5,...,40} (tezip_amd/sweep.py)
+(cfg4, 320 x 1024x1024, -w 40, `abs 2`: tests/test_gpu_fullsize.py::test_cfg4_full_length_on_one_gpu.)
+
+"End to end against the oracle" = key mask, pre-zstd entropy stream (payload + table + trailer),
+key-frame stream and the decoded frames are compared byte for byte with oracle/oracle.py driven
+by the C PredNet (oracle/tz_oracle.c); at 512x512 the oracle needs > 1 s per frame, so cfg3/cfg5
+use properties plus spot checks."""
+import numpy as np
+import pytest
+
+from oracle import coracle
+from oracle import oracle as O
+from tezip_amd import compress, decompress, synth, sweep, zstd
+from tezip_amd.prednet import PredNetConfig
+
+pytestmark = pytest.mark.gpu
+
+CFG = PredNetConfig()
+WTS = CFG.init_weights(seed=123)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tezip_amd import _lib
+    c = _lib.Context(0)
+    c.load_model(CFG, WTS)
+    yield c
+    c.close()
+
+
+class _Oracle:
+    def __init__(self, hp, wp):
+        self.net = coracle.CPredNet(WTS, CFG.stack_sizes, CFG.R_stack_sizes, hp, wp)
+
+    def c0(self, a, b):
+        return self.net.c0()
+
+    def next(self, f):
+        return self.net.next(np.asarray(f, np.float32))
+
+
+def _end_to_end_vs_oracle(ctx, frames, p, window, mode, bound):
+    nt, h, w = frames.shape[:3]
+    hp, wp = (h + 7) // 8 * 8, (w + 7) // 8 * 8
+    pred = _Oracle(hp, wp)
+    ref = O.compress_oracle(frames, p, window, None, mode, bound, pred, True)
+    ctx.prepare(hp, wp, max_batch=(nt - p + window - 1) // window)
+    key, _ = ctx.rollout(frames, p, window)
+    np.testing.assert_array_equal(key, ref["key"])
+    payload, table, _ = ctx.encode(mode, bound, True)
+    stream = compress.build_stream(payload, table, (1, nt, h, w, 3), p)
+    np.testing.assert_array_equal(stream, ref["stream"])            # what entropy.dat holds before zstd
+    key_stack = np.zeros_like(frames)
+    key_stack[key] = frames[key]
+    np.testing.assert_array_equal(key_stack.reshape(-1), ref["key_frame"])  # what key_frame.dat holds before zstd
+    pl, tb, shape, warm = decompress.parse_stream(stream.tobytes())
+    decompress.check_stream(shape, warm, pl.size, key_stack.size)
+    ctx.rollout_decode(key_stack, warm)
+    dec = ctx.decode(np.ascontiguousarray(pl), np.ascontiguousarray(tb))
+    np.testing.assert_array_equal(dec, O.decode_stream(ref["stream"], ref["key_frame"], pred))
+    return dec, key
+
+
+def test_cfg1_64x64_w20_lossless_end_to_end_vs_oracle(ctx):
+    frames = synth.moving_blobs(40, 64, 64, seed=1)   # 'L' source expanded to RGB (compress.py:114)
+    dec, key = _end_to_end_vs_oracle(ctx, frames, 0, 20, "abs", [0.0])
+    assert key.nonzero()[0].tolist() == [0, 20] and np.array_equal(dec, frames)
+
+
+def test_cfg2_128x160_w10_lossless_end_to_end_vs_oracle(ctx):
+    frames = synth.translating_scene(40, 128, 160, seed=2)
+    dec, key = _end_to_end_vs_oracle(ctx, frames, 0, 10, "abs", [0.0])
+    assert key.nonzero()[0].tolist() == [0, 10, 20, 30] and np.array_equal(dec, frames)
+
+
+def test_cfg3_512_nt80_w20_workload(ctx):
+    frames = synth.turbulence(80, 512, 512, seed=3)
+    ctx.prepare(512, 512, max_batch=4)
+    key, _ = ctx.rollout(frames, 0, 20)
+    assert key.nonzero()[0].tolist() == [0, 20, 40, 60]
+    enc_pred = ctx.get_predictions()
+    key_stack = np.zeros_like(frames)
+    key_stack[key] = frames[key]
+    results = {}
+    for mode, bound, tol in (("rel", [1e-3], 0), ("abs", [2.0], 3)):
+        payload, table, delta = ctx.encode(mode, bound, True, want_delta=True)
+        assert 0 < len(table) <= 1021 and int(payload.min()) >= 0 and int(payload.max()) < len(table)
+        assert (delta[key] == 0).all()
+        results[mode] = (payload, table, delta)
+    # oracle spot checks on the encoder side: a depth-19 prediction (the deepest recursion of a
+    # 20-frame window), a quantised frame of 3 x 262,144-element chains, the head of the stream
+    net = coracle.CPredNet(WTS, CFG.stack_sizes, CFG.R_stack_sizes, 512, 512)
+    cur = coracle.u8_to_f32_frame(frames[0], 512, 512)
+    for d in range(1, 20):
+        cur = net.next(cur)
+        if d in (1, 10):
+            np.testing.assert_array_equal(enc_pred[d], cur, err_msg="depth %d" % d)
+    np.testing.assert_array_equal(enc_pred[19], cur, err_msg="depth 19")
+    raw19 = coracle.delta_frame(cur, frames[19])
+    np.testing.assert_array_equal(results["abs"][2][19], coracle.error_bound_frame(frames[19], raw19, "abs", [2.0]))
+    np.testing.assert_array_equal(results["rel"][2][19], coracle.error_bound_frame(frames[19], raw19, "rel", [1e-3]))
+    # decoder: regenerates the encoder's predictions bit for bit; lossless / within the bound
+    ctx.rollout_decode(key_stack, 0)
+    assert np.array_equal(ctx.get_predictions()[~key], enc_pred[~key])
+    for mode, tol in (("rel", 0), ("abs", 3)):
+        dec = ctx.decode(results[mode][0], results[mode][1])
+        err = int(np.abs(dec.astype(np.int16) - frames.astype(np.int16)).max())
+        assert err <= tol, (mode, err)
+
+
+def _windows(key, nt):
+    k = key.nonzero()[0].tolist()
+    return [b - a for a, b in zip(k, k[1:] + [nt])]
+
+
+def test_cfg5_512_dwp_lossless_windows_5_to_40(ctx):
+    frames = synth.turbulence(80, 512, 512, seed=3)
+    fe_pad = 512 * 512 * 3
+    ctx.prepare(512, 512, max_batch=1)
+    _, probe = ctx.rollout(frames[:41], 0, None, 1e9, want_mse=True)   # one 41-frame window: the MSE curve
+    assert (np.diff(probe[1:]) > 0).all()                               # recursion error grows with depth
+    key = None
+    for depth in (12, 16, 20, 8, 24, 30):                               # a threshold reached at about that depth
+        thr = float(probe[depth])
+        key, mse = ctx.rollout(frames, 0, None, thr, want_mse=True)
+        lens = _windows(key, 80)
+        if all(5 <= n <= 40 for n in lens[:-1]) and lens[-1] <= 40 and len(lens) > 2:
+            break
+    else:
+        pytest.fail("no threshold gave 5..40-frame windows: %r" % (lens,))
+    # the decisions replayed from the device's own predictions (compress.py:245-263)
+    pred = ctx.get_predictions()
+    sse = ctx.window_sse(frames, pred)
+    run, k0, expect = 0.0, 1, [0]
+    for idx in range(1, 80):
+        run += sse[idx]
+        stop = run / ((idx - k0 + 1) * fe_pad)
+        assert stop == pytest.approx(mse[idx], rel=1e-12)
+        if stop > thr:
+            expect.append(idx)
+            k0, run = idx + 1, 0.0
+    assert key.nonzero()[0].tolist() == expect   # a rejected frame becomes the next key frame
+    payload, table, _ = ctx.encode("abs", [0.0], True)
+    key_stack = np.zeros_like(frames)
+    key_stack[key] = frames[key]
+    kd = ctx.rollout_decode(key_stack, 0)
+    assert (kd == key).all() and np.array_equal(ctx.get_predictions()[~key], pred[~key])
+    assert np.array_equal(ctx.decode(payload, table), frames)
+
+
+def test_cfg5_512_swp_sweep_5_to_40_lossless(ctx):
+    frames = synth.turbulence(80, 512, 512, seed=3)
+    rows, (best_w, key_bytes, ent_bytes) = sweep.sweep(ctx, frames, 0, sweep.DEFAULT_WINDOWS, "abs", [0.0])
+    assert [r["window"] for r in rows] == list(sweep.DEFAULT_WINDOWS)
+    for r in rows:
+        n_windows = (80 + r["window"] - 1) // r["window"]
+        assert r["key_frames"] in (n_windows, n_windows + 1)  # + the last frame when it starts a window
+    best = min(rows, key=lambda r: (r["total_bytes"], r["window"]))
+    assert best["window"] == best_w and len(key_bytes) == best["key_bytes"] and len(ent_bytes) == best["entropy_bytes"]
+    # more key frames cost key_frame.dat bytes monotonically
+    kb = [r["key_bytes"] for r in rows]
+    assert all(a >= b for a, b in zip(kb, kb[1:]))
+    # the kept output is a complete reference-format pair: decode it
+    key_stack = np.frombuffer(zstd.decompress(key_bytes), np.uint8).reshape(frames.shape)
+    pl, tb, shape, warm = decompress.parse_stream(zstd.decompress(ent_bytes))
+    decompress.check_stream(shape, warm, pl.size, key_stack.size)
+    ctx.prepare(512, 512, max_batch=min(64, (80 + best_w - 1) // best_w))
+    ctx.rollout_decode(np.ascontiguousarray(key_stack), warm)
+    assert np.array_equal(ctx.decode(np.ascontiguousarray(pl), np.ascontiguousarray(tb)), frames)

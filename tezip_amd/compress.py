@@ -96,6 +96,25 @@ def build_stream(payload, table, shape5, warm_up):
     return np.concatenate([np.asarray(payload, dtype=np.int16).reshape(-1), trailer])
 
 
+def pack_outputs(frames, key, payload, table, warm_up):
+    """compress.py:271-278 and 375-400: the two zstd-9 frames (key_frame.dat, entropy.dat) as bytes."""
+    nt, H, W = frames.shape[:3]
+    key_frame = np.zeros_like(frames)
+    key_frame[key] = frames[key]
+    key_bytes = zstd.compress_array(key_frame, 9, zstd.default_threads())
+    stream = build_stream(payload, table, (1, nt, H, W, 3), warm_up)
+    return key_bytes, zstd.compress_array(stream, 9, zstd.default_threads())
+
+
+def write_outputs(out_dir, frames, key, payload, table, warm_up):
+    key_bytes, entropy_bytes = pack_outputs(frames, key, payload, table, warm_up)
+    with open(os.path.join(out_dir, "key_frame.dat"), mode='wb') as f:
+        f.write(key_bytes)
+    with open(os.path.join(out_dir, "entropy.dat"), mode='wb') as f:
+        f.write(entropy_bytes)
+    return len(key_bytes), len(entropy_bytes)
+
+
 def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, MODE, BOUND_VALUE, GPU_FLAG, VERBOSE,
         ENTROPY_RUN, device=0):
     if not GPU_FLAG:
@@ -165,13 +184,6 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
                 if ENTROPY_RUN:
                     print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
 
-        # key frames (compress.py:271-278)
-        key_frame = np.zeros_like(origine_img)
-        key_frame[key] = origine_img[key]
-        with open(os.path.join(OUTPUT_DIR, "key_frame.dat"), mode='wb') as f:
-            f.write(zstd.compress_array(key_frame, 9, zstd.default_threads()))
-        stream = build_stream(payload, table if ENTROPY_RUN else None, (1, nt, H, W, 3), PREPROCESS)
-        with open(os.path.join(OUTPUT_DIR, "entropy.dat"), mode='wb') as f:
-            f.write(zstd.compress_array(stream, 9, zstd.default_threads()))
+        write_outputs(OUTPUT_DIR, origine_img, key, payload, table if ENTROPY_RUN else None, PREPROCESS)
     finally:
         ctx.close()

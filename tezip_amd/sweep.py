@@ -1,0 +1,116 @@
+"""SWP window-size sweep (BASELINE.json configs[4] "dynamic window-size search (window=5..40)",
+SURVEY.md §8d.5).
+
+The reference has no search: `-w` fixes the window (compress.py:249) and `-t` lets the window MSE
+cut it (DWP).  "Search" is therefore run as what a user of the reference would do by hand:
+compress the same stack once per candidate `-w`, keep the smallest output.  Candidates are
+independent jobs, so they shard over the GPUs of a node with nothing exchanged but the resulting
+sizes (one value per GPU for the 8 values 5,10,...,40 on 8 GPUs); every candidate's output is
+exactly what `tezip.py -c ... -w <value>` writes.
+"""
+import os
+
+import numpy as np
+
+from . import _lib
+from . import dist as tzdist
+from .compress import pack_outputs
+
+DEFAULT_WINDOWS = (5, 10, 15, 20, 25, 30, 35, 40)
+
+
+def sweep(ctx, frames, warm_up, windows, mode, bound, entropy=True, keep_best=True):
+    """Compress `frames` (nt,H,W,3 uint8, host) once per window size on this context.
+    Returns (rows, best) with rows = [{window, key_frames, key_bytes, entropy_bytes, total_bytes}]
+    and best = (window, key_frame.dat bytes, entropy.dat bytes) of the smallest total (ties: the
+    smaller window)."""
+    nt, h, w = frames.shape[:3]
+    hp, wp = _lib.pad8(h), _lib.pad8(w)
+    rows, best = [], None
+    for win in windows:
+        if win < 1:
+            raise ValueError("window sizes must be >= 1")
+        nwin = max(1, (nt - warm_up + win - 1) // win)
+        ctx.prepare(hp, wp, min(nwin, 64))
+        key, _ = ctx.rollout(frames, warm_up, win)
+        payload, table, _ = ctx.encode(mode, bound, entropy)
+        kb, eb = pack_outputs(frames, key, payload, table if entropy else None, warm_up)
+        row = dict(window=int(win), key_frames=int(key.sum()), key_bytes=len(kb), entropy_bytes=len(eb),
+                   total_bytes=len(kb) + len(eb))
+        rows.append(row)
+        if best is None or row["total_bytes"] < best[0]["total_bytes"]:
+            best = (row, kb if keep_best else None, eb if keep_best else None)
+    return rows, (best[0]["window"], best[1], best[2])
+
+
+def sweep_sharded(ctx, frames, warm_up, windows, mode, bound, entropy=True):
+    """The same over the ranks of a torch.distributed job: rank r takes windows[r::world]; the
+    sizes are all-gathered; returns (rows of every candidate sorted by window, best_window,
+    (key bytes, entropy bytes) on the rank that holds the best candidate else None)."""
+    job = tzdist.active()
+    if job is None:
+        rows, (bw, kb, eb) = sweep(ctx, frames, warm_up, windows, mode, bound, entropy)
+        return rows, bw, (kb, eb)
+    import torch.distributed as dist
+    rank, world = job
+    mine = list(windows)[rank::world]
+    rows, best = (sweep(ctx, frames, warm_up, mine, mode, bound, entropy) if mine else ([], (None, None, None)))
+    per = max(1, (len(windows) + world - 1) // world)
+    flat = np.full(per * 4, -1, np.int64)
+    for i, r in enumerate(rows):
+        flat[4 * i: 4 * i + 4] = [r["window"], r["key_frames"], r["key_bytes"], r["entropy_bytes"]]
+    allrows = []
+    for v in tzdist._all_gather_i64(flat.tolist(), dist):
+        for i in range(per):
+            wv, kf, kbytes, ebytes = (int(x) for x in v[4 * i: 4 * i + 4])
+            if wv > 0:
+                allrows.append(dict(window=wv, key_frames=kf, key_bytes=kbytes, entropy_bytes=ebytes,
+                                    total_bytes=kbytes + ebytes))
+    allrows.sort(key=lambda r: r["window"])
+    bw = min(allrows, key=lambda r: (r["total_bytes"], r["window"]))["window"]
+    return allrows, bw, ((best[1], best[2]) if best[0] == bw else None)
+
+
+def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOWS, MODE, BOUND_VALUE, VERBOSE, ENTROPY_RUN, device=0):
+    """`tezip.py -c model dir out -p P --sweep 5 10 ... -m MODE -b ...`: writes the output of the
+    best window (same three files as compress.run) plus sweep.txt with every candidate's size."""
+    from .compress import load_images, make_context, open_model
+    from .data_utils import padding_shape
+    frames, files, is_rgb = load_images(DATA_DIR)
+    nt, H, W = frames.shape[:3]
+    cfg, wts, _ = open_model(WEIGHTS_DIR)
+    hp, wp = padding_shape(H, W)
+    job = tzdist.active()
+    if job:
+        device = tzdist.init_from_env()
+    ctx = make_context(cfg, wts, hp, wp, 1, device)
+    try:
+        rows, bw, blobs = sweep_sharded(ctx, frames, PREPROCESS, list(WINDOWS or DEFAULT_WINDOWS), MODE, BOUND_VALUE, ENTROPY_RUN)
+    finally:
+        ctx.close()
+    rank0 = job is None or job[0] == 0
+    if rank0 and not os.path.exists(OUTPUT_DIR):
+        os.mkdir(OUTPUT_DIR)
+    if job:
+        import torch.distributed as dist
+        dist.barrier()  # the directory exists before the owner of the best candidate writes into it
+    if blobs is not None:
+        with open(os.path.join(OUTPUT_DIR, "key_frame.dat"), "wb") as f:
+            f.write(blobs[0])
+        with open(os.path.join(OUTPUT_DIR, "entropy.dat"), "wb") as f:
+            f.write(blobs[1])
+    if rank0:
+        with open(os.path.join(OUTPUT_DIR, 'filename.txt'), 'w', encoding='UTF-8') as f:
+            f.write(f"{int(is_rgb)}\n")
+            for name in files:
+                f.write("%s\n" % name)
+        raw = nt * H * W * (3 if is_rgb else 1)
+        with open(os.path.join(OUTPUT_DIR, "sweep.txt"), "w") as f:
+            for r in rows:
+                line = "window %d: key frames %d, key_frame.dat %d B, entropy.dat %d B, ratio %.4f%s" % (
+                    r["window"], r["key_frames"], r["key_bytes"], r["entropy_bytes"], raw / float(r["total_bytes"]),
+                    "  <- best" if r["window"] == bw else "")
+                f.write(line + "\n")
+                if VERBOSE:
+                    print(line)
+    return rows, bw

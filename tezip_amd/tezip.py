@@ -30,6 +30,9 @@ FLAG_TABLE = (
     ("-f", "--force", dict(action="store_true")),
     ("-v", "--verbose", dict(action="store_true")),
     ("-n", "--no_entropy", dict(action="store_false")),  # store_false: entropy remap is on by default
+    # not in the reference: compress once per candidate -w and keep the smallest output (BASELINE.json configs[4];
+    # tezip_amd/sweep.py).  No value = 5 10 15 20 25 30 35 40.  Takes the place of -w / -t.
+    (None, "--sweep", dict(type=int, nargs="*", metavar="window_size", dest="sweep", default=None)),
 )
 
 TEXT = {
@@ -53,7 +56,7 @@ BOUNDS_WANTED = {"abs": 1, "rel": 1, "pwrel": 1, "absrel": 2}
 def build_parser():
     parser = argparse.ArgumentParser(prog="TEZIP", formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     for short, long_, kw in FLAG_TABLE:
-        parser.add_argument(short, long_, **kw)
+        parser.add_argument(*([short, long_] if short else [long_]), **kw)
     return parser
 
 
@@ -80,7 +83,7 @@ def check_compress(arg):
     of the message to print; prints the mode name where the reference does."""
     if arg.preprocess is None:
         return "no_p"
-    have_w, have_t = arg.window is not None, arg.threshold is not None
+    have_w, have_t = arg.window is not None or getattr(arg, "sweep", None) is not None, arg.threshold is not None
     if not have_w and not have_t:
         return "no_window"
     if have_w and have_t:
@@ -120,6 +123,10 @@ def main(arg):
     if problem:
         return complain(problem)
     model, src, dst = arg.compress
+    if arg.sweep is not None and arg.window is None:
+        from . import sweep
+        return sweep.run(model, src, dst, arg.preprocess[0], arg.sweep or None, arg.mode[0], arg.bound, arg.verbose,
+                         arg.no_entropy)
     window = arg.window[0] if arg.window is not None else None
     threshold = arg.threshold[0] if arg.threshold is not None else None
     return compress.run(model, src, dst, arg.preprocess[0], window, threshold, arg.mode[0], arg.bound, gpu,
