@@ -62,12 +62,38 @@ def test_padding_helpers_match_reference():
 
 
 def test_model_dir_roundtrip_and_keras_style_json(tmp_path):
+    import json
     cfg = PredNetConfig()
     w = cfg.init_weights(seed=2, bias_scale=0.1)
     weights.save_model(str(tmp_path), cfg, w, 128, 160)
+    # the reference's two files (train.py:109,114-117), nothing else
+    assert sorted(os.listdir(tmp_path)) == ["prednet_model.json", "prednet_weights.hdf5"]
     cfg2, w2, shape = weights.load_model(str(tmp_path))
     assert cfg2.stack_sizes == (3, 48, 96, 192) and shape == (128, 160)
     assert all((a == b).all() for a, b in zip(w, w2))
+    # model.to_json() schema of the training graph (train.py:62-71)
+    mj = json.loads(open(tmp_path / "prednet_model.json").read())
+    layers = mj["config"]["layers"]
+    assert [l["class_name"] for l in layers] == ["InputLayer", "PredNet", "TimeDistributed", "Flatten", "Dense"]
+    assert layers[0]["config"]["batch_input_shape"] == [None, 2, 128, 160, 3]      # compress.py:168
+    assert layers[1]["config"]["output_mode"] == "error" and layers[1]["config"]["data_format"] == "channels_last"
+    assert layers[2]["config"]["layer"]["class_name"] == "Dense" and mj["keras_version"] == "2.2.4"
+    assert mj["config"]["output_layers"] == [["dense_2", 0, 0]] and layers[4]["inbound_nodes"] == [[["flatten_1", 0, 0, {}]]]
+    # a stale converted copy must not shadow the reference's file
+    other = cfg.init_weights(seed=99)
+    np.savez(tmp_path / "prednet_weights.npz", **{"w%03d" % i: x for i, x in enumerate(other)})
+    _, w3, _ = weights.load_model(str(tmp_path))
+    assert all((a == b).all() for a, b in zip(w, w3))
+    os.remove(tmp_path / "prednet_weights.hdf5")      # legacy directory: only the npz
+    _, w4, _ = weights.load_model(str(tmp_path))
+    assert all((a == b).all() for a, b in zip(other, w4))
+    # activations the kernels do not implement are refused, not silently replaced (prednet.py:95-98)
+    for key, val in (("LSTM_activation", "relu"), ("LSTM_inner_activation", "sigmoid"), ("A_activation", "tanh"),
+                     ("error_activation", "linear"), ("extrap_start_time", 5)):
+        bad = json.loads(weights.make_model_json(cfg, 128, 160))
+        bad["config"]["layers"][1]["config"][key] = val
+        with pytest.raises(NotImplementedError):
+            weights.parse_model_json(json.dumps(bad))
     # a json shaped like Keras 2.2.4's model.to_json() with extra layers (train.py:63-70)
     js = ('{"class_name":"Model","config":{"layers":[{"class_name":"InputLayer","config":{"batch_input_shape":'
           '[null,2,64,64,3]}},{"class_name":"PredNet","config":{"stack_sizes":[3,48,96,192],"R_stack_sizes":[3,48,96,192],'
@@ -174,3 +200,33 @@ def test_corrupt_or_truncated_streams_are_rejected_before_the_native_call():
     with pytest.raises(ValueError):
         p2, t2, shape2, warm2 = decompress.parse_stream(cut)
         decompress.check_stream(shape2, warm2, p2.size, 2 * 4 * 5 * 3)
+
+
+def test_hdf5_written_here_is_read_by_real_h5py(tmp_path):
+    """The "and back" half of the model import/export row: prednet_weights.hdf5 written by
+    tezip_amd/h5lite.py, opened by libhdf5 through h5py (conda interpreter of the build container)
+    following Keras 2.2.4's load_weights traversal.  Skipped where that interpreter is missing."""
+    import hashlib
+    import subprocess
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py) or subprocess.run([py, "-c", "import h5py"], capture_output=True).returncode != 0:
+        pytest.skip("no interpreter with h5py on this machine")
+    cfg = PredNetConfig()
+    w = cfg.init_weights(seed=31, bias_scale=0.2)
+    weights.save_model(str(tmp_path), cfg, w, 64, 64)
+    r = subprocess.run([py, os.path.join(GOLDEN, "check_h5_with_h5py.py"), str(tmp_path / "prednet_weights.hdf5")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "keras_version 2.2.4 backend tensorflow"
+    assert lines[1] == "layers input_1,pred_net_1,time_distributed_1,flatten_1,dense_2"
+    h = hashlib.sha1()
+    for a in w:
+        h.update(np.ascontiguousarray(a, np.float32).tobytes())
+    got = dict((l.split()[0], l.split()[1:]) for l in lines[2:])
+    assert got["pred_net_1"][:2] == ["46", h.hexdigest()]
+    assert got["pred_net_1"][2:] == ["pred_net_1/layer_a_0/kernel:0", "pred_net_1/layer_o_3/bias:0"]  # prednet.py:212 order
+    assert got["time_distributed_1"][0] == "2" and got["dense_2"][0] == "2"
+    # and the built-in reader returns the same arrays from the same file
+    _, back, _ = weights.load_model(str(tmp_path))
+    assert all((a == b).all() for a, b in zip(w, back))

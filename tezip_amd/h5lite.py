@@ -171,3 +171,189 @@ def load_prednet_weights(path, names):
             raise ValueError("cannot locate %s in %s (%d matches)" % (n, path, len(hit)))
         out.append(hit[0].astype(np.float32))
     return out
+
+
+# ------------------------------------------------------------------------------------- writer
+# The mirror image of the reader: the same HDF5 subset (superblock v0, old-style groups, object
+# headers v1, contiguous little-endian float datasets) plus fixed-length string attributes, which
+# is all Keras 2.2.4's `load_weights` / `load_weights_from_hdf5_group` looks at
+# (`layer_names`, `weight_names`, `keras_version`, `backend`).  Written files are read back by real
+# h5py / libhdf5 (tests/test_host.py runs that check with the conda interpreter when it exists).
+LEAF_K, INTERNAL_K = 16, 16   # symbol-table node holds 2*LEAF_K entries: every group fits one node
+
+
+class Group:
+    def __init__(self, attrs=None):
+        self.attrs = dict(attrs or {})   # name -> bytes (scalar string) | list of bytes (1-D string array)
+        self.children = {}               # name -> Group | numpy array
+
+    def group(self, name, attrs=None):
+        g = self.children[name] = Group(attrs)
+        return g
+
+    def dataset(self, name, arr):
+        self.children[name] = np.ascontiguousarray(arr)
+
+
+def _pad8(b):
+    return b + b"\x00" * (-len(b) % 8)
+
+
+def _string_dtype(size):
+    return bytes([0x13, 0x01, 0, 0]) + struct.pack("<I", max(size, 1))  # fixed string, null padded, ASCII
+
+
+def _float_dtype(itemsize):
+    if itemsize == 4:
+        prop = struct.pack("<HHBBBBI", 0, 32, 23, 8, 0, 23, 127)
+        return bytes([0x11, 0x20, 31, 0]) + struct.pack("<I", 4) + prop
+    prop = struct.pack("<HHBBBBI", 0, 64, 52, 11, 0, 52, 1023)
+    return bytes([0x11, 0x20, 63, 0]) + struct.pack("<I", 8) + prop
+
+
+def _dataspace(shape):
+    return bytes([1, len(shape), 0, 0, 0, 0, 0, 0]) + b"".join(struct.pack("<Q", d) for d in shape)
+
+
+def _attr_message(name, value):
+    if isinstance(value, (bytes, str)):
+        v = value.encode() if isinstance(value, str) else value
+        size, shape, data = max(len(v), 1), (), v.ljust(max(len(v), 1), b"\x00")
+    else:
+        items = [x.encode() if isinstance(x, str) else bytes(x) for x in value]
+        size = max([len(x) for x in items] + [1])
+        shape, data = (len(items),), b"".join(x.ljust(size, b"\x00") for x in items)
+    nm = name.encode() + b"\x00"
+    dt, ds = _string_dtype(size), _dataspace(shape)
+    head = struct.pack("<BBHHH", 1, 0, len(nm), len(dt), len(ds))
+    return 0x0C, head + _pad8(nm) + _pad8(dt) + _pad8(ds) + data
+
+
+def _object_header(messages):
+    body = b""
+    for mtype, payload in messages:
+        p = _pad8(payload)
+        if len(p) > 0xFFF8:
+            raise ValueError("HDF5 header message too large (%d bytes)" % len(p))
+        body += struct.pack("<HHB3x", mtype, len(p), 0) + p
+    return struct.pack("<BBHII4x", 1, 0, len(messages), 1, len(body)) + body
+
+
+class _Writer:
+    def __init__(self):
+        self.buf = bytearray(96)  # superblock goes here at the end
+
+    def alloc(self, data):
+        off = len(self.buf)
+        self.buf += _pad8(bytes(data))
+        return off
+
+    def reserve(self, n):
+        off = len(self.buf)
+        self.buf += b"\x00" * ((n + 7) & ~7)
+        return off
+
+    def put(self, off, data):
+        self.buf[off:off + len(data)] = data
+
+    def write_dataset(self, arr):
+        if arr.dtype not in (np.float32, np.float64):
+            raise NotImplementedError("only float32/float64 datasets")
+        raw = self.alloc(arr.astype(arr.dtype.newbyteorder("<")).tobytes()) if arr.size else UNDEF
+        msgs = [(0x01, _dataspace(arr.shape)), (0x03, _float_dtype(arr.dtype.itemsize)),
+                (0x05, bytes([2, 2, 2, 0])),  # fill value v2: late allocation, written if set, none defined
+                (0x08, bytes([3, 1]) + struct.pack("<QQ", raw, arr.nbytes))]
+        return self.alloc(_object_header(msgs))
+
+    def write_group(self, g):
+        """-> (object header address, b-tree address, heap address)"""
+        names = sorted(g.children, key=lambda s: s.encode())
+        if len(names) > 2 * LEAF_K:
+            raise NotImplementedError("more than %d entries in one group" % (2 * LEAF_K))
+        kids = {}
+        for n in names:  # children first: their addresses go into the symbol table node
+            c = g.children[n]
+            kids[n] = self.write_group(c) if isinstance(c, Group) else (self.write_dataset(c), None, None)
+        heap_data, offs = bytearray(8), {}
+        for n in names:
+            offs[n] = len(heap_data)
+            heap_data += _pad8(n.encode() + b"\x00")
+        free_off = len(heap_data)
+        free_len = max(16, 88 - len(heap_data) if len(heap_data) < 72 else 16)
+        heap_data += struct.pack("<QQ", 1, free_len) + b"\x00" * (free_len - 16)
+        data_addr = self.alloc(heap_data)
+        heap = self.alloc(b"HEAP" + bytes(4) + struct.pack("<QQQ", len(heap_data), free_off, data_addr))
+        snod = b"SNOD" + struct.pack("<BBH", 1, 0, len(names))
+        for n in names:
+            hdr, bt, hp = kids[n]
+            if bt is None:
+                snod += struct.pack("<QQII16x", offs[n], hdr, 0, 0)
+            else:
+                snod += struct.pack("<QQIIQQ", offs[n], hdr, 1, 0, bt, hp)
+        snod = snod.ljust(8 + 2 * LEAF_K * 40, b"\x00")
+        tree = b"TREE" + struct.pack("<BBHQQ", 0, 0, 1 if names else 0, UNDEF, UNDEF)
+        if names:
+            snod_addr = self.alloc(snod)
+            tree += struct.pack("<QQQ", 0, snod_addr, offs[names[-1]])
+        tree = tree.ljust(24 + (2 * INTERNAL_K + 1) * 8 + 2 * INTERNAL_K * 8, b"\x00")
+        btree = self.alloc(tree)
+        msgs = [(0x11, struct.pack("<QQ", btree, heap))] + [_attr_message(k, v) for k, v in g.attrs.items()]
+        return self.alloc(_object_header(msgs)), btree, heap
+
+    def finish(self, root):
+        hdr, bt, hp = self.write_group(root)
+        sb = SIG + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + struct.pack("<HHI", LEAF_K, INTERNAL_K, 0)
+        sb += struct.pack("<QQQQ", 0, UNDEF, len(self.buf), UNDEF)
+        sb += struct.pack("<QQIIQQ", 0, hdr, 1, 0, bt, hp)
+        assert len(sb) == 96
+        self.put(0, sb)
+        return bytes(self.buf)
+
+
+def write_file(path, root):
+    data = _Writer().finish(root)
+    with open(path, "wb") as f:
+        f.write(data)
+
+
+def save_prednet_checkpoint(path, cfg, weights, nt=2, model_config=None):
+    """Writes `prednet_weights.hdf5` in the layout of the reference's Keras 2.2.4
+    `ModelCheckpoint` (train.py:109: a full-model file, weights under /model_weights): layers
+    input_1, pred_net_1 (the 46 arrays of prednet.py:210-227 as
+    pred_net_1/layer_<key>_<level>/{kernel,bias}:0), time_distributed_1 and dense_2 with the fixed
+    loss weights of train.py:56-59,67-69 (the reference's `load_weights` insists on every weighted
+    layer of the model json being present), flatten_1."""
+    L = cfg.nb_layers
+    kv = b"2.2.4"
+    root = Group({"keras_version": kv, "backend": b"tensorflow"})
+    if model_config is not None:
+        root.attrs["model_config"] = model_config if isinstance(model_config, bytes) else model_config.encode()
+    mw = root.group("model_weights", {"layer_names": [b"input_1", b"pred_net_1", b"time_distributed_1", b"flatten_1", b"dense_2"],
+                                      "backend": b"tensorflow", "keras_version": kv})
+    mw.group("input_1", {"weight_names": []})
+    mw.group("flatten_1", {"weight_names": []})
+    names = []
+    pn = mw.group("pred_net_1")
+    inner = pn.group("pred_net_1")
+    for (n, shape), w in zip(cfg.weight_shapes(), weights):
+        key, kind = n.split("/")
+        stem = key.rstrip("0123456789")
+        lname = "layer_%s_%s" % (stem, key[len(stem):])
+        if lname not in inner.children:
+            inner.group(lname)
+        inner.children[lname].dataset(kind + ":0", np.asarray(w, np.float32).reshape(shape))
+        names.append(("pred_net_1/%s/%s:0" % (lname, kind)).encode())
+    pn.attrs["weight_names"] = names
+    layer_loss = np.zeros((L, 1), np.float32)
+    layer_loss[0] = 1.0                                  # train.py:56-57: the "L_0" model
+    time_loss = np.full((nt, 1), 1.0 / (nt - 1), np.float32)
+    time_loss[0] = 0.0                                   # train.py:58-59
+    td = mw.group("time_distributed_1", {"weight_names": [b"time_distributed_1/kernel:0", b"time_distributed_1/bias:0"]})
+    tdi = td.group("time_distributed_1")
+    tdi.dataset("kernel:0", layer_loss)
+    tdi.dataset("bias:0", np.zeros(1, np.float32))
+    de = mw.group("dense_2", {"weight_names": [b"dense_2/kernel:0", b"dense_2/bias:0"]})
+    dei = de.group("dense_2")
+    dei.dataset("kernel:0", time_loss)
+    dei.dataset("bias:0", np.zeros(1, np.float32))
+    write_file(path, root)

@@ -8,8 +8,9 @@ means, Adam (lr 1e-3, 1e-4 from epoch 75; Keras defaults beta 0.9/0.999, eps 1e-
 consecutive frames of one source, start drawn from all valid starts (data_utils.py:29-30).
 The forward pass here is ordinary torch conv2d (any device torch has); it is the same function
 as the inference path's TZ-PA1 arithmetic up to float32 summation order, which training does
-not need bit for bit.  Output: prednet_model.json + prednet_weights.npz in WEIGHTS_DIR, readable
-by compress.run / decompress.run.  Data: X_train.npy etc. from tezip_amd.train_data_create.
+not need bit for bit.  Output: prednet_model.json + prednet_weights.hdf5 in WEIGHTS_DIR (the
+reference's own two files, Keras layout: tezip_amd/weights.py), readable by compress.run /
+decompress.run here and by the reference's compress.py:143-173.  Data: X_train.npy etc. from tezip_amd.train_data_create.
 """
 import os
 

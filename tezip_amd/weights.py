@@ -5,10 +5,16 @@ plus `prednet_weights.hdf5` (a full-model Keras checkpoint, train.py:109) and re
 PredNet layer from them (compress.py:143-173).  Here:
   * prednet_model.json is read the same way (the PredNet layer's config gives the channel
     stacks, the InputLayer's batch_input_shape the padded frame size);
-  * weights are read from `prednet_weights.npz` (this build's native format: arrays
-    w000..wNNN in the Keras weight-list order of prednet.py:210-227), or from the reference's
-    `prednet_weights.hdf5` -- with h5py when it is importable, otherwise with the built-in
-    minimal reader tezip_amd/h5lite.py (h5py is not part of the image this was built in).
+  * weights are read from the reference's `prednet_weights.hdf5` -- with h5py when it is
+    importable, otherwise with the built-in minimal reader tezip_amd/h5lite.py (h5py is not part
+    of the image this was built in) -- or, when there is no such file, from a legacy
+    `prednet_weights.npz` (arrays w000..wNNN in the Keras weight-list order of
+    prednet.py:210-227).  When both exist the hdf5 wins: it is the file the reference (re)writes.
+  * `save_model` writes the same two files the reference's trainer leaves behind: a
+    `model.to_json()`-shaped prednet_model.json (every layer of train.py:62-71 with the config keys
+    Keras 2.2.4 emits, so that `model_from_json` can rebuild it) and a Keras-layout full-model
+    prednet_weights.hdf5 (tezip_amd/h5lite.py writer): a model trained or converted here can be
+    consumed by /root/reference/src/compress.py:143-173.
 """
 import json
 import os
@@ -26,6 +32,10 @@ def _find_layers(model_json):
     cfg = model_json.get("config", model_json)
     layers = cfg.get("layers", []) if isinstance(cfg, dict) else cfg
     return layers
+
+
+SUPPORTED_ACTIVATIONS = {"error_activation": "relu", "A_activation": "relu", "LSTM_activation": "tanh",
+                         "LSTM_inner_activation": "hard_sigmoid"}
 
 
 def parse_model_json(text):
@@ -48,27 +58,74 @@ def parse_model_json(text):
     fmt = pred.get("data_format", pred.get("dim_ordering", "channels_last"))
     if fmt not in ("channels_last", "tf"):
         raise NotImplementedError("only channels_last models are supported")
+    # the kernels hard-code the reference's defaults (prednet.py:78-79, 95-98); a model that asks
+    # for anything else must not be predicted with the wrong function
+    for key, want in SUPPORTED_ACTIVATIONS.items():
+        if pred.get(key, want) != want:
+            raise NotImplementedError("%s=%r: the HIP predictor implements %r only" % (key, pred[key], want))
+    if pred.get("extrap_start_time") is not None:
+        raise NotImplementedError("extrap_start_time is not supported (the reference never sets it, train.py:62-64)")
     cfg = PredNetConfig(pred["stack_sizes"], pred.get("R_stack_sizes"), pred.get("A_filt_sizes"),
                         pred.get("Ahat_filt_sizes"), pred.get("R_filt_sizes"), pred.get("pixel_max", 1.0))
     return cfg, shape
 
 
+def _dense_config(name, units=1):
+    """Dense.get_config() of Keras 2.2.4 with default arguments."""
+    return {"name": name, "trainable": False, "units": units, "activation": "linear", "use_bias": True,
+            "kernel_initializer": {"class_name": "VarianceScaling",
+                                   "config": {"scale": 1.0, "mode": "fan_avg", "distribution": "uniform", "seed": None}},
+            "bias_initializer": {"class_name": "Zeros", "config": {}},
+            "kernel_regularizer": None, "bias_regularizer": None, "activity_regularizer": None,
+            "kernel_constraint": None, "bias_constraint": None}
+
+
 def make_model_json(cfg, hp, wp, nt=2):
-    """A minimal Keras-style model json that parse_model_json (and the reference's field
-    accesses, compress.py:163-169) understand."""
-    return json.dumps({"class_name": "Model", "config": {"name": "model_1", "layers": [
-        {"class_name": "InputLayer", "name": "input_1",
-         "config": {"batch_input_shape": [None, nt, hp, wp, cfg.stack_sizes[0]], "dtype": "float32", "name": "input_1"}},
-        {"class_name": "PredNet", "name": "pred_net_1",
-         "config": dict(cfg.to_json_dict()["config"], output_mode="error", return_sequences=True)}]},
-        "keras_version": "2.2.4", "backend": "tensorflow"})
+    """prednet_model.json as `model.to_json()` writes it for the training graph of
+    train.py:62-71 (Input -> PredNet(output_mode='error') -> TimeDistributed(Dense(1)) -> Flatten ->
+    Dense(1)), Keras 2.2.4 functional-model schema.  The reference rebuilds the model from this
+    with `model_from_json(..., custom_objects={'PredNet': PredNet})` and reads `layers[0]`'s
+    batch_input_shape and `layers[1].get_config()` (compress.py:155-169)."""
+    pred_cfg = {"name": "pred_net_1", "trainable": True, "return_sequences": True, "return_state": False,
+                "go_backwards": False, "stateful": False, "unroll": False, "implementation": 0,
+                "stack_sizes": list(cfg.stack_sizes), "R_stack_sizes": list(cfg.R_stack_sizes),
+                "A_filt_sizes": list(cfg.A_filt_sizes), "Ahat_filt_sizes": list(cfg.Ahat_filt_sizes),
+                "R_filt_sizes": list(cfg.R_filt_sizes), "pixel_max": 1.0,
+                "error_activation": "relu", "A_activation": "relu", "LSTM_activation": "tanh",
+                "LSTM_inner_activation": "hard_sigmoid", "data_format": "channels_last",
+                "extrap_start_time": None, "output_mode": "error"}
+    layers = [
+        {"name": "input_1", "class_name": "InputLayer",
+         "config": {"batch_input_shape": [None, nt, hp, wp, cfg.stack_sizes[0]], "dtype": "float32", "sparse": False,
+                    "name": "input_1"}, "inbound_nodes": []},
+        {"name": "pred_net_1", "class_name": "PredNet", "config": pred_cfg, "inbound_nodes": [[["input_1", 0, 0, {}]]]},
+        {"name": "time_distributed_1", "class_name": "TimeDistributed",
+         "config": {"name": "time_distributed_1", "trainable": False,
+                    "layer": {"class_name": "Dense", "config": _dense_config("dense_1")}},
+         "inbound_nodes": [[["pred_net_1", 0, 0, {}]]]},
+        {"name": "flatten_1", "class_name": "Flatten",
+         "config": {"name": "flatten_1", "trainable": True, "data_format": "channels_last"},
+         "inbound_nodes": [[["time_distributed_1", 0, 0, {}]]]},
+        {"name": "dense_2", "class_name": "Dense", "config": _dense_config("dense_2"),
+         "inbound_nodes": [[["flatten_1", 0, 0, {}]]]},
+    ]
+    return json.dumps({"class_name": "Model",
+                       "config": {"name": "model_1", "layers": layers, "input_layers": [["input_1", 0, 0]],
+                                  "output_layers": [["dense_2", 0, 0]]},
+                       "keras_version": "2.2.4", "backend": "tensorflow"})
 
 
 def save_model(model_dir, cfg, weights, hp, wp):
+    """The reference's model directory: prednet_model.json + prednet_weights.hdf5 (train.py:109,114-117)."""
+    from . import h5lite
     os.makedirs(model_dir, exist_ok=True)
+    text = make_model_json(cfg, hp, wp)
     with open(os.path.join(model_dir, JSON_NAME), "w") as f:
-        f.write(make_model_json(cfg, hp, wp))
-    np.savez(os.path.join(model_dir, NPZ_NAME), **{"w%03d" % i: np.asarray(w, np.float32) for i, w in enumerate(weights)})
+        f.write(text)
+    h5lite.save_prednet_checkpoint(os.path.join(model_dir, H5_NAME), cfg, weights, nt=2, model_config=text)
+    stale = os.path.join(model_dir, NPZ_NAME)
+    if os.path.exists(stale):  # a converted copy of OLDER weights would shadow nothing now, but is misleading
+        os.remove(stale)
 
 
 def _load_h5(path, cfg):
@@ -107,15 +164,15 @@ def load_model(model_dir):
         cfg, shape = parse_model_json(f.read())
     npz = os.path.join(model_dir, NPZ_NAME)
     h5 = os.path.join(model_dir, H5_NAME)
-    if os.path.exists(npz):
-        z = np.load(npz)
-        weights = [z["w%03d" % i] for i in range(len(z.files))]
-    elif os.path.exists(h5):
+    if os.path.exists(h5):  # the reference's file wins over a converted copy (which may be stale)
         try:
             weights = _load_h5(h5, cfg)
         except ImportError:  # no h5py in this image: the built-in reader covers Keras' files
             from . import h5lite
             weights = h5lite.load_prednet_weights(h5, [n for n, _ in cfg.weight_shapes()])
+    elif os.path.exists(npz):
+        z = np.load(npz)
+        weights = [z["w%03d" % i] for i in range(len(z.files))]
     else:
         raise OSError("No such file or directory: %s" % h5)
     shapes = cfg.weight_shapes()
