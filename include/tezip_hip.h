@@ -105,7 +105,9 @@ int tz_rollout_decode(tz_ctx* ctx, const uint8_t* key_frames, int nt, int H, int
 int tz_get_predictions(tz_ctx* ctx, float* out);
 
 /* ---- encoder back half on the context-resident rollout (compress.py:289-373) ---------------
- * payload: nt*H*W*3 int16 = rank(1600 - sd) when entropy != 0, else sd.
+ * payload: nt*H*W*3 int16 = rank(1600 - sd) when bit 0 of `entropy` is set, else sd.
+ * Bit 1 of `entropy` (value 2; NOT a reference feature, off in the reference's format): the
+ * payload is returned byte-shuffled, i.e. as nt*H*W*3 low bytes followed by as many high bytes.
  * table: >= TZ_MAX_TABLE int16 (host), *table_len receives T (or -1 when entropy == 0).
  * delta_out (may be NULL): the int16 delta stack after quantisation, before the spatial delta. */
 int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t* payload,
@@ -138,6 +140,10 @@ int tz_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8_
  * NULL): TZ_NBINS uint64 counts of the output symbols are ADDED (compress.py:354). */
 int tz_spatial_delta(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, int16_t carry,
                      int apply_offset, int16_t* out, unsigned long long* hist);
+/* Opt-in byte shuffle (no reference counterpart; BASELINE.json's north star names the stage):
+ * int16[n] <-> n low bytes | n high bytes.  n must be a multiple of 8 for the forward direction. */
+int tz_byte_shuffle(tz_ctx* ctx, const int16_t* in, size_t n, uint8_t* out);
+int tz_byte_unshuffle(tz_ctx* ctx, const uint8_t* in, size_t n, int16_t* out);
 /* tz_build_table: compress.py:352-361 (host): count desc, ties ascending symbol. */
 int tz_build_table(const unsigned long long* hist, int nbins, int16_t* table, int* table_len);
 /* tz_remap: compress.py:84-90 (symbol -> rank). */

@@ -137,3 +137,32 @@ def test_cli_under_torchrun_shards_windows_and_writes_identical_files(tmp_path):
     decompress.run(mdir, one, udir, True, False)
     ref = np.stack([np.array(Image.open(os.path.join(udir, "frame_%03d.png" % t))) for t in range(nt)])
     np.testing.assert_array_equal(got, ref)
+
+
+def test_opt_in_byte_shuffle_roundtrip_and_default_off(tmp_path):
+    """--shuffle (not a reference feature): entropy.dat holds the payload as byte planes and says so
+    in its trailer (first shape entry 2); this build decodes it; without the flag the stream is the
+    reference's, byte for byte."""
+    from PIL import Image
+    from tezip_amd import _lib
+    cfg = PredNetConfig(stack_sizes=(3, 16, 32))
+    nt, h, w = 9, 24, 40
+    frames = synth.translating_scene(nt, h, w, seed=8)
+    mdir = str(tmp_path / "model")
+    weights.save_model(mdir, cfg, cfg.init_weights(seed=8, bias_scale=0.1), 24, 40)
+    ddir = _write(tmp_path, frames, False)
+    plain, shuf, out = str(tmp_path / "plain"), str(tmp_path / "shuf"), str(tmp_path / "out")
+    compress.run(mdir, ddir, plain, 0, 4, None, "abs", [0.0], True, False, True)
+    compress.run(mdir, ddir, shuf, 0, 4, None, "abs", [0.0], True, False, True, SHUFFLE=True)
+    a = np.frombuffer(zstd.decompress(open(os.path.join(plain, "entropy.dat"), "rb").read()), "<i2")
+    b = np.frombuffer(zstd.decompress(open(os.path.join(shuf, "entropy.dat"), "rb").read()), "<i2")
+    n = nt * h * w * 3
+    assert a.size == b.size and a[-6] == 1 and b[-6] == 2 and (a[n:-6] == b[n:-6]).all() and (a[-5:] == b[-5:]).all()
+    planes = b[:n].view(np.uint8)
+    assert (planes[:n] == (a[:n].astype(np.uint16) & 0xFF)).all() and (planes[n:] == (a[:n].astype(np.uint16) >> 8)).all()
+    ctx = _lib.Context(0)
+    assert (ctx.byte_unshuffle(planes) == a[:n]).all() and (ctx.byte_shuffle(np.ascontiguousarray(a[:n])) == planes).all()
+    ctx.close()
+    decompress.run(mdir, shuf, out, True, False)
+    got = np.stack([np.array(Image.open(os.path.join(out, "frame_%03d.png" % t))) for t in range(nt)])
+    assert np.array_equal(got, frames)

@@ -190,7 +190,7 @@ def test_corrupt_or_truncated_streams_are_rejected_before_the_native_call():
     with pytest.raises(ValueError, match="shape"):
         decompress.check_stream((1, 2, 4, 5, 1), warm, 2 * 4 * 5, 2 * 4 * 5)
     with pytest.raises(ValueError, match="shape"):
-        decompress.check_stream((2, 2, 4, 5, 3), warm, p.size, p.size)
+        decompress.check_stream((3, 2, 4, 5, 3), warm, p.size, p.size)
     with pytest.raises(ValueError, match="warm-up"):
         decompress.check_stream(shape, 2, p.size, p.size)
     with pytest.raises(ValueError, match="warm-up"):

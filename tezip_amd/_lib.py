@@ -51,6 +51,8 @@ _SIGS = {
     "tz_error_bound": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_double, C.c_double]),
     "tz_spatial_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int16, C.c_int, C.c_void_p, C.c_void_p]),
+    "tz_byte_shuffle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tz_byte_unshuffle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tz_build_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "tz_remap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "tz_unmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -247,7 +249,23 @@ class Context:
         self._ck(self.lib.tz_get_predictions(self.h, out.ctypes.data))
         return out
 
-    def encode(self, mode, bound, entropy=True, payload=None, want_delta=False):
+    def byte_shuffle(self, x, out=None):
+        n = _numel(x)
+        if out is None:
+            out = np.empty(2 * n, np.uint8)
+        self._ck(self.lib.tz_byte_shuffle(self.h, _ptr(x), n, _ptr(out)))
+        return out
+
+    def byte_unshuffle(self, planes, out=None):
+        n = _numel(planes) // 2
+        if out is None:
+            out = np.empty(n, np.int16)
+        self._ck(self.lib.tz_byte_unshuffle(self.h, _ptr(planes), n, _ptr(out)))
+        return out
+
+    def encode(self, mode, bound, entropy=True, payload=None, want_delta=False, shuffle=False):
+        """shuffle=True (not a reference format): `payload` then holds the two byte planes of the
+        int16 payload (same buffer size), see tz_byte_shuffle."""
         nt, h, w = self._shape
         b0 = float(bound[0])
         b1 = float(bound[1]) if len(bound) > 1 else 0.0
@@ -256,7 +274,7 @@ class Context:
         table = np.zeros(TZ_MAX_TABLE, np.int16)
         tlen = C.c_int(0)
         delta = np.empty((nt, h, w, 3), np.int16) if want_delta else None
-        self._ck(self.lib.tz_encode(self.h, MODES[mode], b0, b1, int(bool(entropy)), _ptr(payload), table.ctypes.data,
+        self._ck(self.lib.tz_encode(self.h, MODES[mode], b0, b1, int(bool(entropy)) | (2 if shuffle else 0), _ptr(payload), table.ctypes.data,
                                     C.byref(tlen), _ptr(delta)))
         t = table[: tlen.value].copy() if tlen.value >= 0 else None
         return payload, t, delta

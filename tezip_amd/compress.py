@@ -86,8 +86,13 @@ def make_context(cfg, wts, hp, wp, max_batch, device=0):
     return ctx
 
 
+SHUFFLE_MARK = 2  # first trailer shape entry of a byte-shuffled stream (the reference always writes 1)
+
+
 def build_stream(payload, table, shape5, warm_up):
-    """compress.py:381-394: payload | table | len(table)  (or | -1) | shape | PREPROCESS, int16."""
+    """compress.py:381-394: payload | table | len(table)  (or | -1) | shape | PREPROCESS, int16.
+    shape5[0] is 1 in the reference's format; SHUFFLE_MARK flags the opt-in byte-shuffled payload
+    (this build only; `payload` then carries the two byte planes in an int16-typed buffer)."""
     if table is not None:
         tail = np.concatenate([table.astype(np.int64), [len(table)]])
     else:
@@ -96,18 +101,18 @@ def build_stream(payload, table, shape5, warm_up):
     return np.concatenate([np.asarray(payload, dtype=np.int16).reshape(-1), trailer])
 
 
-def pack_outputs(frames, key, payload, table, warm_up):
+def pack_outputs(frames, key, payload, table, warm_up, shuffled=False):
     """compress.py:271-278 and 375-400: the two zstd-9 frames (key_frame.dat, entropy.dat) as bytes."""
     nt, H, W = frames.shape[:3]
     key_frame = np.zeros_like(frames)
     key_frame[key] = frames[key]
     key_bytes = zstd.compress_array(key_frame, 9, zstd.default_threads())
-    stream = build_stream(payload, table, (1, nt, H, W, 3), warm_up)
+    stream = build_stream(payload, table, (SHUFFLE_MARK if shuffled else 1, nt, H, W, 3), warm_up)
     return key_bytes, zstd.compress_array(stream, 9, zstd.default_threads())
 
 
-def write_outputs(out_dir, frames, key, payload, table, warm_up):
-    key_bytes, entropy_bytes = pack_outputs(frames, key, payload, table, warm_up)
+def write_outputs(out_dir, frames, key, payload, table, warm_up, shuffled=False):
+    key_bytes, entropy_bytes = pack_outputs(frames, key, payload, table, warm_up, shuffled)
     with open(os.path.join(out_dir, "key_frame.dat"), mode='wb') as f:
         f.write(key_bytes)
     with open(os.path.join(out_dir, "entropy.dat"), mode='wb') as f:
@@ -116,7 +121,9 @@ def write_outputs(out_dir, frames, key, payload, table, warm_up):
 
 
 def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, MODE, BOUND_VALUE, GPU_FLAG, VERBOSE,
-        ENTROPY_RUN, device=0):
+        ENTROPY_RUN, device=0, SHUFFLE=False):
+    """SHUFFLE (--shuffle; NOT in the reference): store the payload as byte planes.  Off by default:
+    a shuffled entropy.dat is flagged in its trailer and is not readable by the reference."""
     if not GPU_FLAG:
         print("ERROR: this build runs the compression path on an AMD MI355X only (no CPU path).")
         exit()
@@ -165,6 +172,8 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
             if res is None:
                 return
             payload, table, key = res
+            if SHUFFLE:
+                payload = ctx.byte_shuffle(np.ascontiguousarray(payload)).view(np.int16)
         else:
             if VERBOSE:
                 ctx.prof_enable(True)
@@ -176,7 +185,7 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
                     if key[i] and i > PREPROCESS:
                         print("move key point")
                 print("predict:{0}".format(time.time() - t0) + "[sec]")
-            payload, table, _ = ctx.encode(MODE, BOUND_VALUE, ENTROPY_RUN)
+            payload, table, _ = ctx.encode(MODE, BOUND_VALUE, ENTROPY_RUN, shuffle=SHUFFLE)
             if VERBOSE:
                 prof = ctx.prof_get()
                 print("error_bound:{0}".format(prof["quant"][0] / 1e3) + "[sec]")
@@ -184,6 +193,6 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
                 if ENTROPY_RUN:
                     print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
 
-        write_outputs(OUTPUT_DIR, origine_img, key, payload, table if ENTROPY_RUN else None, PREPROCESS)
+        write_outputs(OUTPUT_DIR, origine_img, key, payload, table if ENTROPY_RUN else None, PREPROCESS, SHUFFLE)
     finally:
         ctx.close()

@@ -823,10 +823,19 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
     if (mode < 0 || mode > 3) return tz_fail(ctx, TZ_ERR_INVALID, "unknown error-bound mode %d", mode);
     const int nt = ctx->nt, H = ctx->H, W = ctx->W;
     const size_t N = (size_t)nt * H * W * 3;
+    const bool shuffle = (entropy & 2) != 0;  // opt-in byte planes (not a reference format)
+    entropy &= 1;
+    if (shuffle && (N & 7)) return tz_fail(ctx, TZ_ERR_INVALID, "byte shuffle needs a multiple of 8 elements");
     std::vector<tz_out> outs;
-    tz_out o_pay, o_delta;
+    tz_out o_pay, o_delta, o_final;
     void *d_delta = nullptr, *d_mask = nullptr, *d_hist = nullptr, *d_sd = nullptr;
     int rc = tz_dev_out(ctx, payload, N * 2, &o_pay);
+    if (rc == TZ_OK && shuffle) {  // the stages below write the plain payload to a scratch buffer instead
+        o_final = o_pay;
+        o_pay = tz_out();
+        o_pay.bytes = N * 2;
+        rc = tz_pool_alloc(ctx, N * 2, &o_pay.dev);
+    }
     if (rc == TZ_OK && delta_out) {
         rc = tz_dev_out(ctx, delta_out, N * 2, &o_delta);
         if (rc == TZ_OK) {
@@ -876,7 +885,45 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
         if (rc == TZ_OK) rc = build_enc_lut(ctx, table, *table_len, &lut);
         if (rc == TZ_OK) rc = remap_out(ctx, (const int16_t*)d_sd, N, lut.data(), &o_pay);  // 369
     }
+    if (rc == TZ_OK && shuffle) {
+        rc = tzk_shuffle(ctx, (const int16_t*)o_pay.dev, N, (uint8_t*)o_final.dev, 0);
+        o_pay = o_final;
+    }
     outs.push_back(o_pay);
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+// Opt-in byte shuffle of an int16 stream and its inverse (stand-alone; tz_encode applies the
+// forward direction itself when bit 1 of `entropy` is set).
+extern "C" int tz_byte_shuffle(tz_ctx* ctx, const int16_t* in, size_t n, uint8_t* out) {
+    if (!ctx || !in || !out) return TZ_ERR_INVALID;
+    const void* din;
+    tz_out o;
+    std::vector<tz_out> outs;
+    int rc = tz_dev_in(ctx, in, n * 2, &din);
+    if (rc == TZ_OK) rc = tz_dev_out(ctx, out, n * 2, &o);
+    if (rc == TZ_OK) {
+        outs.push_back(o);
+        rc = tzk_shuffle(ctx, (const int16_t*)din, n, (uint8_t*)o.dev, 0);
+    }
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+extern "C" int tz_byte_unshuffle(tz_ctx* ctx, const uint8_t* in, size_t n, int16_t* out) {
+    if (!ctx || !in || !out) return TZ_ERR_INVALID;
+    const void* din;
+    tz_out o;
+    std::vector<tz_out> outs;
+    int rc = tz_dev_in(ctx, in, n * 2, &din);
+    if (rc == TZ_OK) rc = tz_dev_out(ctx, out, n * 2, &o);
+    if (rc == TZ_OK) {
+        outs.push_back(o);
+        rc = tzk_shuffle(ctx, (const int16_t*)din, n, (uint8_t*)o.dev, 1);
+    }
     if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
     tz_pool_release_all(ctx);
     return rc;

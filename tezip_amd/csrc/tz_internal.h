@@ -153,6 +153,8 @@ int tzk_error_bound(tz_ctx*, const uint8_t* orig, int16_t* diff, const uint8_t* 
 int tzk_spatial_delta(tz_ctx*, const int16_t* in, size_t n, int has_carry, int16_t carry, int apply_offset,
                       int16_t* out, unsigned long long* d_hist);
 int tzk_lut(tz_ctx*, const int16_t* in, size_t n, const int16_t* h_lut2112, int post_offset, int16_t* out);
+// forward: int16[n] -> low-byte plane | high-byte plane (2n bytes); inverse: planes (passed as `in`) -> int16[n] at `out`
+int tzk_shuffle(tz_ctx*, const int16_t* in, size_t n, uint8_t* out, int inverse);
 int tzk_undelta(tz_ctx*, const int16_t* in, size_t n, int has_carry, int16_t carry, int16_t* out);
 int tzk_reconstruct(tz_ctx*, const float* pred, const uint8_t* key, const uint8_t* d_key_mask, const int16_t* diff,
                     int nframes, int H, int W, int Hp, int Wp, uint8_t* out);

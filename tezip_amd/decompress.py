@@ -9,7 +9,7 @@ import numpy as np
 
 from . import _lib, zstd
 from . import dist as tzdist
-from .compress import make_context, open_model
+from .compress import SHUFFLE_MARK, make_context, open_model
 from .data_utils import padding_shape
 
 
@@ -33,7 +33,7 @@ def check_stream(shape, warm_up, payload_len, key_len):
     the native library.  The reference fails with a ValueError at its reshapes
     (decompress.py:115,240) for the same inconsistencies."""
     one, nt, H, W, C = shape
-    if one != 1 or C != 3 or nt < 1 or H < 1 or W < 1:
+    if one not in (1, SHUFFLE_MARK) or C != 3 or nt < 1 or H < 1 or W < 1:
         raise ValueError("entropy.dat: unsupported stack shape %r (expected (1, nt, H, W, 3))" % (tuple(shape),))
     n = nt * H * W * C
     if payload_len != n:
@@ -95,6 +95,8 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
         device = tzdist.init_from_env()
     ctx = make_context(cfg, wts, hp, wp, 64 if nt > 64 else max(1, nt), device)
     try:
+        if shape[0] == SHUFFLE_MARK:  # this build's opt-in byte planes -> the int16 payload
+            payload = ctx.byte_unshuffle(np.ascontiguousarray(payload).view(np.uint8))
         if job:
             # key intervals sharded over the ranks (tezip_amd/dist.py); rank 0 saves the images
             frames = tzdist.decompress_sharded(tzdist.HipEngine(ctx, device), key_frames, payload, table, warm_up)

@@ -32,6 +32,8 @@ FLAG_TABLE = (
     ("-n", "--no_entropy", dict(action="store_false")),  # store_false: entropy remap is on by default
     # not in the reference: compress once per candidate -w and keep the smallest output (BASELINE.json configs[4];
     # tezip_amd/sweep.py).  No value = 5 10 15 20 25 30 35 40.  Takes the place of -w / -t.
+    # not in the reference: byte-shuffled payload (flagged in the trailer; the reference cannot read such a file)
+    (None, "--shuffle", dict(action="store_true")),
     (None, "--sweep", dict(type=int, nargs="*", metavar="window_size", dest="sweep", default=None)),
 )
 
@@ -130,7 +132,7 @@ def main(arg):
     window = arg.window[0] if arg.window is not None else None
     threshold = arg.threshold[0] if arg.threshold is not None else None
     return compress.run(model, src, dst, arg.preprocess[0], window, threshold, arg.mode[0], arg.bound, gpu,
-                        arg.verbose, arg.no_entropy)
+                        arg.verbose, arg.no_entropy, SHUFFLE=arg.shuffle)
 
 
 if __name__ == "__main__":
