@@ -97,6 +97,15 @@ int tz_set_conv_impl(tz_ctx* ctx, int lds_dma);
  * the context for tz_encode.  Rejects nt < warm_up+2 (the reference misbehaves there). */
 int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int W, int warm_up, int window,
                double threshold, uint8_t* key_mask, double* mse_log);
+/* Streaming ingestion (the reference holds every frame in RAM, compress.py:116-122): instead of one
+ * stack, stage the frames window by window -- tz_frames_begin(nt,H,W), then tz_frames_put for any
+ * partition of [0,nt) (asynchronous on the context's copy stream; a pageable source is free again
+ * on return, a pinned one after tz_frames_fence) -- and call tz_rollout with frames == NULL.
+ * tz_frames_get copies frames of the resident stack back (e.g. the key frames for key_frame.dat). */
+int tz_frames_begin(tz_ctx* ctx, int nt, int H, int W);
+int tz_frames_put(tz_ctx* ctx, int first, int count, const uint8_t* frames);
+int tz_frames_fence(tz_ctx* ctx);
+int tz_frames_get(tz_ctx* ctx, int first, int count, uint8_t* out);
 /* Decoder replay: key_frames = the key_frame.dat stack (zeros except key frames); key
  * positions are recovered as decompress.py:123-129 does (any non-zero sample). */
 int tz_rollout_decode(tz_ctx* ctx, const uint8_t* key_frames, int nt, int H, int W, int warm_up,
@@ -112,6 +121,10 @@ int tz_get_predictions(tz_ctx* ctx, float* out);
  * delta_out (may be NULL): the int16 delta stack after quantisation, before the spatial delta. */
 int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t* payload,
               int16_t* table, int* table_len, int16_t* delta_out);
+/* Streaming delivery: tz_encode with payload == NULL keeps the payload in the context; it is then
+ * fetched in pieces of `count` int16 elements starting at `offset` (compress.py:375-400 appends and
+ * compresses one monolithic array). */
+int tz_payload_get(tz_ctx* ctx, size_t offset, size_t count, int16_t* out);
 /* First stage of tz_encode only (compress.py:292-319): delta + error-bound quantisation of the
  * context-resident rollout -> int16 delta stack nt*H*W*3.  Used when frame windows are sharded
  * over GPUs: the spatial delta and the histogram then need a carry / a sum across shards

@@ -166,3 +166,38 @@ def test_opt_in_byte_shuffle_roundtrip_and_default_off(tmp_path):
     decompress.run(mdir, shuf, out, True, False)
     got = np.stack([np.array(Image.open(os.path.join(out, "frame_%03d.png" % t))) for t in range(nt)])
     assert np.array_equal(got, frames)
+
+
+def test_host_memory_does_not_grow_with_the_number_of_frames(tmp_path):
+    """the reference holds every frame and the whole int16 stream in RAM
+    (compress.py:116-122, 329-333, 375-400); here the frames stream through a ring of window
+    buffers into HBM and both output files are compressed from pieces.  Peak RSS of a whole
+    `tezip.py -c` process must not depend on nt (4x the frames = 151 MB more frames + payload if it
+    were held), and the longer run still round-trips."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from conftest import ROOT
+    cfg = PredNetConfig(stack_sizes=(3, 16, 32))
+    h = w = 256
+    mdir = str(tmp_path / "model")
+    weights.save_model(mdir, cfg, cfg.init_weights(seed=8, bias_scale=0.1), h, w)
+    frames = synth.turbulence(256, h, w, seed=12)
+    peak = {}
+    for nt in (64, 256):
+        d = tmp_path / ("data%d" % nt)
+        d.mkdir()
+        for t in range(nt):
+            Image.fromarray(frames[t]).save(d / ("frame_%03d.png" % t), compress_level=1)
+        code = ("import resource, sys; sys.path.insert(0, %r); from tezip_amd import tezip;"
+                "tezip.main(tezip.build_parser().parse_args(['-c', %r, %r, %r, '-p', '0', '-w', '16', '-m', 'abs', '-b', '0']));"
+                "print('MAXRSS_KB', resource.getrusage(resource.RUSAGE_SELF).ru_maxrss)"
+                % (ROOT, mdir, str(d), str(tmp_path / ("comp%d" % nt))))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        peak[nt] = int([l for l in r.stdout.splitlines() if l.startswith("MAXRSS_KB")][0].split()[1])
+    held = (256 - 64) * h * w * 3 * 3 / 1024          # frames + int16 payload the reference would hold, KiB
+    assert peak[256] - peak[64] < 0.25 * held, peak
+    decompress.run(mdir, str(tmp_path / "comp256"), str(tmp_path / "out"), True, False)
+    got = np.stack([np.array(Image.open(os.path.join(str(tmp_path / "out"), "frame_%03d.png" % t))) for t in (0, 100, 255)])
+    assert np.array_equal(got, frames[[0, 100, 255]])

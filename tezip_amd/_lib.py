@@ -39,6 +39,11 @@ _SIGS = {
     "tz_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                              C.c_void_p, C.c_void_p]),
     "tz_rollout_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "tz_frames_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "tz_frames_put": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tz_frames_fence": (C.c_int, [C.c_void_p]),
+    "tz_frames_get": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tz_payload_get": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "tz_get_predictions": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tz_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                             C.POINTER(C.c_int), C.c_void_p]),
@@ -225,12 +230,41 @@ class Context:
         if len(x.shape) != 4 or x.shape[3] != 3:  # compress.py:114: grayscale is expanded to 3 channels first
             raise ValueError("%s must be a (nt, H, W, 3) uint8 stack, got shape %r" % (what, tuple(x.shape)))
 
-    def rollout(self, frames, warm_up, window, threshold=0.0, want_mse=False):
+    # streaming ingestion / delivery (tz_frames_* / tz_payload_get)
+    def frames_begin(self, nt, h, w):
+        self._ck(self.lib.tz_frames_begin(self.h, nt, h, w))
+        self._staged = (nt, h, w)
+
+    def frames_put(self, first, frames):
         self._check_stack(frames, "frames")
-        nt, h, w = frames.shape[:3]
+        self._ck(self.lib.tz_frames_put(self.h, int(first), int(frames.shape[0]), _ptr(frames, np.uint8)))
+
+    def frames_fence(self):
+        self._ck(self.lib.tz_frames_fence(self.h))
+
+    def frames_get(self, first, count, out=None):
+        nt, h, w = self._shape
+        if out is None:
+            out = np.empty((count, h, w, 3), np.uint8)
+        self._ck(self.lib.tz_frames_get(self.h, int(first), int(count), _ptr(out)))
+        return out
+
+    def payload_get(self, offset, count, out=None):
+        if out is None:
+            out = np.empty(count, np.int16)
+        self._ck(self.lib.tz_payload_get(self.h, int(offset), int(count), _ptr(out)))
+        return out
+
+    def rollout(self, frames, warm_up, window, threshold=0.0, want_mse=False):
+        """frames: (nt,H,W,3) uint8 stack (host or device), or None after frames_begin / frames_put."""
+        if frames is None:
+            nt, h, w = self._staged
+        else:
+            self._check_stack(frames, "frames")
+            nt, h, w = frames.shape[:3]
         key = np.zeros(nt, np.uint8)
         mse = np.zeros(nt, np.float64) if want_mse else None
-        self._ck(self.lib.tz_rollout(self.h, _ptr(frames, np.uint8), nt, h, w, warm_up, int(window or 0),
+        self._ck(self.lib.tz_rollout(self.h, None if frames is None else _ptr(frames, np.uint8), nt, h, w, warm_up, int(window or 0),
                                      float(threshold or 0.0), key.ctypes.data, _ptr(mse)))
         self._shape = (nt, h, w)
         return key.astype(bool), mse
@@ -269,7 +303,10 @@ class Context:
         nt, h, w = self._shape
         b0 = float(bound[0])
         b1 = float(bound[1]) if len(bound) > 1 else 0.0
-        if payload is None:
+        resident = isinstance(payload, str) and payload == "resident"  # stays in the context: payload_get
+        if resident:
+            payload = None
+        elif payload is None:
             payload = np.empty(nt * h * w * 3, np.int16)
         table = np.zeros(TZ_MAX_TABLE, np.int16)
         tlen = C.c_int(0)

@@ -120,24 +120,183 @@ def write_outputs(out_dir, frames, key, payload, table, warm_up, shuffled=False)
     return len(key_bytes), len(entropy_bytes)
 
 
+class FrameSource:
+    """compress.py:97-131 as a stream: the sorted image files of a directory decoded on a thread pool
+    into a small ring of window-sized buffers (the reference appends every image to one growing
+    array, compress.py:116-122).  Same acceptance rules and messages as load_images."""
+
+    def __init__(self, data_dir):
+        from PIL import Image, UnidentifiedImageError
+        self.Image, self.errors = Image, (PermissionError, IndexError, UnidentifiedImageError, IsADirectoryError, ValueError)
+        self.data_dir = data_dir
+        self.paths = sorted(glob.glob(os.path.join(data_dir, '*')))
+        if len(self.paths) == 0:
+            print("ERROR:", data_dir, "is an empty or non-existent directory")
+            exit()
+        try:
+            first = Image.open(self.paths[0])
+            mode = first.mode
+            if all([mode != 'RGB', mode != 'L']):
+                print("ERROR: input image is {0}. Only RGB and grayscale are supported.".format(mode))
+                exit()
+            self.is_rgb = mode == 'RGB'
+            self.W, self.H = first.size
+        except self.errors:
+            self.fail()
+        self.nt = len(self.paths)
+        self.files = [os.path.basename(p) for p in self.paths]
+
+    def fail(self):
+        print(self.data_dir, "contains files or folders that are not images.")
+        exit()
+
+    def _decode_into(self, dst, path):
+        img = self.Image.open(path)
+        arr = np.asarray(img if self.is_rgb else img.convert('RGB'))
+        if arr.shape != dst.shape:  # another size or mode: np.array of such a list is not a stack (compress.py:122)
+            raise ValueError(path)
+        dst[...] = arr
+
+    def chunks(self, per_chunk, pool, ring=3):
+        """Yields (first frame index, uint8 (k,H,W,3) view) in order; a yielded buffer is reused
+        `ring` chunks later, so the consumer must be done with it when it asks for the next one."""
+        bufs = [np.empty((per_chunk, self.H, self.W, 3), np.uint8) for _ in range(ring)]
+        starts = list(range(0, self.nt, per_chunk))
+
+        def submit(ci):
+            f0 = starts[ci]
+            n = min(per_chunk, self.nt - f0)
+            buf = bufs[ci % ring]
+            return [pool.submit(self._decode_into, buf[j], self.paths[f0 + j]) for j in range(n)], buf[:n], f0
+
+        pending = [submit(ci) for ci in range(min(ring - 1, len(starts)))]
+        nxt = len(pending)
+        while pending:
+            futs, view, f0 = pending.pop(0)
+            try:
+                for ft in futs:
+                    ft.result()
+            except self.errors:
+                self.fail()
+            if nxt < len(starts):  # its buffer was handed out `ring` chunks ago
+                pending.append(submit(nxt))
+                nxt += 1
+            yield f0, view
+
+
+PAYLOAD_CHUNK = 8 << 20  # int16 elements fetched and fed to zstd at a time
+
+
+def _stream_outputs(ctx, out_dir, nt, H, W, key, table, warm_up, shuffled, pool):
+    """key_frame.dat and entropy.dat (compress.py:271-278, 375-400) from the context-resident frames
+    and payload, piece by piece: nothing of size nt*H*W lives on the host."""
+    n = nt * H * W * 3
+    key_idx = [int(i) for i in np.nonzero(key)[0]]
+    key_frames = {i: ctx.frames_get(i, 1)[0] for i in key_idx}   # few frames; fetched before the worker starts
+
+    def key_file():
+        zero = np.zeros((H, W, 3), np.uint8)
+        with open(os.path.join(out_dir, "key_frame.dat"), mode='wb') as f:
+            sc = zstd.StreamCompressor(f, n, 9, max(1, zstd.default_threads() // 4))
+            for i in range(nt):
+                sc.write(key_frames.get(i, zero))
+            return sc.close()
+
+    kf = pool.submit(key_file)   # compresses while the payload is fetched and compressed here
+    if table is not None:
+        tail = np.concatenate([table.astype(np.int64), [len(table)]])
+    else:
+        tail = np.array([-1], dtype=np.int64)
+    trailer = np.concatenate([tail, [SHUFFLE_MARK if shuffled else 1, nt, H, W, 3], [warm_up]]).astype(np.int16)
+    bufs = [np.empty(min(PAYLOAD_CHUNK, n), np.int16) for _ in range(2)]
+    with open(os.path.join(out_dir, "entropy.dat"), mode='wb') as f:
+        sc = zstd.StreamCompressor(f, n * 2 + trailer.nbytes, 9, zstd.default_threads())
+        for k, off in enumerate(range(0, n, PAYLOAD_CHUNK)):
+            cnt = min(PAYLOAD_CHUNK, n - off)
+            piece = ctx.payload_get(off, cnt, out=bufs[k % 2][:cnt])
+            sc.write(piece)
+        sc.write(trailer)
+        esize = sc.close()
+    return kf.result(), esize
+
+
 def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, MODE, BOUND_VALUE, GPU_FLAG, VERBOSE,
         ENTROPY_RUN, device=0, SHUFFLE=False):
     """SHUFFLE (--shuffle; NOT in the reference): store the payload as byte planes.  Off by default:
-    a shuffled entropy.dat is flagged in its trailer and is not readable by the reference."""
+    a shuffled entropy.dat is flagged in its trailer and is not readable by the reference.
+
+    One process: the images stream through a ring of window buffers into HBM while the model loads,
+    and key_frame.dat / entropy.dat are written from context-resident data in pieces, so host memory
+    does not grow with the number of frames.  Under torch.distributed.run the windows are sharded
+    over the ranks (tezip_amd/dist.py) from a stack that every rank loads."""
     if not GPU_FLAG:
         print("ERROR: this build runs the compression path on an AMD MI355X only (no CPU path).")
         exit()
-    rank0 = tzdist.active() is None or tzdist.active()[0] == 0
+    if tzdist.active() is not None:
+        return _run_sharded(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, MODE, BOUND_VALUE,
+                            VERBOSE, ENTROPY_RUN, device, SHUFFLE)
+    if not os.path.exists(OUTPUT_DIR):
+        os.mkdir(OUTPUT_DIR)
+    src = FrameSource(DATA_DIR)
+    with open(os.path.join(OUTPUT_DIR, 'filename.txt'), 'w', encoding='UTF-8') as f:
+        f.write(f"{int(src.is_rgb)}\n")
+        for file_name in src.files:
+            f.write("%s\n" % file_name)
+    nt, H, W = src.nt, src.H, src.W
+    per_chunk = max(1, min(WINDOW_SIZE or 16, 64))
+    with ThreadPoolExecutor(max_workers=io_threads() + 1) as pool:
+        chunks = src.chunks(per_chunk, pool)   # decoding starts with the first next(); model + HIP start-up overlap it
+        head = next(chunks)
+        cfg, wts, model_shape = open_model(WEIGHTS_DIR)
+        hp, wp = padding_shape(H, W)
+        if model_shape is not None and (model_shape[0] != hp or model_shape[1] != wp):
+            print("ERROR:Image size is out of scope for this model.")
+            print("Compatible sizes for this model are height", model_shape[0] - 7, "to", model_shape[0], "and width",
+                  model_shape[1] - 7, "to", model_shape[1])
+            exit()
+        if nt < PREPROCESS + 2:
+            print("ERROR: need at least warm_up+2 images (%d given, warm_up %d)." % (nt, PREPROCESS))
+            exit()
+        nwin = 1 if WINDOW_SIZE is None else max(1, (nt - PREPROCESS + WINDOW_SIZE - 1) // WINDOW_SIZE)
+        ctx = make_context(cfg, wts, hp, wp, min(nwin, 64), device)
+        try:
+            ctx.frames_begin(nt, H, W)
+            ctx.frames_put(*head)
+            for f0, view in chunks:
+                ctx.frames_put(f0, view)   # pageable ring buffer: free again when the call returns
+            if VERBOSE:
+                ctx.prof_enable(True)
+            t0 = time.time()
+            key, mse = ctx.rollout(None, PREPROCESS, WINDOW_SIZE, THRESHOLD, want_mse=bool(VERBOSE))
+            if VERBOSE:
+                for i in range(PREPROCESS + 1, nt):
+                    print("MSE:", mse[i])
+                    if key[i] and i > PREPROCESS:
+                        print("move key point")
+                print("predict:{0}".format(time.time() - t0) + "[sec]")
+            _, table, _ = ctx.encode(MODE, BOUND_VALUE, ENTROPY_RUN, payload="resident", shuffle=SHUFFLE)
+            if VERBOSE:
+                prof = ctx.prof_get()
+                print("error_bound:{0}".format(prof["quant"][0] / 1e3) + "[sec]")
+                print("finding_difference:{0}".format(prof["spatial_delta_hist"][0] / 1e3) + "[sec]")
+                if ENTROPY_RUN:
+                    print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
+            _stream_outputs(ctx, OUTPUT_DIR, nt, H, W, key, table if ENTROPY_RUN else None, PREPROCESS, SHUFFLE, pool)
+        finally:
+            ctx.close()
+
+
+def _run_sharded(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, MODE, BOUND_VALUE, VERBOSE,
+                 ENTROPY_RUN, device, SHUFFLE):
+    rank0 = tzdist.active()[0] == 0
     if rank0 and not os.path.exists(OUTPUT_DIR):
         os.mkdir(OUTPUT_DIR)
     origine_img, files, isRGB = load_images(DATA_DIR)
-
     if rank0:
         with open(os.path.join(OUTPUT_DIR, 'filename.txt'), 'w', encoding='UTF-8') as f:
             f.write(f"{int(isRGB)}\n")
             for file_name in files:
                 f.write("%s\n" % file_name)
-
     nt, H, W = origine_img.shape[:3]
     cfg, wts, model_shape = open_model(WEIGHTS_DIR)
     hp, wp = padding_shape(H, W)
@@ -149,9 +308,8 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
     if nt < PREPROCESS + 2:
         print("ERROR: need at least warm_up+2 images (%d given, warm_up %d)." % (nt, PREPROCESS))
         exit()
-
     job = tzdist.active()
-    if job and WINDOW_SIZE is None:
+    if WINDOW_SIZE is None:
         if job[0] == 0:
             print("NOTE: DWP (-t) finds its windows sequentially and does not shard: running on rank 0 only.")
         else:
@@ -162,7 +320,7 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
         nt_local = max(b - a for a, b in tzdist.plan_shards(nt, PREPROCESS, WINDOW_SIZE, job[1]))
         nwin = max(1, (nt_local + WINDOW_SIZE - 1) // WINDOW_SIZE)
     else:
-        nwin = 1 if WINDOW_SIZE is None else max(1, (nt - PREPROCESS + WINDOW_SIZE - 1) // WINDOW_SIZE)
+        nwin = 1
     ctx = make_context(cfg, wts, hp, wp, min(nwin, 64), device)
     try:
         if job:
@@ -175,24 +333,8 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
             if SHUFFLE:
                 payload = ctx.byte_shuffle(np.ascontiguousarray(payload)).view(np.int16)
         else:
-            if VERBOSE:
-                ctx.prof_enable(True)
-            t0 = time.time()
-            key, mse = ctx.rollout(origine_img, PREPROCESS, WINDOW_SIZE, THRESHOLD, want_mse=bool(VERBOSE))
-            if VERBOSE:
-                for i in range(PREPROCESS + 1, nt):
-                    print("MSE:", mse[i])
-                    if key[i] and i > PREPROCESS:
-                        print("move key point")
-                print("predict:{0}".format(time.time() - t0) + "[sec]")
+            key, _ = ctx.rollout(origine_img, PREPROCESS, None, THRESHOLD)
             payload, table, _ = ctx.encode(MODE, BOUND_VALUE, ENTROPY_RUN, shuffle=SHUFFLE)
-            if VERBOSE:
-                prof = ctx.prof_get()
-                print("error_bound:{0}".format(prof["quant"][0] / 1e3) + "[sec]")
-                print("finding_difference:{0}".format(prof["spatial_delta_hist"][0] / 1e3) + "[sec]")
-                if ENTROPY_RUN:
-                    print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
-
         write_outputs(OUTPUT_DIR, origine_img, key, payload, table if ENTROPY_RUN else None, PREPROCESS, SHUFFLE)
     finally:
         ctx.close()

@@ -86,6 +86,7 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
     if (ctx->d_pred) (void)hipFree(ctx->d_pred);
     if (ctx->d_sched) (void)hipFree(ctx->d_sched);
+    if (ctx->d_payload) (void)hipFree(ctx->d_payload);
     for (auto& s : ctx->prof)
         for (auto& e : s.pending) {
             (void)hipEventDestroy(e.first);
@@ -434,6 +435,8 @@ static int rollout_setup(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int 
         return tz_fail(ctx, TZ_ERR_INVALID,
                        "Image size is out of scope for this model: compatible sizes are height %d to %d and width %d to %d",
                        Hp - 7, Hp, Wp - 7, Wp);  // compress.py:178-181
+    if (!frames && (!ctx->staged || ctx->nt != nt || ctx->H != H || ctx->W != W))
+        return tz_fail(ctx, TZ_ERR_STATE, "no frame stack of this shape was staged (tz_frames_begin / tz_frames_put)");
     ctx->nt = nt;
     ctx->H = H;
     ctx->W = W;
@@ -445,8 +448,14 @@ static int rollout_setup(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int 
     ctx->pending_sent.clear();
     const size_t fsz = (size_t)H * W * 3;
     size_t fb = (size_t)nt * fsz, pb = (size_t)nt * Hp * Wp * 3 * 4;
+    if (frames) ctx->staged = false;
     TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_frames, &ctx->cap_frames, fb));
     TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_pred, &ctx->cap_pred, pb));
+    if (!frames) {  // staged by tz_frames_put on the copy stream: the compute stream waits for the last of them
+        TZ_HIP(ctx, hipEventRecord(ctx->ev_frames, ctx->copy_stream));
+        TZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_frames, 0));
+        return TZ_OK;
+    }
     if (tz_is_device_ptr(frames)) {
         TZ_HIP(ctx, hipMemcpyAsync(ctx->d_frames, frames, fb, hipMemcpyDeviceToDevice, ctx->stream));
         return TZ_OK;
@@ -549,9 +558,62 @@ static int run_schedule(tz_ctx* ctx, std::vector<PredItem>& items) {
     return TZ_OK;
 }
 
+// ---- streaming ingestion / delivery: the frame stack enters window by window and the payload
+// leaves chunk by chunk, so that the host never holds more than a few windows (SURVEY.md §8f-3;
+// the reference keeps everything in RAM, compress.py:116-122,329-333).
+extern "C" int tz_frames_begin(tz_ctx* ctx, int nt, int H, int W) {
+    if (!ctx) return TZ_ERR_INVALID;
+    if (nt < 1 || H < 1 || W < 1 || nt > 32767 || H > 32767 || W > 32767)
+        return tz_fail(ctx, TZ_ERR_INVALID, "bad sequence shape nt=%d H=%d W=%d (int16 trailer limits)", nt, H, W);
+    ctx->have_rollout = false;
+    ctx->staged = false;
+    TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_frames, &ctx->cap_frames, (size_t)nt * H * W * 3));
+    // earlier work queued on the compute stream may still read d_frames
+    TZ_HIP(ctx, hipEventRecord(ctx->ev_compute, ctx->stream));
+    TZ_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compute, 0));
+    ctx->nt = nt;
+    ctx->H = H;
+    ctx->W = W;
+    ctx->staged = true;
+    return TZ_OK;
+}
+
+extern "C" int tz_frames_put(tz_ctx* ctx, int first, int count, const uint8_t* frames) {
+    if (!ctx || !frames) return TZ_ERR_INVALID;
+    if (!ctx->staged) return tz_fail(ctx, TZ_ERR_STATE, "tz_frames_put needs a tz_frames_begin first");
+    if (first < 0 || count < 0 || first + count > ctx->nt) return tz_fail(ctx, TZ_ERR_INVALID, "frames [%d, %d) outside the stack", first, first + count);
+    const size_t fsz = (size_t)ctx->H * ctx->W * 3;
+    return tz_h2d(ctx, ctx->d_frames + (size_t)first * fsz, frames, (size_t)count * fsz, ctx->copy_stream);
+}
+
+extern "C" int tz_frames_fence(tz_ctx* ctx) {
+    if (!ctx) return TZ_ERR_INVALID;
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    return TZ_OK;
+}
+
+extern "C" int tz_frames_get(tz_ctx* ctx, int first, int count, uint8_t* out) {
+    if (!ctx || !out) return TZ_ERR_INVALID;
+    if (!ctx->d_frames || first < 0 || count < 0 || first + count > ctx->nt)
+        return tz_fail(ctx, TZ_ERR_INVALID, "frames [%d, %d) outside the resident stack", first, first + count);
+    const size_t fsz = (size_t)ctx->H * ctx->W * 3;
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    TZ_TRY(tz_d2h(ctx, out, ctx->d_frames + (size_t)first * fsz, (size_t)count * fsz, ctx->stream));
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TZ_OK;
+}
+
+extern "C" int tz_payload_get(tz_ctx* ctx, size_t offset, size_t count, int16_t* out) {
+    if (!ctx || !out) return TZ_ERR_INVALID;
+    if (!ctx->d_payload || offset + count > ctx->payload_len) return tz_fail(ctx, TZ_ERR_INVALID, "payload range outside the resident payload");
+    TZ_TRY(tz_d2h(ctx, out, ctx->d_payload + offset, count * 2, ctx->stream));
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TZ_OK;
+}
+
 extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int W, int warm_up, int window,
                           double threshold, uint8_t* key_mask, double* mse_log) {
-    if (!ctx || !frames) return TZ_ERR_INVALID;
+    if (!ctx) return TZ_ERR_INVALID;
     if (window < 0) return tz_fail(ctx, TZ_ERR_INVALID, "window must be >= 0");
     if (nt < warm_up + 2)  // the reference breaks here
         return tz_fail(ctx, TZ_ERR_INVALID, "need at least warm_up+2 frames (nt=%d, warm_up=%d)", nt, warm_up);
@@ -818,8 +880,14 @@ static int remap_out(tz_ctx* ctx, const int16_t* d_sd, size_t N, const int16_t* 
 
 extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t* payload, int16_t* table,
                          int* table_len, int16_t* delta_out) {
-    if (!ctx || !payload || !table_len || (entropy && !table)) return TZ_ERR_INVALID;
+    if (!ctx || !table_len || ((entropy & 1) && !table)) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode needs a tz_rollout first");
+    if (!payload) {  // keep the payload in the context: it leaves through tz_payload_get
+        const size_t n = (size_t)ctx->nt * ctx->H * ctx->W * 3;
+        TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_payload, &ctx->cap_payload, n * 2));
+        ctx->payload_len = n;
+        payload = ctx->d_payload;
+    }
     if (mode < 0 || mode > 3) return tz_fail(ctx, TZ_ERR_INVALID, "unknown error-bound mode %d", mode);
     const int nt = ctx->nt, H = ctx->H, W = ctx->W;
     const size_t N = (size_t)nt * H * W * 3;

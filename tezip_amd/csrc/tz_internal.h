@@ -78,6 +78,9 @@ struct tz_ctx {
     hipEvent_t stage_ev[kStages] = {nullptr, nullptr, nullptr, nullptr};
     bool stage_busy[kStages] = {false, false, false, false};
     int stage_next = 0;
+    bool staged = false;                    // d_frames was filled by tz_frames_begin / tz_frames_put
+    int16_t* d_payload = nullptr;           // resident payload of a tz_encode(payload = NULL)
+    size_t cap_payload = 0, payload_len = 0;
     const uint8_t* pending_src = nullptr;  // host frame stack whose non-key frames are still to be sent
     std::vector<uint8_t> pending_sent;     // nt: 1 = already on its way
     std::vector<hipEvent_t> chunk_ev;  // payload chunk hand-over events (compute -> copy stream)

@@ -20,6 +20,14 @@ _MT = False
 ZSTD_c_compressionLevel, ZSTD_c_nbWorkers = 100, 400
 
 
+class _InBuffer(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+
+class _OutBuffer(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+
 def _bind(L):
     L.ZSTD_compressBound.restype = C.c_size_t
     L.ZSTD_compressBound.argtypes = [C.c_size_t]
@@ -40,6 +48,11 @@ def _bind(L):
     L.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.ZSTD_compress2.restype = C.c_size_t
     L.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.ZSTD_CCtx_setPledgedSrcSize.restype = C.c_size_t
+    L.ZSTD_CCtx_setPledgedSrcSize.argtypes = [C.c_void_p, C.c_ulonglong]
+    L.ZSTD_compressStream2.restype = C.c_size_t
+    L.ZSTD_compressStream2.argtypes = [C.c_void_p, C.POINTER(_OutBuffer), C.POINTER(_InBuffer), C.c_int]
+    L.ZSTD_CStreamOutSize.restype = C.c_size_t
 
 
 def _has_workers(L):
@@ -144,3 +157,56 @@ def decompress(data):
     if L.ZSTD_isError(n):
         raise RuntimeError("zstd: " + L.ZSTD_getErrorName(n).decode())
     return dst.raw[:n]
+
+
+class StreamCompressor:
+    """One standard zstd frame written piece by piece (ZSTD_compressStream2): the input never has
+    to exist as a whole in memory, and with `threads` > 1 libzstd compresses the pieces on its own
+    worker threads while the caller fetches the next one.  The total size is pledged up front so the
+    frame header carries the content size -- the reference's `zstd.decompress` needs it
+    (decompress.py:89,98)."""
+
+    def __init__(self, fileobj, total_bytes, level=9, threads=0):
+        self.L, self.f = _lib(), fileobj
+        self.cctx = self.L.ZSTD_createCCtx()
+        self.L.ZSTD_CCtx_setParameter(self.cctx, ZSTD_c_compressionLevel, int(level))
+        if threads > 1 and _MT:
+            self.L.ZSTD_CCtx_setParameter(self.cctx, ZSTD_c_nbWorkers, int(threads))
+        self._ck(self.L.ZSTD_CCtx_setPledgedSrcSize(self.cctx, int(total_bytes)))
+        self.cap = max(int(self.L.ZSTD_CStreamOutSize()), 1 << 20)
+        self.out = C.create_string_buffer(self.cap)
+        self.written = 0
+        self.fed = 0
+
+    def _ck(self, n):
+        if self.L.ZSTD_isError(n):
+            raise RuntimeError("zstd: " + self.L.ZSTD_getErrorName(n).decode())
+        return n
+
+    def _pump(self, ptr, size, directive):
+        ib = _InBuffer(ptr, size, 0)
+        while True:
+            ob = _OutBuffer(C.addressof(self.out), self.cap, 0)
+            left = self._ck(self.L.ZSTD_compressStream2(self.cctx, C.byref(ob), C.byref(ib), directive))
+            if ob.pos:
+                self.f.write(self.out.raw[:ob.pos] if ob.pos < self.cap else self.out.raw)
+                self.written += ob.pos
+            if directive == 0 and ib.pos == ib.size:
+                return
+            if directive != 0 and left == 0:
+                return
+
+    def write(self, arr):
+        """arr: C-contiguous numpy array (its memory is read in place)."""
+        self.fed += arr.nbytes
+        if arr.nbytes:
+            self._pump(arr.ctypes.data, arr.nbytes, 0)  # ZSTD_e_continue
+
+    def close(self):
+        if self.cctx:
+            try:
+                self._pump(None, 0, 2)                     # ZSTD_e_end
+            finally:
+                self.L.ZSTD_freeCCtx(self.cctx)
+                self.cctx = None
+        return self.written
