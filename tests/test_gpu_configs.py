@@ -169,9 +169,10 @@ def test_cfg5_512_swp_sweep_5_to_40_lossless(ctx):
         assert r["key_frames"] in (n_windows, n_windows + 1)  # + the last frame when it starts a window
     best = min(rows, key=lambda r: (r["total_bytes"], r["window"]))
     assert best["window"] == best_w and len(key_bytes) == best["key_bytes"] and len(ent_bytes) == best["entropy_bytes"]
-    # more key frames cost key_frame.dat bytes monotonically
-    kb = [r["key_bytes"] for r in rows]
-    assert all(a >= b for a, b in zip(kb, kb[1:]))
+    # key_frame.dat grows with the number of key frames
+    for a in rows:
+        for b in rows:
+            assert a["key_frames"] <= b["key_frames"] or a["key_bytes"] > b["key_bytes"]
     # the kept output is a complete reference-format pair: decode it
     key_stack = np.frombuffer(zstd.decompress(key_bytes), np.uint8).reshape(frames.shape)
     pl, tb, shape, warm = decompress.parse_stream(zstd.decompress(ent_bytes))

@@ -187,6 +187,21 @@ class FrameSource:
 PAYLOAD_CHUNK = 8 << 20  # int16 elements fetched and fed to zstd at a time
 
 
+class _Stages:
+    """Stage wall times of compress.run on stderr when TEZIP_TIMING is set (scripts/host_pipeline.py)."""
+
+    def __init__(self):
+        self.on = bool(os.environ.get("TEZIP_TIMING"))
+        self.t0 = self.last = time.perf_counter()
+
+    def mark(self, name):
+        if self.on:
+            import sys
+            now = time.perf_counter()
+            print("[tezip timing] %-34s %7.3f s  (at %.3f s)" % (name, now - self.last, now - self.t0), file=sys.stderr)
+            self.last = now
+
+
 def _stream_outputs(ctx, out_dir, nt, H, W, key, table, warm_up, shuffled, pool):
     """key_frame.dat and entropy.dat (compress.py:271-278, 375-400) from the context-resident frames
     and payload, piece by piece: nothing of size nt*H*W lives on the host."""
@@ -237,6 +252,7 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
                             VERBOSE, ENTROPY_RUN, device, SHUFFLE)
     if not os.path.exists(OUTPUT_DIR):
         os.mkdir(OUTPUT_DIR)
+    stages = _Stages()
     src = FrameSource(DATA_DIR)
     with open(os.path.join(OUTPUT_DIR, 'filename.txt'), 'w', encoding='UTF-8') as f:
         f.write(f"{int(src.is_rgb)}\n")
@@ -246,8 +262,11 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
     per_chunk = max(1, min(WINDOW_SIZE or 16, 64))
     with ThreadPoolExecutor(max_workers=io_threads() + 1) as pool:
         chunks = src.chunks(per_chunk, pool)   # decoding starts with the first next(); model + HIP start-up overlap it
+        stages.mark("list + probe + filename.txt")
         head = next(chunks)
+        stages.mark("first window decoded")
         cfg, wts, model_shape = open_model(WEIGHTS_DIR)
+        stages.mark("model directory read")
         hp, wp = padding_shape(H, W)
         if model_shape is not None and (model_shape[0] != hp or model_shape[1] != wp):
             print("ERROR:Image size is out of scope for this model.")
@@ -259,11 +278,13 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
             exit()
         nwin = 1 if WINDOW_SIZE is None else max(1, (nt - PREPROCESS + WINDOW_SIZE - 1) // WINDOW_SIZE)
         ctx = make_context(cfg, wts, hp, wp, min(nwin, 64), device)
+        stages.mark("context + model prepare")
         try:
             ctx.frames_begin(nt, H, W)
             ctx.frames_put(*head)
             for f0, view in chunks:
                 ctx.frames_put(f0, view)   # pageable ring buffer: free again when the call returns
+            stages.mark("remaining windows decoded + staged")
             if VERBOSE:
                 ctx.prof_enable(True)
             t0 = time.time()
@@ -274,7 +295,9 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
                     if key[i] and i > PREPROCESS:
                         print("move key point")
                 print("predict:{0}".format(time.time() - t0) + "[sec]")
+            stages.mark("rollout")
             _, table, _ = ctx.encode(MODE, BOUND_VALUE, ENTROPY_RUN, payload="resident", shuffle=SHUFFLE)
+            stages.mark("encode (payload resident)")
             if VERBOSE:
                 prof = ctx.prof_get()
                 print("error_bound:{0}".format(prof["quant"][0] / 1e3) + "[sec]")
@@ -282,6 +305,7 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
                 if ENTROPY_RUN:
                     print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
             _stream_outputs(ctx, OUTPUT_DIR, nt, H, W, key, table if ENTROPY_RUN else None, PREPROCESS, SHUFFLE, pool)
+            stages.mark("key_frame.dat + entropy.dat")
         finally:
             ctx.close()
 
