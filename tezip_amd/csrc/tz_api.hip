@@ -4,6 +4,7 @@
 #include <stdarg.h>
 
 #include <algorithm>
+#include <thread>
 
 #include "tz_internal.h"
 
@@ -168,6 +169,27 @@ static int stage_acquire(tz_ctx* ctx, int* idx) {
     return TZ_OK;
 }
 
+// memcpy between pageable memory and a pinned staging buffer on a few threads: one core moves
+// ~8-10 GB/s, a PCIe 5 x16 link four to five times that
+static void copy_mt(void* dst, const void* src, size_t n) {
+    constexpr size_t kMin = (size_t)2 << 20;
+    constexpr int kThreads = 4;
+    if (n < 2 * kMin) {
+        memcpy(dst, src, n);
+        return;
+    }
+    const size_t per = ((n + kThreads - 1) / kThreads + 4095) & ~(size_t)4095;
+    std::thread th[kThreads - 1];
+    int started = 0;
+    for (int i = 1; i < kThreads; ++i) {
+        const size_t off = per * i;
+        if (off >= n) break;
+        th[started++] = std::thread([=] { memcpy((uint8_t*)dst + off, (const uint8_t*)src + off, std::min(per, n - off)); });
+    }
+    memcpy(dst, src, std::min(per, n));
+    for (int i = 0; i < started; ++i) th[i].join();
+}
+
 int tz_h2d(tz_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (bytes == 0) return TZ_OK;
     if (tz_ptr_kind(src) != 0) {
@@ -179,7 +201,7 @@ int tz_h2d(tz_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s)
         const size_t n = std::min(tz_ctx::kStageBytes, bytes - off);
         int i;
         TZ_TRY(stage_acquire(ctx, &i));
-        memcpy(ctx->stage[i], (const uint8_t*)src + off, n);
+        copy_mt(ctx->stage[i], (const uint8_t*)src + off, n);
         TZ_HIP(ctx, hipMemcpyAsync((uint8_t*)dst + off, ctx->stage[i], n, hipMemcpyHostToDevice, s));
         TZ_HIP(ctx, hipEventRecord(ctx->stage_ev[i], s));
         ctx->stage_busy[i] = true;
@@ -206,7 +228,7 @@ int tz_d2h(tz_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s)
         if (prev >= 0) {
             TZ_HIP(ctx, hipEventSynchronize(ctx->stage_ev[prev]));
             ctx->stage_busy[prev] = false;
-            memcpy((uint8_t*)dst + prev_off, ctx->stage[prev], prev_n);
+            copy_mt((uint8_t*)dst + prev_off, ctx->stage[prev], prev_n);
         }
         prev = i;
         prev_off = off;
@@ -215,7 +237,7 @@ int tz_d2h(tz_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s)
     if (prev >= 0) {
         TZ_HIP(ctx, hipEventSynchronize(ctx->stage_ev[prev]));
         ctx->stage_busy[prev] = false;
-        memcpy((uint8_t*)dst + prev_off, ctx->stage[prev], prev_n);
+        copy_mt((uint8_t*)dst + prev_off, ctx->stage[prev], prev_n);
     }
     return TZ_OK;
 }
@@ -424,6 +446,62 @@ __global__ void k_bcast_frame(const float* __restrict__ src, size_t fe, const in
 // reads) go ahead and the compute stream waits for them only; rollout_finish_upload sends the rest
 // once the predictor launches are queued, so that the bulk of the stack (needed by the delta stage
 // only) crosses PCIe while the predictor runs.
+// ---- DWP control on the device (compress.py:245-264)
+struct DwpState {
+    int key_idx;   // first predicted frame of the open window (the reference's key_idx)
+    int pad;
+    double run;    // squared-error sum of the open window
+};
+
+__global__ void k_dwp_init(DwpState* st, int p, int nt, int* idx_table, int stride, uint8_t* key) {
+    st->key_idx = p + 1;
+    st->run = 0.0;
+    idx_table[0] = 1;              // idx == key_idx: the input of the first step is the real frame p
+    idx_table[stride] = p;
+    idx_table[2 * stride] = p + 1;
+    if (p < nt) key[p] = 1;        // compress.py:219-220
+}
+
+// One wave; lane 0 decides.  part[nblk]: the frame's per-block squared-error sums (k_sse), added in
+// block order exactly as tzk_sse does on the host.
+__global__ void k_dwp_decide(DwpState* st, const double* __restrict__ part, int nblk, int idx, int nt, double fe_pad,
+                             double threshold, int* idx_table, int stride, uint8_t* key, uint8_t* gfirst, double* mse,
+                             int* c0_flag) {
+    // all lanes fetch the partials at once (one memory round trip), lane 0 adds them in order
+    extern __shared__ double s_part[];
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) s_part[b] = part[b];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double t = 0.0;
+    for (int b = 0; b < nblk; ++b) t = t + s_part[b];
+    int key_idx = st->key_idx;
+    double run = st->run + t;
+    const double stop = run / ((double)(idx - key_idx + 1) * fe_pad);   // compress.py:246
+    mse[idx] = stop;
+    if (stop > threshold) {                                            // compress.py:249
+        gfirst[idx] = 1;
+        if (idx == nt - 1) key[idx] = 1;                               // compress.py:260-262
+        else c0_flag[idx] = 1;
+        key_idx = idx + 1;
+        run = 0.0;
+    }
+    st->key_idx = key_idx;
+    st->run = run;
+    const int nidx = idx + 1;                                          // selection of the next step (218-222)
+    if (nidx < nt) {
+        const int from_key = nidx == key_idx;
+        idx_table[0] = from_key;
+        idx_table[stride] = nidx - 1;
+        idx_table[2 * stride] = nidx;
+        if (from_key) key[nidx - 1] = 1;
+    }
+}
+
+__global__ void k_bcast_frame_if(const float* __restrict__ src, size_t fe, const int* __restrict__ flag, float* __restrict__ dst) {
+    if (!*flag) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < fe; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 static int rollout_setup(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int W, int warm_up,
                          const std::vector<int>* first = nullptr) {
     if (!ctx->model) return tz_fail(ctx, TZ_ERR_STATE, "no model loaded");
@@ -687,31 +765,59 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
             if (rc == TZ_OK) rc = fill_c0(ctx, dropped);  // slot 0 of the next group holds C0 (258)
         }
     } else {
-        // DWP: boundaries depend on the window MSE of the padded frames (compress.py:245-249)
+        // DWP: boundaries depend on the window MSE of the padded frames (compress.py:245-249).  The
+        // decision is taken ON THE DEVICE (k_dwp_decide): it sums the frame's partial squared errors
+        // in the fixed order, compares the window mean with the threshold, marks the key frame and
+        // writes the input selection of the next predictor step, so the host only queues launches
+        // -- no round trip per frame -- and reads the key mask / MSE log once at the end.
         rc = fill_c0(ctx, c0_slots);
-        int key_idx = p + 1;
-        double run = 0.0;
+        int Hp_, Wp_, maxB;
+        if (rc == TZ_OK) rc = tz_model_dims(ctx, &Hp_, &Wp_, &maxB);
+        const int nblk = tzk_sse_blocks(ctx->Hp, ctx->Wp);
+        void *d_state = nullptr, *d_part = nullptr, *d_key = nullptr, *d_gf = nullptr, *d_mse = nullptr, *d_flag = nullptr;
+        if (rc == TZ_OK) rc = tz_ensure(ctx, (void**)&ctx->d_sched, &ctx->cap_sched, 3 * (size_t)maxB * sizeof(int));
+        if (rc == TZ_OK) rc = tz_pool_alloc(ctx, sizeof(DwpState), &d_state);
+        if (rc == TZ_OK) rc = tz_pool_alloc(ctx, sizeof(double) * nblk, &d_part);
+        if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_key);
+        if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_gf);
+        if (rc == TZ_OK) rc = tz_pool_alloc(ctx, sizeof(double) * nt, &d_mse);
+        if (rc == TZ_OK) rc = tz_pool_alloc(ctx, sizeof(int) * nt, &d_flag);
+        if (rc == TZ_OK) rc = tz_upload(ctx, d_key, key.data(), nt);
+        if (rc == TZ_OK) rc = tz_upload(ctx, d_gf, gfirst.data(), nt);
+        if (rc == TZ_OK) {
+            hipError_t e = hipMemsetAsync(d_mse, 0, sizeof(double) * nt, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, sizeof(int) * nt, ctx->stream);
+            if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "DWP state: %s", hipGetErrorString(e));
+        }
+        const float* c0 = nullptr;
+        if (rc == TZ_OK) rc = tz_model_c0_dev(ctx, &c0);
+        if (rc == TZ_OK) {
+            hipLaunchKernelGGL(k_dwp_init, dim3(1), dim3(1), 0, ctx->stream, (DwpState*)d_state, p, nt, ctx->d_sched, maxB,
+                               (uint8_t*)d_key);
+            if (hipGetLastError() != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "k_dwp_init launch failed");
+        }
+        const int gx = (int)std::min<size_t>((fe_pad + 255) / 256, 1024);
         for (int idx = p + 1; idx < nt && rc == TZ_OK; ++idx) {
-            bool from_key = idx == key_idx;
-            if (from_key) key[idx - 1] = 1;
-            int isk = from_key ? 1 : 0, in = idx - 1, out = idx;
-            rc = tz_model_predict_batch(ctx, 1, &isk, &in, &out, ctx->d_frames, H, W, ctx->d_pred, ctx->d_pred);
+            rc = tz_model_predict_batch_dev(ctx, 1, ctx->d_sched, maxB, ctx->d_frames, H, W, ctx->d_pred, ctx->d_pred);
             if (rc != TZ_OK) break;
-            double sse = 0.0;
-            rc = tzk_sse(ctx, ctx->d_frames + (size_t)idx * H * W * 3, ctx->d_pred + (size_t)idx * fe_pad, 1, H, W,
-                         ctx->Hp, ctx->Wp, &sse);
+            rc = tzk_sse_launch(ctx, ctx->d_frames + (size_t)idx * H * W * 3, ctx->d_pred + (size_t)idx * fe_pad, 1, H, W,
+                                ctx->Hp, ctx->Wp, (double*)d_part);
             if (rc != TZ_OK) break;
-            run = run + sse;
-            double stop = run / (double)((size_t)(idx - key_idx + 1) * fe_pad);
-            mse[idx] = stop;
-            if (stop > threshold) {
-                gfirst[idx] = 1;
-                std::vector<int> one(1, idx);
-                if (idx != nt - 1) rc = fill_c0(ctx, one);  // slot 0 of the new group holds C0 (258)
-                if (idx == nt - 1) key[idx] = 1;           // ... or keeps the prediction (260-262)
-                key_idx = idx + 1;
-                run = 0.0;
-            }
+            hipLaunchKernelGGL(k_dwp_decide, dim3(1), dim3(256), sizeof(double) * nblk, ctx->stream, (DwpState*)d_state, (const double*)d_part, nblk,
+                               idx, nt, (double)fe_pad, threshold, ctx->d_sched, maxB, (uint8_t*)d_key, (uint8_t*)d_gf,
+                               (double*)d_mse, (int*)d_flag);
+            // slot 0 of the new group holds C0 (258); the last frame keeps its prediction (260-262)
+            if (idx != nt - 1)
+                hipLaunchKernelGGL(k_bcast_frame_if, dim3(gx), dim3(256), 0, ctx->stream, c0, fe_pad, (const int*)d_flag + idx,
+                                   ctx->d_pred + (size_t)idx * fe_pad);
+            if (hipGetLastError() != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "DWP launch failed");
+        }
+        if (rc == TZ_OK) {
+            hipError_t e = hipMemcpyAsync(key.data(), d_key, nt, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(gfirst.data(), d_gf, nt, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(mse.data(), d_mse, sizeof(double) * nt, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "DWP result download: %s", hipGetErrorString(e));
         }
     }
     for (int i = 0; i < nt; ++i)

@@ -189,8 +189,10 @@ static constexpr int QW = 15;  // worker waves per chain (+1 resolver wave = 102
 
 struct QSlot {
     double cu[64], cl[64], pu[64], pl[64];
+    double ou[64], ol[64];         // (u, l) of the run that is open at the chunk end when the chain enters at s
     unsigned long long heads[64];  // heads[s]: bit mask of the nxt-chain that starts at s
     int nxt[64];
+    int olast[64];                 // head (lane) of that open run = top bit of heads[s]
 };
 
 __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ orig, const int16_t* __restrict__ diff,
@@ -280,6 +282,14 @@ __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ or
                     }
                 }
                 sl.heads[lane] = M;
+                // 2c. what the resolver needs once it knows where the carried run breaks (s = this
+                // lane): the state of the run left open at the chunk end.  Looked up here, by 15 waves
+                // in parallel, it is one lane read on the resolver's serial path instead of a
+                // mask read, a count-leading-zeros and a second lane read.
+                const int lastl = 63 - __clzll((long long)M);
+                sl.ou[lane] = shfl_d(cu, lastl);
+                sl.ol[lane] = shfl_d(cl, lastl);
+                sl.olast[lane] = lastl;
             }
         } else if (wv == 0 && r > 0) {
             // The walk over the chunks is the serial critical path of the whole kernel (the workers
@@ -288,13 +298,15 @@ __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ or
             // while chunk w resolves, and the lookups at the wave-uniform positions j0 / last are
             // register reads (v_readlane), not LDS permutes.
             struct Pre {
-                double pu, pl, cu, cl;
+                double pu, pl, cu, cl, ou, ol, tu, tl;
                 unsigned long long hd;
-                int nx;
+                int nx, olast;
             };
             auto load = [&](int w) {
                 const QSlot& sl = slots[(r - 1) & 1][w];
-                return Pre{sl.pu[lane], sl.pl[lane], sl.cu[lane], sl.cl[lane], sl.heads[lane], sl.nxt[lane]};
+                // tu / tl: the chunk totals, the same LDS word for every lane (a broadcast read)
+                return Pre{sl.pu[lane], sl.pl[lane], sl.cu[lane], sl.cl[lane], sl.ou[lane], sl.ol[lane], sl.pu[63], sl.pl[63],
+                           sl.heads[lane], sl.nxt[lane], sl.olast[lane]};
             };
             auto rl_d = [](double v, int src) {  // src is wave-uniform
                 const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -310,9 +322,9 @@ __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ or
                 // 4. where does the carried run break?
                 const double eu = u < cur.pu ? u : cur.pu, el = l > cur.pl ? l : cur.pl;
                 const unsigned long long brk = __ballot(eu - el < 0.0);
-                if (brk == 0ull) {
-                    u = rl_d(eu, 63);
-                    l = rl_d(el, 63);
+                if (brk == 0ull) {  // the run swallows the chunk: no lane read at all
+                    u = u < cur.tu ? u : cur.tu;
+                    l = l > cur.tl ? l : cur.tl;
                     cur = nx;
                     continue;
                 }
@@ -325,16 +337,16 @@ __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ or
                     }
                     if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
                 }
+                // the serial path continues with the state of the run open at the chunk end ...
+                u = rl_d(cur.ou, j0);
+                l = rl_d(cur.ol, j0);
+                chead = ch * 64 + __builtin_amdgcn_readlane(cur.olast, j0);
+                // 5. ... while the closed runs store their value at their head (off that path)
                 const unsigned long long heads =
                     ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cur.hd >> 32), j0) << 32) |
                     (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cur.hd, j0);
-                const int last = 63 - __clzll((long long)heads);
-                // 5. closed runs store their value at their head; the last head carries on
                 if (((heads >> lane) & 1ull) && cur.nx < 64)
                     t[(size_t)(ch * 64 + lane) * 3 + c] = (int16_t)(long long)((cur.cu + cur.cl) / 2);
-                u = rl_d(cur.cu, last);
-                l = rl_d(cur.cl, last);
-                chead = ch * 64 + last;
                 cur = nx;
             }
         }
@@ -968,19 +980,26 @@ __global__ __launch_bounds__(256) void k_sse(const uint8_t* __restrict__ orig, c
     if (threadIdx.x == 0) partial[(size_t)f * nblk + b] = s[0];
 }
 
+int tzk_sse_blocks(int Hp, int Wp) { return (int)(((size_t)Hp * Wp * 3 + 4095) / 4096); }
+
+// launch only: per-block partial sums of nframes frames into d_part[nframes][tzk_sse_blocks]
+int tzk_sse_launch(tz_ctx* ctx, const uint8_t* orig, const float* pred, int nframes, int H, int W, int Hp, int Wp,
+                   double* d_part) {
+    if (nframes <= 0) return TZ_OK;
+    const int nblk = tzk_sse_blocks(Hp, Wp);
+    tz_prof_scope ps(ctx, TZP_SSE);
+    hipLaunchKernelGGL(k_sse, dim3(nblk, nframes), dim3(256), 0, ctx->stream, orig, pred, H, W, Hp, Wp, nblk, d_part);
+    TZ_HIP(ctx, hipGetLastError());
+    return TZ_OK;
+}
+
 int tzk_sse(tz_ctx* ctx, const uint8_t* orig, const float* pred, int nframes, int H, int W, int Hp, int Wp,
             double* h_sse) {
     if (nframes <= 0) return TZ_OK;
-    size_t n = (size_t)Hp * Wp * 3;
-    int nblk = (int)((n + 4095) / 4096);
+    const int nblk = tzk_sse_blocks(Hp, Wp);
     void* d_part;
     TZ_TRY(tz_pool_alloc(ctx, sizeof(double) * nblk * nframes, &d_part));
-    {
-        tz_prof_scope ps(ctx, TZP_SSE);
-        hipLaunchKernelGGL(k_sse, dim3(nblk, nframes), dim3(256), 0, ctx->stream, orig, pred, H, W, Hp, Wp, nblk,
-                           (double*)d_part);
-        TZ_HIP(ctx, hipGetLastError());
-    }
+    TZ_TRY(tzk_sse_launch(ctx, orig, pred, nframes, H, W, Hp, Wp, (double*)d_part));
     std::vector<double> part((size_t)nblk * nframes);
     TZ_HIP(ctx, hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, ctx->stream));
     TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));

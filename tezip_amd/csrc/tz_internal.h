@@ -163,6 +163,9 @@ int tzk_reconstruct(tz_ctx*, const float* pred, const uint8_t* key, const uint8_
                     int nframes, int H, int W, int Hp, int Wp, uint8_t* out);
 int tzk_sse(tz_ctx*, const uint8_t* orig, const float* pred, int nframes, int H, int W, int Hp, int Wp,
             double* h_sse);
+int tzk_sse_blocks(int Hp, int Wp);
+int tzk_sse_launch(tz_ctx*, const uint8_t* orig, const float* pred, int nframes, int H, int W, int Hp, int Wp,
+                   double* d_part);
 // tz_prednet.hip
 void tz_model_free(tz_ctx* ctx);
 int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int* h_in_idx, const int* h_out_idx,
