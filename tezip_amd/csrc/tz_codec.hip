@@ -189,10 +189,8 @@ static constexpr int QW = 15;  // worker waves per chain (+1 resolver wave = 102
 
 struct QSlot {
     double cu[64], cl[64], pu[64], pl[64];
-    double ou[64], ol[64];         // (u, l) of the run that is open at the chunk end when the chain enters at s
     unsigned long long heads[64];  // heads[s]: bit mask of the nxt-chain that starts at s
     int nxt[64];
-    int olast[64];                 // head (lane) of that open run = top bit of heads[s]
 };
 
 __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ orig, const int16_t* __restrict__ diff,
@@ -282,14 +280,6 @@ __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ or
                     }
                 }
                 sl.heads[lane] = M;
-                // 2c. what the resolver needs once it knows where the carried run breaks (s = this
-                // lane): the state of the run left open at the chunk end.  Looked up here, by 15 waves
-                // in parallel, it is one lane read on the resolver's serial path instead of a
-                // mask read, a count-leading-zeros and a second lane read.
-                const int lastl = 63 - __clzll((long long)M);
-                sl.ou[lane] = shfl_d(cu, lastl);
-                sl.ol[lane] = shfl_d(cl, lastl);
-                sl.olast[lane] = lastl;
             }
         } else if (wv == 0 && r > 0) {
             // The walk over the chunks is the serial critical path of the whole kernel (the workers
@@ -298,15 +288,13 @@ __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ or
             // while chunk w resolves, and the lookups at the wave-uniform positions j0 / last are
             // register reads (v_readlane), not LDS permutes.
             struct Pre {
-                double pu, pl, cu, cl, ou, ol, tu, tl;
+                double pu, pl, cu, cl;
                 unsigned long long hd;
-                int nx, olast;
+                int nx;
             };
             auto load = [&](int w) {
                 const QSlot& sl = slots[(r - 1) & 1][w];
-                // tu / tl: the chunk totals, the same LDS word for every lane (a broadcast read)
-                return Pre{sl.pu[lane], sl.pl[lane], sl.cu[lane], sl.cl[lane], sl.ou[lane], sl.ol[lane], sl.pu[63], sl.pl[63],
-                           sl.heads[lane], sl.nxt[lane], sl.olast[lane]};
+                return Pre{sl.pu[lane], sl.pl[lane], sl.cu[lane], sl.cl[lane], sl.heads[lane], sl.nxt[lane]};
             };
             auto rl_d = [](double v, int src) {  // src is wave-uniform
                 const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -322,9 +310,9 @@ __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ or
                 // 4. where does the carried run break?
                 const double eu = u < cur.pu ? u : cur.pu, el = l > cur.pl ? l : cur.pl;
                 const unsigned long long brk = __ballot(eu - el < 0.0);
-                if (brk == 0ull) {  // the run swallows the chunk: no lane read at all
-                    u = u < cur.tu ? u : cur.tu;
-                    l = l > cur.tl ? l : cur.tl;
+                if (brk == 0ull) {
+                    u = rl_d(eu, 63);
+                    l = rl_d(el, 63);
                     cur = nx;
                     continue;
                 }
@@ -337,16 +325,16 @@ __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ or
                     }
                     if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
                 }
-                // the serial path continues with the state of the run open at the chunk end ...
-                u = rl_d(cur.ou, j0);
-                l = rl_d(cur.ol, j0);
-                chead = ch * 64 + __builtin_amdgcn_readlane(cur.olast, j0);
-                // 5. ... while the closed runs store their value at their head (off that path)
                 const unsigned long long heads =
                     ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cur.hd >> 32), j0) << 32) |
                     (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cur.hd, j0);
+                const int last = 63 - __clzll((long long)heads);
+                // 5. closed runs store their value at their head; the last head carries on
                 if (((heads >> lane) & 1ull) && cur.nx < 64)
                     t[(size_t)(ch * 64 + lane) * 3 + c] = (int16_t)(long long)((cur.cu + cur.cl) / 2);
+                u = rl_d(cur.cu, last);
+                l = rl_d(cur.cl, last);
+                chead = ch * 64 + last;
                 cur = nx;
             }
         }
