@@ -1,0 +1,67 @@
+"""bench.py's launch contract, checked without a GPU: `--gpus N` outside torchrun must start the N
+ranks itself -- as a fresh torch.distributed.run child on 127.0.0.1, before anything in the parent
+touches the GPU -- and pass the driver's flags through; under torchrun (WORLD_SIZE set) it must not
+spawn again."""
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture()
+def bench(monkeypatch):
+    monkeypatch.syspath_prepend(ROOT)
+    import importlib
+    import bench as b
+    return importlib.reload(b)
+
+
+def test_gpus_flag_spawns_the_ranks(bench, monkeypatch):
+    calls = {}
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        calls["cmd"], calls["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: pytest.fail("the parent must not initialise the GPU"))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = calls["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert calls["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    assert "TEZIP_BENCH_SINGLE_DEVICE" not in calls["env"]           # 8 GPUs visible: one rank per GPU over RCCL
+
+
+def test_fewer_gpus_than_ranks_rehearses_on_one_device_over_gloo(bench, monkeypatch):
+    calls = {}
+
+    class R:
+        returncode = 0
+
+    monkeypatch.setattr(bench.subprocess, "run", lambda cmd, env=None, **kw: calls.update(cmd=cmd, env=env) or R())
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("TEZIP_BENCH_BACKEND", raising=False)
+    assert bench.spawn_ranks(2, ["--gpus", "2"]) == 0
+    assert calls["env"]["TEZIP_BENCH_SINGLE_DEVICE"] == "1" and calls["env"]["TEZIP_BENCH_BACKEND"] == "gloo"
+
+
+def test_flop_accounting_matches_the_design_numbers(bench):
+    from tezip_amd.prednet import PredNetConfig
+    cfg = PredNetConfig()
+    assert bench.live_flops_per_px0(cfg) == 416754      # executed live work per level-0 pixel and frame
+    assert bench.conv16_flops_per_px0(cfg) == 405504    # ... of which k_conv16 (levels >= 1)
