@@ -135,6 +135,14 @@ int tz_encode_delta(tz_ctx* ctx, int mode, double b0, double b1, int16_t* delta_
  * nt*H*W*3 of that rollout: the reference fails at its reshape otherwise (decompress.py:240). */
 int tz_decode(tz_ctx* ctx, const int16_t* payload, size_t payload_len, const int16_t* table, int table_len,
               uint8_t* frames_out);
+/* Streaming decode (decompress.py:87-113 decompresses and holds both files whole): stage the
+ * payload in pieces -- tz_payload_begin(count), tz_payload_put(offset, count, src) on the copy
+ * stream -- and the key-frame stack with tz_frames_begin / tz_frames_put, then tz_rollout_decode
+ * with key_frames == NULL and tz_decode with payload == NULL; with frames_out == NULL the decoded
+ * frames stay in the context and are fetched window by window with tz_decoded_get. */
+int tz_payload_begin(tz_ctx* ctx, size_t count);
+int tz_payload_put(tz_ctx* ctx, size_t offset, size_t count, const int16_t* src);
+int tz_decoded_get(tz_ctx* ctx, int first, int count, uint8_t* out);
 /* Last stage of tz_decode only (decompress.py:252-256): reconstruct from an already decoded
  * int16 delta stack (sharded decoding: the inverse scan carry comes from the previous shard). */
 int tz_decode_delta(tz_ctx* ctx, const int16_t* delta, uint8_t* frames_out);

@@ -43,6 +43,9 @@ _SIGS = {
     "tz_frames_put": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "tz_frames_fence": (C.c_int, [C.c_void_p]),
     "tz_frames_get": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tz_payload_begin": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "tz_payload_put": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "tz_decoded_get": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "tz_payload_get": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "tz_get_predictions": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tz_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
@@ -249,6 +252,19 @@ class Context:
         self._ck(self.lib.tz_frames_get(self.h, int(first), int(count), _ptr(out)))
         return out
 
+    def payload_begin(self, count):
+        self._ck(self.lib.tz_payload_begin(self.h, int(count)))
+
+    def payload_put(self, offset, piece):
+        self._ck(self.lib.tz_payload_put(self.h, int(offset), _numel(piece), _ptr(piece, np.int16)))
+
+    def decoded_get(self, first, count, out=None):
+        nt, h, w = self._shape
+        if out is None:
+            out = np.empty((count, h, w, 3), np.uint8)
+        self._ck(self.lib.tz_decoded_get(self.h, int(first), int(count), _ptr(out)))
+        return out
+
     def payload_get(self, offset, count, out=None):
         if out is None:
             out = np.empty(count, np.int16)
@@ -270,10 +286,15 @@ class Context:
         return key.astype(bool), mse
 
     def rollout_decode(self, key_frames, warm_up):
-        self._check_stack(key_frames, "key_frames")
-        nt, h, w = key_frames.shape[:3]
+        """key_frames: the (nt,H,W,3) key stack, or None after frames_begin / frames_put."""
+        if key_frames is None:
+            nt, h, w = self._staged
+        else:
+            self._check_stack(key_frames, "key_frames")
+            nt, h, w = key_frames.shape[:3]
         key = np.zeros(nt, np.uint8)
-        self._ck(self.lib.tz_rollout_decode(self.h, _ptr(key_frames, np.uint8), nt, h, w, warm_up, key.ctypes.data))
+        self._ck(self.lib.tz_rollout_decode(self.h, None if key_frames is None else _ptr(key_frames, np.uint8), nt, h, w,
+                                            warm_up, key.ctypes.data))
         self._shape = (nt, h, w)
         return key.astype(bool)
 
@@ -334,14 +355,20 @@ class Context:
         return out
 
     def decode(self, payload, table, out=None):
+        """payload None: the pieces staged with payload_begin / payload_put.  out="resident": the
+        frames stay in the context (decoded_get)."""
         nt, h, w = self._shape
-        if _numel(payload) != nt * h * w * 3:  # decompress.py:240: the reference's reshape raises
-            raise ValueError("payload holds %d elements, expected %d" % (_numel(payload), nt * h * w * 3))
-        if out is None:
+        n = nt * h * w * 3
+        if payload is not None and _numel(payload) != n:  # decompress.py:240: the reference's reshape raises
+            raise ValueError("payload holds %d elements, expected %d" % (_numel(payload), n))
+        resident = isinstance(out, str) and out == "resident"
+        if resident:
+            out = None
+        elif out is None:
             out = np.empty((nt, h, w, 3), np.uint8)
         tl = -1 if table is None else len(table)
         tb = None if table is None else np.ascontiguousarray(table, np.int16)
-        self._ck(self.lib.tz_decode(self.h, _ptr(payload), _numel(payload), _ptr(tb), tl, _ptr(out)))
+        self._ck(self.lib.tz_decode(self.h, None if payload is None else _ptr(payload), n, _ptr(tb), tl, _ptr(out)))
         return out
 
     # ---- operator seams

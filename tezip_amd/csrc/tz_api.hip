@@ -88,6 +88,7 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
     if (ctx->d_pred) (void)hipFree(ctx->d_pred);
     if (ctx->d_sched) (void)hipFree(ctx->d_sched);
     if (ctx->d_payload) (void)hipFree(ctx->d_payload);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
     for (auto& s : ctx->prof)
         for (auto& e : s.pending) {
             (void)hipEventDestroy(e.first);
@@ -681,6 +682,31 @@ extern "C" int tz_frames_get(tz_ctx* ctx, int first, int count, uint8_t* out) {
     return TZ_OK;
 }
 
+extern "C" int tz_payload_begin(tz_ctx* ctx, size_t count) {
+    if (!ctx) return TZ_ERR_INVALID;
+    TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_payload, &ctx->cap_payload, std::max<size_t>(count, 8) * 2));
+    ctx->payload_len = count;
+    TZ_HIP(ctx, hipEventRecord(ctx->ev_compute, ctx->stream));  // earlier work may still read the old payload
+    TZ_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compute, 0));
+    return TZ_OK;
+}
+
+extern "C" int tz_payload_put(tz_ctx* ctx, size_t offset, size_t count, const int16_t* src) {
+    if (!ctx || !src) return TZ_ERR_INVALID;
+    if (!ctx->d_payload || offset + count > ctx->payload_len) return tz_fail(ctx, TZ_ERR_INVALID, "payload range outside the staged payload");
+    return tz_h2d(ctx, ctx->d_payload + offset, src, count * 2, ctx->copy_stream);
+}
+
+extern "C" int tz_decoded_get(tz_ctx* ctx, int first, int count, uint8_t* out) {
+    if (!ctx || !out) return TZ_ERR_INVALID;
+    if (!ctx->d_out || !ctx->have_decoded || first < 0 || count < 0 || first + count > ctx->nt)
+        return tz_fail(ctx, TZ_ERR_INVALID, "frames [%d, %d) outside the resident decoded stack", first, first + count);
+    const size_t fsz = (size_t)ctx->H * ctx->W * 3;
+    TZ_TRY(tz_d2h(ctx, out, ctx->d_out + (size_t)first * fsz, (size_t)count * fsz, ctx->stream));
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TZ_OK;
+}
+
 extern "C" int tz_payload_get(tz_ctx* ctx, size_t offset, size_t count, int16_t* out) {
     if (!ctx || !out) return TZ_ERR_INVALID;
     if (!ctx->d_payload || offset + count > ctx->payload_len) return tz_fail(ctx, TZ_ERR_INVALID, "payload range outside the resident payload");
@@ -839,7 +865,7 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
 
 extern "C" int tz_rollout_decode(tz_ctx* ctx, const uint8_t* key_frames, int nt, int H, int W, int warm_up,
                                  uint8_t* key_mask) {
-    if (!ctx || !key_frames) return TZ_ERR_INVALID;
+    if (!ctx) return TZ_ERR_INVALID;
     int rc = rollout_setup(ctx, key_frames, nt, H, W, warm_up);
     if (rc != TZ_OK) return rc;
     // decompress.py:123-129: a frame is a key frame iff it has a non-zero sample
@@ -1146,11 +1172,23 @@ extern "C" int tz_decode_delta(tz_ctx* ctx, const int16_t* delta, uint8_t* frame
 
 extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, size_t payload_len, const int16_t* table, int table_len,
                          uint8_t* frames_out) {
-    if (!ctx || !payload || !frames_out) return TZ_ERR_INVALID;
+    if (!ctx) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || !ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_decode needs a tz_rollout_decode first");
     if (table_len > TZ_NBINS || (table_len >= 0 && !table && table_len > 0)) return tz_fail(ctx, TZ_ERR_INVALID, "bad table");
     const int nt = ctx->nt, H = ctx->H, W = ctx->W;
     const size_t N = (size_t)nt * H * W * 3;
+    if (!payload) {  // staged with tz_payload_begin / tz_payload_put (on the copy stream)
+        if (!ctx->d_payload || ctx->payload_len < N) return tz_fail(ctx, TZ_ERR_STATE, "no staged payload of %zu elements", N);
+        TZ_HIP(ctx, hipEventRecord(ctx->ev_frames, ctx->copy_stream));
+        TZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_frames, 0));
+        payload = ctx->d_payload;
+    }
+    ctx->have_decoded = false;
+    if (!frames_out) {  // keep the frames in the context: tz_decoded_get
+        TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_out, &ctx->cap_out, N));
+        frames_out = ctx->d_out;
+        ctx->have_decoded = true;
+    }
     if (payload_len != N)  // decompress.py:240: the reshape raises
         return tz_fail(ctx, TZ_ERR_INVALID, "payload holds %zu elements, the key-frame stack implies %zu", payload_len, N);
     std::vector<tz_out> outs;

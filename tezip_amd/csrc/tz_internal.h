@@ -81,6 +81,9 @@ struct tz_ctx {
     bool staged = false;                    // d_frames was filled by tz_frames_begin / tz_frames_put
     int16_t* d_payload = nullptr;           // resident payload of a tz_encode(payload = NULL)
     size_t cap_payload = 0, payload_len = 0;
+    uint8_t* d_out = nullptr;               // resident decoded frames of a tz_decode(frames_out = NULL)
+    size_t cap_out = 0;
+    bool have_decoded = false;
     const uint8_t* pending_src = nullptr;  // host frame stack whose non-key frames are still to be sent
     std::vector<uint8_t> pending_sent;     // nt: 1 = already on its way
     std::vector<hipEvent_t> chunk_ev;  // payload chunk hand-over events (compute -> copy stream)

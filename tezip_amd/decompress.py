@@ -45,6 +45,114 @@ def check_stream(shape, warm_up, payload_len, key_len):
         raise ValueError("entropy.dat: warm-up count %d outside [0, %d)" % (warm_up, nt))
 
 
+TAIL_ELEMS = _lib.TZ_NBINS + 8  # the longest trailer: table (<= 2111 symbols) + T + shape(5) + warm_up
+
+
+def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shape, VERBOSE, device):
+    """decompress.py:87-279 with nothing of size nt*H*W on the host: entropy.dat is decompressed
+    piece by piece straight into HBM (the trailer is read from the last piece), key_frame.dat
+    likewise, the decoded frames come back window by window and are PNG-encoded on a thread pool
+    while the next window is fetched.  Returns False when the stream needs the whole-array path
+    (this build's opt-in byte-shuffled payload)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from .compress import io_threads
+    paths = {n: os.path.join(DATA_DIR, n) for n in ("key_frame.dat", "entropy.dat")}
+    for n in ("key_frame.dat", "entropy.dat"):
+        if not os.path.exists(paths[n]):
+            print("ERROR: No such file or directory:", paths[n])
+            exit()
+    ctx = _lib.Context(device)
+    try:
+        ctx.load_model(cfg, wts)
+        tail = np.zeros(0, np.int16)
+        total = off = 0
+        with open(paths["entropy.dat"], "rb") as f:
+            for size, piece in zstd.stream_decompress(f):
+                if total == 0:
+                    if size % 2 or size < 16:
+                        raise ValueError("entropy.dat is too short")
+                    total = size // 2
+                    ctx.payload_begin(total)
+                if piece.size % 2:
+                    raise ValueError("entropy.dat: odd-sized piece")
+                p16 = piece.view(np.int16)
+                ctx.payload_put(off, p16)       # staged on the copy stream; the piece buffer is free on return
+                off += p16.size
+                tail = np.concatenate([tail, p16[-TAIL_ELEMS:]])[-TAIL_ELEMS:]
+        if off != total:
+            raise ValueError("entropy.dat: truncated stream")
+        warm_up, shape, tlen = int(tail[-1]), tuple(int(v) for v in tail[-6:-1]), int(tail[-7])
+        if tlen < -1 or tlen > tail.size - 7:
+            raise ValueError("corrupt table length %d" % tlen)
+        table = None if tlen == -1 else np.ascontiguousarray(tail[tail.size - 7 - tlen: tail.size - 7])
+        payload_len = total - 7 - max(tlen, 0)
+        with open(paths["key_frame.dat"], "rb") as f:
+            head = f.read(64)
+        key_len = zstd.content_size(head)
+        check_stream(shape, warm_up, payload_len, key_len)
+        if shape[0] == SHUFFLE_MARK:
+            return False
+        _, nt, H, W, C = shape
+        hp, wp = padding_shape(H, W)
+        if model_shape is not None and (model_shape[0] != hp or model_shape[1] != wp):
+            print("ERROR:keyframe size and model size do not match.")
+            print("model size: height ", model_shape[0] - 7, "～", model_shape[0], " width ", model_shape[1] - 7, "～", model_shape[1])
+            print("key frame size: height ", H, " width ", W)
+            exit()
+        if len(file_names) != nt:
+            print("ERROR：The lengths of filename.txt and images do not match.")
+            print("filename.txt：", len(file_names))
+            print("number of images", nt)
+            exit()
+        ctx.prepare(hp, wp, 64 if nt > 64 else max(1, nt))
+        fb = H * W * C
+        per = max(1, (16 << 20) // fb)
+        ctx.frames_begin(nt, H, W)
+        first = 0
+        with open(paths["key_frame.dat"], "rb") as f:
+            for _, piece in zstd.stream_decompress(f, piece_bytes=per * fb):
+                k = piece.size // fb
+                ctx.frames_put(first, piece[: k * fb].reshape(k, H, W, C))
+                first += k
+        if first != nt:
+            raise ValueError("key_frame.dat: truncated stream")
+        if VERBOSE:
+            ctx.prof_enable(True)
+        t0 = time.time()
+        ctx.rollout_decode(None, warm_up)
+        if VERBOSE:
+            print("predict:{0}".format(time.time() - t0) + "[sec]")
+        ctx.decode(None, table, out="resident")
+        if VERBOSE:
+            prof = ctx.prof_get()
+            if table is not None:
+                print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
+            print("finding_difference:{0}".format(prof["undelta_scan"][0] / 1e3) + "[sec]")
+        print("save as RGB" if isRGB else "save as gray")
+        ring = [np.empty((per, H, W, C), np.uint8) for _ in range(3)]
+        busy = [[], [], []]
+
+        def save(buf, j, name):
+            # decompress.py:272-278: the grayscale save is overwritten by an unconditional RGB save
+            Image.fromarray(buf[j]).save(os.path.join(OUTPUT_DIR, name))
+
+        with ThreadPoolExecutor(max_workers=io_threads()) as pool:  # PIL's encoder releases the GIL
+            for ci, f0 in enumerate(range(0, nt, per)):
+                k = min(per, nt - f0)
+                slot = ci % 3
+                for ft in busy[slot]:
+                    ft.result()           # the encoders of the window that used this buffer are done
+                ctx.decoded_get(f0, k, out=ring[slot][:k])
+                busy[slot] = [pool.submit(save, ring[slot], j, file_names[f0 + j]) for j in range(k)]
+            for fs in busy:
+                for ft in fs:
+                    ft.result()
+    finally:
+        ctx.close()
+    return True
+
+
 def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
     if not GPU_FLAG:
         print("ERROR: this build runs the decompression path on an AMD MI355X only (no CPU path).")
@@ -65,6 +173,10 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
         isRGB = bool(int(file_names.pop(0)))
 
     cfg, wts, model_shape = open_model(WEIGHTS_DIR)
+    if job is None and not os.environ.get("TEZIP_NO_STREAMING"):
+        done = _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shape, VERBOSE, device)
+        if done:
+            return
 
     def read(name):
         try:

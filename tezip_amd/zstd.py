@@ -53,6 +53,10 @@ def _bind(L):
     L.ZSTD_compressStream2.restype = C.c_size_t
     L.ZSTD_compressStream2.argtypes = [C.c_void_p, C.POINTER(_OutBuffer), C.POINTER(_InBuffer), C.c_int]
     L.ZSTD_CStreamOutSize.restype = C.c_size_t
+    L.ZSTD_createDCtx.restype = C.c_void_p
+    L.ZSTD_freeDCtx.argtypes = [C.c_void_p]
+    L.ZSTD_decompressStream.restype = C.c_size_t
+    L.ZSTD_decompressStream.argtypes = [C.c_void_p, C.POINTER(_OutBuffer), C.POINTER(_InBuffer)]
 
 
 def _has_workers(L):
@@ -210,3 +214,59 @@ class StreamCompressor:
                 self.L.ZSTD_freeCCtx(self.cctx)
                 self.cctx = None
         return self.written
+
+
+def content_size(head):
+    """Decompressed size announced by the frame header (`head`: at least the first 18 bytes)."""
+    L = _lib()
+    size = L.ZSTD_getFrameContentSize(bytes(head), len(head))
+    if size in (2 ** 64 - 1, 2 ** 64 - 2):
+        raise RuntimeError("zstd: frame without a content size (not written by zstd.compress)")
+    return int(size)
+
+
+def stream_decompress(fileobj, piece_bytes=16 << 20, read_bytes=4 << 20):
+    """Generator over the decompressed content of ONE zstd frame read from `fileobj`: yields
+    (content_size, uint8 numpy piece) with pieces of `piece_bytes` (the last one shorter); the
+    yielded array is reused by the next iteration.  Raises like decompress() when the frame has
+    no content size (the reference's frames always carry it)."""
+    import numpy as np
+    L = _lib()
+    head = fileobj.read(read_bytes)
+    size = L.ZSTD_getFrameContentSize(head, len(head))
+    if size in (2 ** 64 - 1, 2 ** 64 - 2):
+        raise RuntimeError("zstd: frame without a content size (not written by zstd.compress)")
+    dctx = L.ZSTD_createDCtx()
+    out = np.empty(max(1, min(piece_bytes, int(size))), np.uint8)
+    try:
+        src = head
+        produced = 0
+        ob = _OutBuffer(out.ctypes.data, out.size, 0)
+        eof = False
+        while produced < size:
+            buf = C.create_string_buffer(src, len(src)) if src else C.create_string_buffer(1)
+            ib = _InBuffer(C.addressof(buf), len(src), 0)
+            progressed = False
+            while produced + ob.pos < size:
+                before = (ib.pos, ob.pos)
+                n = L.ZSTD_decompressStream(dctx, C.byref(ob), C.byref(ib))
+                if L.ZSTD_isError(n):
+                    raise RuntimeError("zstd: " + L.ZSTD_getErrorName(n).decode())
+                progressed = progressed or (ib.pos, ob.pos) != before
+                if ob.pos == ob.size:
+                    produced += ob.pos
+                    yield int(size), out[:ob.pos]
+                    ob = _OutBuffer(out.ctypes.data, out.size, 0)
+                elif ib.pos == ib.size:
+                    break  # needs more input (or only flushes what it still holds)
+            if produced + ob.pos >= size:
+                break
+            if eof and not progressed:
+                raise RuntimeError("zstd: truncated frame")
+            src = fileobj.read(read_bytes)
+            eof = not src
+        if ob.pos:
+            produced += ob.pos
+            yield int(size), out[:ob.pos]
+    finally:
+        L.ZSTD_freeDCtx(dctx)
