@@ -361,7 +361,7 @@ def main():
     conv_ms, conv_n = prof["conv3x3_mfma"]
     flops_step = live_flops_per_px0(cfg) * H * W * n_pred
     conv_tflops = flops_step / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    SUB = ("conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general")  # sub-classes of conv3x3_mfma
+    SUB = ("conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general", "convlat_small_grid")  # sub-classes of conv3x3_mfma
     step_dev_ms = sum(v[0] for k, v in prof.items() if k not in SUB)
     c16_ms, c16_n = prof["conv16_lds_dma"]               # the dominant kernel on its own
     c16_flops = conv16_flops_per_px0(cfg) * H * W * n_pred

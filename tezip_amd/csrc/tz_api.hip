@@ -48,6 +48,8 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
     {
         const char* e = getenv("TEZIP_CONV16");  // diagnostic default of tz_set_conv_impl
         if (e && e[0] == '0') ctx->conv_impl = 0;
+        e = getenv("TEZIP_LAT_MAX_WG");          // 0 = never use k_convlat
+        if (e) ctx->lat_max_wg = atoi(e);
     }
     ctx->device = device;
     if (hip_stream) {
@@ -357,7 +359,8 @@ tz_prof_scope::~tz_prof_scope() {
 
 static const char* kProfNames[TZP_COUNT] = {"conv3x3_mfma", "err0", "delta", "quant", "spatial_delta_hist",
                                             "lut_remap", "undelta_scan", "reconstruct", "sse",
-                                            "conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general"};
+                                            "conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general",
+                                            "convlat_small_grid"};
 
 extern "C" int tz_prof_enable(tz_ctx* ctx, int on) {
     if (!ctx) return TZ_ERR_INVALID;

@@ -38,6 +38,7 @@ struct ConvArgs {
     const float* Wp;    // [weight slots * 16][ncols], slot order = the K-loop order (see pack_conv)
     const float* Wimg;  // the same weights in LDS image order for k_conv16 (see pack_conv), or null
     const float* Wblk;  // block-step image for k_conv16b (see pack_block_image), or null
+    const float* Wlat;  // per-wave fragment image for k_convlat: [slot][column block][4 column tiles][lane][k-step], or null
     const float* zero;  // >= 16 bytes of zeros: LDS-DMA source of out-of-image patch pixels
     int ncols;
     const float* bias;  // [ncols]
@@ -750,6 +751,243 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     if (UPS) run_phase(std::true_type{}, nbe, nblk);
     __builtin_amdgcn_s_setprio(0);
     conv_epilogue<NT, EPI, MAP>(a, acc, n, cb, ty0, tx0, wv, lane, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_convlat: the same convolutions (same fmaf chains, same epilogue arithmetic) for launches that
+// are too small to fill the chip -- 64x64 / 128x160 frames, where a level is 1-6 of k_conv16's
+// 16x16-pixel tiles.  There the launch costs what ONE workgroup costs, and a k_conv16 wave walks the
+// K loop with 8 MFMAs per k-step plus a barrier per 32 MFMAs with nobody to overlap with: 234 us for
+// the top-level gates whatever the frame size.  The chain order forbids splitting K, so the only
+// way to shorten the critical path is to give every wave ONE accumulator tile and to put the tiles
+// on as many SIMDs as there are:
+//   workgroup = 4 waves = 16 pixels x one column block; wave w owns column tile w (for the gate
+//   convolutions: the i | f | g | o columns of 16 channels, so the LSTM update still sees its four
+//   gates inside one workgroup, through 4 KB of LDS);
+//   16 pixels = a 4x4 block (MAP_LINEAR / MAP_POOL: the 4 accumulator registers of a lane are one
+//   2x2 pooling window) or one parity class of an 8x8 region (MAP_PARITY: the collapsed weights of
+//   an upsampled source depend on the parity class);
+//   B fragments never touch LDS: the weights are packed a third time, per (slot, column block,
+//   column tile) as [lane][k-step], so a lane's four k-steps of a slot are ONE 16-byte global load,
+//   prefetched LAT_D slots ahead in registers (nothing is shared between waves, hence no barrier);
+//   A fragments come from a halo patch in LDS (6x6 / 10x10 pixels x 16 channels per block,
+//   channels stored [element][k-step] so that a lane's four k-steps are one ds_read_b128), staged one
+//   block ahead through registers, one barrier per 16-channel block.
+// Per slot a wave issues 4 dependent MFMAs (the chain), i.e. the K loop runs at the latency of the
+// matrix pipe: 3456/4 k-steps x ~36 cycles = 13 us for the top level instead of 234.
+static constexpr int LAT_D = 8;    // weight prefetch depth in slots
+static constexpr int LPS = 20;     // floats per patch pixel in LDS: 16 channels + 4 (bank spread, 16-byte aligned)
+
+template <int MAP>
+__device__ __forceinline__ void lat_row_to_pixel(int r, int pc, int& py, int& px) {
+    if (MAP == MAP_POOL) {  // rows 4g..4g+3 = the 2x2 window g of the 4x4 block
+        const int g = r >> 2, q = r & 3;
+        py = 2 * (g >> 1) + (q >> 1);
+        px = 2 * (g & 1) + (q & 1);
+    } else if (MAP == MAP_PARITY) {  // parity class pc of an 8x8 region
+        py = 2 * (r >> 2) + (pc >> 1);
+        px = 2 * (r & 3) + (pc & 1);
+    } else {
+        py = r >> 2;
+        px = r & 3;
+    }
+}
+
+template <int EPI, bool UPS>
+__global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
+    constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
+    constexpr int TS = MAP == MAP_PARITY ? 8 : 4;      // tile footprint in pixels
+    constexpr int PWL = TS + 2, PPL = PWL * PWL;       // same-resolution halo patch
+    constexpr int LWL = 6, LPL = LWL * LWL;            // half-resolution patch of an upsampled source
+    constexpr int NIT = (PPL * 4 + 255) / 256;         // staging items (pixel, channel quad) per thread
+    __shared__ __attribute__((aligned(16))) float sP[2][PPL * LPS];
+    __shared__ float sE[4 * 16 * 17];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NTW = a.ncols / (16 * a.ncb);            // column tiles per block: 3 or 4
+    const int ltx = (a.W + TS - 1) / TS, lty = (a.H + TS - 1) / TS;
+    const int ntiles = ltx * lty * (MAP == MAP_PARITY ? 4 : 1);
+    int bid = blockIdx.x;
+    const int cb = bid % a.ncb;
+    bid /= a.ncb;
+    const int tile = bid % ntiles, n = bid / ntiles;
+    const int pc = MAP == MAP_PARITY ? (tile & 3) : 0;
+    const int reg = MAP == MAP_PARITY ? (tile >> 2) : tile;
+    const int ty0 = (reg / ltx) * TS, tx0 = (reg % ltx) * TS;
+    const int g = lane >> 4;
+    const bool active = wv < NTW;
+
+    const int nb0 = a.src[0].cpt;
+    const int nblk = nb0 + (a.nsrc > 1 ? a.src[1].cpt : 0);
+    const bool up0 = UPS && a.src[0].up != 0;
+    const int nbe = up0 ? 0 : (UPS && a.nsrc > 1 && a.src[1].up ? nb0 : nblk);  // same-resolution blocks
+
+    // ---- patch staging: global -> registers (one block ahead) -> LDS, channels permuted to [element][k-step]
+    float4 stg[NIT];
+    auto fetch_patch = [&](int blk) {
+        const bool s1 = blk >= nb0;
+        const ConvSrc& s = s1 ? a.src[1] : a.src[0];
+        const int c0 = (s1 ? blk - nb0 : blk) * 16;
+        const float* base = s.p + (long long)n * s.nstride;
+        const bool up = UPS && blk >= nbe;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it, p = i >> 2, q = i & 3;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (up) {
+                const int Y = p / LWL, X = p - Y * LWL;
+                const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
+                if (p < LPL && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1))
+                    v = *(const float4*)(base + ((long long)ly * (a.W >> 1) + lx) * s.pstride + c0 + 4 * q);
+            } else {
+                const int Y = p / PWL, X = p - Y * PWL;
+                const int yy = ty0 - 1 + Y, xx = tx0 - 1 + X;
+                if (p < PPL && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+                    v = *(const float4*)(base + ((long long)yy * a.W + xx) * s.pstride + c0 + 4 * q);
+            }
+            stg[it] = v;
+        }
+    };
+    auto store_patch = [&](int buf, bool up) {
+        float* d = sP[buf];
+        const int np = up ? LPL : PPL;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it, p = i >> 2, q = i & 3;
+            if (p < np) {
+                d[p * LPS + 0 + q] = stg[it].x;   // element e of quad q is channel 4q + e = k-step q, element e
+                d[p * LPS + 4 + q] = stg[it].y;
+                d[p * LPS + 8 + q] = stg[it].z;
+                d[p * LPS + 12 + q] = stg[it].w;
+            }
+        }
+    };
+
+    // ---- accumulator: rows 4g..4g+3 of the tile, column lane&15 of this wave's column tile
+    const int col = cb * (NTW * 16) + wv * 16 + (lane & 15);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        if (a.init) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int py, px;
+                lat_row_to_pixel<MAP>(4 * g + r, pc, py, px);
+                const int y = ty0 + py, x = tx0 + px;
+                const long long pix = (y < a.H && x < a.W) ? (long long)y * a.W + x : 0;
+                acc[r] = a.init[pix * a.ncols + col];
+            }
+        } else {
+            const float b = a.bias[col];
+            acc = (f32x4){b, b, b, b};
+        }
+    }
+    // LDS float offsets of this lane's A row (GEMM row lane&15, element g) for tap (0,0)
+    int abase, abase_lo;
+    {
+        int py, px;
+        lat_row_to_pixel<MAP>(lane & 15, pc, py, px);
+        abase = (py * PWL + px) * LPS + g * 4;
+        abase_lo = (((py >> 1) + (py & 1)) * LWL + (px >> 1) + (px & 1)) * LPS + g * 4;
+    }
+    const long long wstride = (long long)a.ncb * 1024;                                 // floats between slots of Wlat
+    const float* wlane = a.Wlat + ((long long)cb * 4 + (active ? wv : 0)) * 256 + lane * 4;
+
+    int slot0 = 0;
+    auto run_phase = [&](auto upc, int b0, int b1) {
+        constexpr bool UP = decltype(upc)::value;
+        constexpr int SPB = UP ? 4 : 9;                   // steps (weight slots this wave uses) per block
+        if (b0 >= b1) return;
+        const int T = (b1 - b0) * SPB;
+        auto wslot = [&](int t) {                          // slot index of step t of this phase
+            return UP ? slot0 + (t >> 2) * 16 + (t & 3) * 4 + pc : slot0 + t;
+        };
+        f32x4 wq[LAT_D];
+#pragma unroll
+        for (int j = 0; j < LAT_D; ++j)
+            if (active && j < T) wq[j] = *(const f32x4*)(wlane + wslot(j) * wstride);
+        // first patch of the phase (every wave is done with the previous phase's buffers)
+        __syncthreads();
+        fetch_patch(b0);
+        store_patch(0, UP);
+        int buf = 0;
+#pragma unroll 1
+        for (int t0 = 0; t0 < T; t0 += LAT_D) {
+#pragma unroll
+            for (int j = 0; j < LAT_D; ++j) {
+                const int t = t0 + j;
+                if (t < T) {
+                    const int blk = t / SPB, st = t - blk * SPB;
+                    if (st == 0) {
+                        if (t > 0) {
+                            buf ^= 1;
+                            store_patch(buf, UP);          // fetched while the previous block computed
+                        }
+                        __syncthreads();
+                        if (b0 + blk + 1 < b1) fetch_patch(b0 + blk + 1);
+                    }
+                    if (active) {
+                        const f32x4 w = wq[j];
+                        if (t + LAT_D < T) wq[j] = *(const f32x4*)(wlane + wslot(t + LAT_D) * wstride);
+                        int off;
+                        if (UP) off = abase_lo + ((st >> 1) * LWL + (st & 1)) * LPS;
+                        else off = abase + ((st / 3) * PWL + (st % 3)) * LPS;
+                        const f32x4 fa = *(const f32x4*)(sP[buf] + off);
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kk], w[kk], acc, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        slot0 += (b1 - b0) * (UP ? 16 : 9);
+    };
+    run_phase(std::false_type{}, 0, nbe);
+    if (UPS) run_phase(std::true_type{}, nbe, nblk);
+
+    // ---- epilogues: the arithmetic of conv_epilogue, re-distributed
+    if (EPI == EPI_LSTM) {
+        // wave w holds gate w (i | f | g | o) of channels cb*16 .. cb*16+15 for the 16 pixels
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sE[(wv * 16 + 4 * g + r) * 17 + (lane & 15)] = acc[r];
+        }
+        __syncthreads();
+        const int row = tid >> 4, j = tid & 15, ch = cb * 16 + j, R = a.Cout;
+        int py, px;
+        lat_row_to_pixel<MAP>(row, pc, py, px);
+        const int y = ty0 + py, x = tx0 + px;
+        if (y < a.H && x < a.W) {
+            const long long pix = (long long)y * a.W + x;
+            const float cp = a.aux ? a.aux[pix * R + ch] : 0.0f;
+            const float gi = tz_hard_sigmoid(sE[(0 * 16 + row) * 17 + j]);
+            const float gf = tz_hard_sigmoid(sE[(1 * 16 + row) * 17 + j]);
+            const float gg = tz_tanh(sE[(2 * 16 + row) * 17 + j]);
+            const float go = tz_hard_sigmoid(sE[(3 * 16 + row) * 17 + j]);
+            const float t1 = gf * cp;
+            const float t2 = gi * gg;
+            const float c = t1 + t2;
+            const float rr = go * tz_tanh(c);
+            a.out0[(long long)n * a.out0_nstride + pix * R + ch] = rr;
+            if (a.out1) a.out1[(long long)n * a.out1_nstride + pix * R + ch] = c;
+        }
+    } else if (EPI == EPI_POOL_ERR) {
+        // prednet.py:289-291 then 274-277 of the next level; a lane's 4 registers are window g
+        const int H2 = a.H >> 1, W2 = a.W >> 1, C = a.Cout;
+        const int yp = (ty0 >> 1) + (g >> 1), xp = (tx0 >> 1) + (g & 1);
+        if (active && col < C && yp < H2 && xp < W2) {
+            const long long pp = (long long)yp * W2 + xp;
+            const float h = a.aux[pp * C + col];
+            float m = tz_relu(acc[0]);
+#pragma unroll
+            for (int r = 1; r < 4; ++r) {
+                const float t = tz_relu(acc[r]);
+                if (t > m) m = t;
+            }
+            const float d1 = h - m, d2 = m - h;
+            float* o = a.out0 + (long long)n * a.out0_nstride;
+            o[pp * 2 * C + col] = tz_relu(d1);
+            o[pp * 2 * C + C + col] = tz_relu(d2);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -27,6 +27,7 @@ enum tz_prof_class {
     TZP_CONV16B,    // k_conv16b: level-0 block-step kernel
     TZP_CONV_SMALL, // k_conv_small: direct VALU 3 -> 3 convolution
     TZP_CONV_GEN,   // k_conv3x3: general kernel
+    TZP_CONVLAT,    // k_convlat: one accumulator tile per wave, for grids that cannot fill the chip
     TZP_COUNT
 };
 
@@ -50,6 +51,7 @@ struct tz_ctx {
     // model + rollout state
     tz_model* model = nullptr;
     int conv_impl = 1;                // tz_set_conv_impl: 1 = LDS-DMA kernels where they apply
+    int lat_max_wg = 150;             // k_conv16 grids up to this many workgroups go to k_convlat (TEZIP_LAT_MAX_WG)
     // rollout-resident data
     int nt = 0, H = 0, W = 0, Hp = 0, Wp = 0, warm_up = 0;
     uint8_t* d_frames = nullptr;      // nt*H*W*3 (encoder: originals; decoder: key stack)

@@ -33,6 +33,7 @@ struct PackedConv {
     float* d_W = nullptr;
     float* d_Wimg = nullptr;  // LDS image order for k_conv16 (every source a multiple of 16 channels), else null
     float* d_Wblk = nullptr;  // block-step image for k_conv16b (first source <= 8 channels at stride 8), else null
+    float* d_Wlat = nullptr;  // per-wave fragment image for k_convlat (same condition as d_Wimg), else null
     const float* d_zero = nullptr;
     float* d_bias = nullptr;
     int nslots = 0, ncols = 0, NT = 1, ncb = 1;
@@ -165,6 +166,18 @@ static int pack_conv(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, con
         TZ_TRY(dmalloc(ctx, m, (void**)&pc->d_Wimg, I.size() * 4));
         TZ_HIP(ctx, hipMemcpy(pc->d_Wimg, I.data(), I.size() * 4, hipMemcpyHostToDevice));
         pc->d_zero = m->d_zero;
+        // k_convlat's image: [slot][column block][column tile (4, the last one empty when NT = 3)][lane][k-step]:
+        // the four k-steps of a lane's B fragment are one 16-byte load
+        std::fill(I.begin(), I.end(), 0.0f);
+        for (int sl = 0; sl < nslots; ++sl)
+            for (int cb = 0; cb < ncb; ++cb)
+                for (int nt = 0; nt < NT; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int kk = 0; kk < 4; ++kk)
+                            I[((((size_t)sl * ncb + cb) * 4 + nt) * 64 + lane) * 4 + kk] =
+                                W[((size_t)sl * 16 + 4 * kk + (lane >> 4)) * ncols + cb * NT * 16 + nt * 16 + (lane & 15)];
+        TZ_TRY(dmalloc(ctx, m, (void**)&pc->d_Wlat, I.size() * 4));
+        TZ_HIP(ctx, hipMemcpy(pc->d_Wlat, I.data(), I.size() * 4, hipMemcpyHostToDevice));
     }
     // k_conv16b's image: block 0 = the <= 8-channel same-resolution source [cb][tap][k-step 0..1][lane][NTI]
     // (padded to whole 1 KB pieces), then per 16-channel block of the upsampled source
@@ -282,6 +295,19 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         TZ_CASE16B(1, EPI_POOL_ERR, false) TZ_CASE16B(3, EPI_POOL_ERR, false) TZ_CASE16B(4, EPI_POOL_ERR, false)
 #undef TZ_CASE16B
     }
+    // grids that cannot fill the chip: one accumulator tile per wave (k_convlat), see the kernel's header
+    if (a.Wlat && a.nsrc > 0 && fullk && ctx->conv_impl && (NT == 3 || NT == 4) && (epi == EPI_LSTM || epi == EPI_POOL_ERR) &&
+        !(epi == EPI_LSTM && NT != 4) && a.ncb * a.tiles_x * a.tiles_y * nbatch <= ctx->lat_max_wg) {
+        const int ts = (epi != EPI_POOL_ERR && ups) ? 8 : 4;
+        const int ltiles = ((a.W + ts - 1) / ts) * ((a.H + ts - 1) / ts) * (ts == 8 ? 4 : 1);
+        const int blocks = a.ncb * ltiles * nbatch;
+        ps.sub = TZP_CONVLAT;
+        if (epi == EPI_LSTM && ups) hipLaunchKernelGGL((k_convlat<EPI_LSTM, true>), dim3(blocks), dim3(256), 0, ctx->stream, a);
+        else if (epi == EPI_LSTM) hipLaunchKernelGGL((k_convlat<EPI_LSTM, false>), dim3(blocks), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_convlat<EPI_POOL_ERR, false>), dim3(blocks), dim3(256), 0, ctx->stream, a);
+        TZ_HIP(ctx, hipGetLastError());
+        return TZ_OK;
+    }
     if (a.Wimg && a.nsrc > 0 && fullk && ctx->conv_impl) {
 #define TZ_CASE16(nt, e, u)                          \
     if (NT == nt && epi == e && ups == u) {          \
@@ -324,6 +350,7 @@ static void fill_srcs(ConvArgs& a, const PackedConv& pc, const float* const* ptr
     a.Wp = pc.d_W;
     a.Wimg = pc.d_Wimg;
     a.Wblk = pc.d_Wblk;
+    a.Wlat = pc.d_Wlat;
     a.zero = pc.d_zero;
     a.bias = pc.d_bias;
     a.ncols = pc.ncols;
