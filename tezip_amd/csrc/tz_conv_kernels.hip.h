@@ -775,8 +775,27 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
 //   block ahead through registers, one barrier per 16-channel block.
 // Per slot a wave issues 4 dependent MFMAs (the chain), i.e. the K loop runs at the latency of the
 // matrix pipe: 3456/4 k-steps x ~36 cycles = 13 us for the top level instead of 234.
-static constexpr int LAT_D = 8;    // weight prefetch depth in slots
-static constexpr int LPS = 20;     // floats per patch pixel in LDS: 16 channels + 4 (bank spread, 16-byte aligned)
+static constexpr int LAT_D = 16;   // weight ring entries per wave (prefetch distance LAT_D - 1 slots)
+
+template <int N>
+__device__ __forceinline__ void wait_vmn() {
+    static_assert(N == 0 || N == 4 || N == 9 || N == LAT_D - 1, "immediate of s_waitcnt");
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+}
+static_assert(LAT_D == 16, "wait_vmn encodes LAT_D - 1 = 15");
+
+// 16-byte LDS read the compiler does not see as one: a plain load from the ring would make it wait
+// for EVERY outstanding LDS-DMA of the same array (vmcnt(0)) in front of each read, i.e. drain the
+// prefetch ring every slot; the explicit vmcnt above is the exact condition.
+__device__ __forceinline__ f32x4 lds_read16_opaque(const float* p) {
+    const unsigned addr = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
 
 template <int MAP>
 __device__ __forceinline__ void lat_row_to_pixel(int r, int pc, int& py, int& px) {
@@ -799,8 +818,11 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     constexpr int TS = MAP == MAP_PARITY ? 8 : 4;      // tile footprint in pixels
     constexpr int PWL = TS + 2, PPL = PWL * PWL;       // same-resolution halo patch
     constexpr int LWL = 6, LPL = LWL * LWL;            // half-resolution patch of an upsampled source
-    constexpr int NIT = (PPL * 4 + 255) / 256;         // staging items (pixel, channel quad) per thread
-    __shared__ __attribute__((aligned(16))) float sP[2][PPL * LPS];
+    constexpr int NPI = (PPL * 4 + 255) / 256;         // patch DMA instructions per wave (items = pixel x channel quad)
+    // LDS: per-wave weight rings (LAT_D x 1 KB each), two patch buffers (16 floats per pixel, as in
+    // memory), the gate exchange of the LSTM epilogue
+    __shared__ __attribute__((aligned(16))) float sW[4 * LAT_D * 256];
+    __shared__ __attribute__((aligned(16))) float sP[2][NPI * 256 * 4];
     __shared__ float sE[4 * 16 * 17];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -822,44 +844,31 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     const bool up0 = UPS && a.src[0].up != 0;
     const int nbe = up0 ? 0 : (UPS && a.nsrc > 1 && a.src[1].up ? nb0 : nblk);  // same-resolution blocks
 
-    // ---- patch staging: global -> registers (one block ahead) -> LDS, channels permuted to [element][k-step]
-    float4 stg[NIT];
-    auto fetch_patch = [&](int blk) {
+    // ---- LDS-DMA issue (item i = pixel i>>2, channel quad i&3 -> 16 bytes at float offset 4i: the
+    // patch keeps the memory layout, 16 floats per pixel)
+    auto issue_patch = [&](int blk, int buf, bool up) {
         const bool s1 = blk >= nb0;
         const ConvSrc& s = s1 ? a.src[1] : a.src[0];
         const int c0 = (s1 ? blk - nb0 : blk) * 16;
         const float* base = s.p + (long long)n * s.nstride;
-        const bool up = UPS && blk >= nbe;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + 256 * it, p = i >> 2, q = i & 3;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < NPI; ++k) {
+            const int i = (k * 4 + wv) * 64 + lane, p = i >> 2, q = i & 3;
+            const float* src = a.zero;
             if (up) {
+                if ((k * 4 + wv) * 64 >= LPL * 4) continue;   // wave-uniform: nothing of this piece is needed
                 const int Y = p / LWL, X = p - Y * LWL;
                 const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
                 if (p < LPL && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1))
-                    v = *(const float4*)(base + ((long long)ly * (a.W >> 1) + lx) * s.pstride + c0 + 4 * q);
+                    src = base + ((long long)ly * (a.W >> 1) + lx) * s.pstride + c0 + 4 * q;
             } else {
+                if ((k * 4 + wv) * 64 >= PPL * 4) continue;
                 const int Y = p / PWL, X = p - Y * PWL;
                 const int yy = ty0 - 1 + Y, xx = tx0 - 1 + X;
                 if (p < PPL && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
-                    v = *(const float4*)(base + ((long long)yy * a.W + xx) * s.pstride + c0 + 4 * q);
+                    src = base + ((long long)yy * a.W + xx) * s.pstride + c0 + 4 * q;
             }
-            stg[it] = v;
-        }
-    };
-    auto store_patch = [&](int buf, bool up) {
-        float* d = sP[buf];
-        const int np = up ? LPL : PPL;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + 256 * it, p = i >> 2, q = i & 3;
-            if (p < np) {
-                d[p * LPS + 0 + q] = stg[it].x;   // element e of quad q is channel 4q + e = k-step q, element e
-                d[p * LPS + 4 + q] = stg[it].y;
-                d[p * LPS + 8 + q] = stg[it].z;
-                d[p * LPS + 12 + q] = stg[it].w;
-            }
+            glds16(src, sP[buf] + (k * 4 + wv) * 256);
         }
     };
 
@@ -881,67 +890,89 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
             acc = (f32x4){b, b, b, b};
         }
     }
-    // LDS float offsets of this lane's A row (GEMM row lane&15, element g) for tap (0,0)
+    // LDS float offsets of this lane's A row (GEMM row lane&15, element g of a quad) for tap (0,0)
     int abase, abase_lo;
     {
         int py, px;
         lat_row_to_pixel<MAP>(lane & 15, pc, py, px);
-        abase = (py * PWL + px) * LPS + g * 4;
-        abase_lo = (((py >> 1) + (py & 1)) * LWL + (px >> 1) + (px & 1)) * LPS + g * 4;
+        abase = (py * PWL + px) * 16 + g;
+        abase_lo = (((py >> 1) + (py & 1)) * LWL + (px >> 1) + (px & 1)) * 16 + g;
     }
     const long long wstride = (long long)a.ncb * 1024;                                 // floats between slots of Wlat
     const float* wlane = a.Wlat + ((long long)cb * 4 + (active ? wv : 0)) * 256 + lane * 4;
+    float* wring = sW + wv * (LAT_D * 256);
 
+    // The K loop: per slot (16 channels x one tap) the wave reads its four B k-steps (one
+    // ds_read_b128 of its private ring entry) and four A values (patch), issues the DMA of the slot
+    // LAT_D - 1 ahead into the entry it consumed last, and runs 4 dependent MFMAs.  All memory
+    // traffic is LDS-DMA, so the waits are explicit: DMAs of a wave complete in order, hence
+    // vmcnt(LAT_D - 1) = "the slot I am about to read has landed" (younger patch DMAs only make the
+    // wait longer), and a patch, issued one block ahead of that block's SPB weight slots, has landed
+    // at vmcnt(SPB).  One barrier per 16-channel block (the patch is shared by the 4 waves).
     int slot0 = 0;
     auto run_phase = [&](auto upc, int b0, int b1) {
         constexpr bool UP = decltype(upc)::value;
-        constexpr int SPB = UP ? 4 : 9;                   // steps (weight slots this wave uses) per block
+        constexpr int SPB = UP ? 4 : 9;                   // slots this wave uses per block
         if (b0 >= b1) return;
         const int T = (b1 - b0) * SPB;
-        auto wslot = [&](int t) {                          // slot index of step t of this phase
-            return UP ? slot0 + (t >> 2) * 16 + (t & 3) * 4 + pc : slot0 + t;
+        auto wsrc = [&](int t) {                          // step t of this phase -> its weights
+            const int slot = UP ? slot0 + (t >> 2) * 16 + (t & 3) * 4 + pc : slot0 + t;
+            return wlane + slot * wstride;
         };
-        f32x4 wq[LAT_D];
-#pragma unroll
-        for (int j = 0; j < LAT_D; ++j)
-            if (active && j < T) wq[j] = *(const f32x4*)(wlane + wslot(j) * wstride);
-        // first patch of the phase (every wave is done with the previous phase's buffers)
+        __syncthreads();                                  // every wave is done with the previous phase's patches
+        issue_patch(b0, 0, UP);
+        if (active)
+            for (int j = 0; j < LAT_D - 1 && j < T; ++j) glds16(wsrc(j), wring + j * 256);
+        // the patch is older than those LAT_D - 1 weight slots (a wave without a column tile -- NT = 3 --
+        // has issued nothing but its part of the patch)
+        if (active && T >= LAT_D - 1) wait_vmn<LAT_D - 1>();
+        else wait_vmn<0>();
         __syncthreads();
-        fetch_patch(b0);
-        store_patch(0, UP);
-        int buf = 0;
+        int buf = 0, tb = 0, rb = 0;
 #pragma unroll 1
-        for (int t0 = 0; t0 < T; t0 += LAT_D) {
+        for (int blk = b0; blk < b1; ++blk) {
+            if (blk > b0) {
+                if (active && tb + LAT_D - 2 < T) wait_vmn<SPB>();  // all SPB slots of the previous block issued a DMA behind the patch
+                else wait_vmn<0>();
+                __syncthreads();
+                buf ^= 1;
+            }
+            if (blk + 1 < b1) issue_patch(blk + 1, buf ^ 1, UP);
+            const float* pa = sP[buf];
 #pragma unroll
-            for (int j = 0; j < LAT_D; ++j) {
-                const int t = t0 + j;
-                if (t < T) {
-                    const int blk = t / SPB, st = t - blk * SPB;
-                    if (st == 0) {
-                        if (t > 0) {
-                            buf ^= 1;
-                            store_patch(buf, UP);          // fetched while the previous block computed
-                        }
-                        __syncthreads();
-                        if (b0 + blk + 1 < b1) fetch_patch(b0 + blk + 1);
+            for (int st = 0; st < SPB; ++st) {
+                if (active) {
+                    const int t = tb + st;
+                    int r = rb + st;
+                    if (r >= LAT_D) r -= LAT_D;
+                    if (t + LAT_D - 1 < T) {
+                        int rp = r - 1;                    // the entry consumed by the previous slot
+                        if (rp < 0) rp += LAT_D;
+                        glds16(wsrc(t + LAT_D - 1), wring + rp * 256);
+                        wait_vmn<LAT_D - 1>();
+                    } else {
+                        wait_vmn<0>();
                     }
-                    if (active) {
-                        const f32x4 w = wq[j];
-                        if (t + LAT_D < T) wq[j] = *(const f32x4*)(wlane + wslot(t + LAT_D) * wstride);
-                        int off;
-                        if (UP) off = abase_lo + ((st >> 1) * LWL + (st & 1)) * LPS;
-                        else off = abase + ((st / 3) * PWL + (st % 3)) * LPS;
-                        const f32x4 fa = *(const f32x4*)(sP[buf] + off);
+                    const f32x4 w = lds_read16_opaque(wring + r * 256 + lane * 4);
+                    int off;
+                    if (UP) off = abase_lo + ((st >> 1) * LWL + (st & 1)) * 16;
+                    else off = abase + ((st / 3) * PWL + (st % 3)) * 16;
+                    float fa[4];
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kk], w[kk], acc, 0, 0, 0);
-                    }
+                    for (int kk = 0; kk < 4; ++kk) fa[kk] = pa[off + 4 * kk];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kk], w[kk], acc, 0, 0, 0);
                 }
             }
+            tb += SPB;
+            rb += SPB;
+            if (rb >= LAT_D) rb -= LAT_D;
         }
         slot0 += (b1 - b0) * (UP ? 16 : 9);
     };
     run_phase(std::false_type{}, 0, nbe);
     if (UPS) run_phase(std::true_type{}, nbe, nblk);
+    __syncthreads();
 
     // ---- epilogues: the arithmetic of conv_epilogue, re-distributed
     if (EPI == EPI_LSTM) {
