@@ -775,27 +775,28 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
 //   block ahead through registers, one barrier per 16-channel block.
 // Per slot a wave issues 4 dependent MFMAs (the chain), i.e. the K loop runs at the latency of the
 // matrix pipe: 3456/4 k-steps x ~36 cycles = 13 us for the top level instead of 234.
-static constexpr int LAT_D = 16;   // weight ring entries per wave (prefetch distance LAT_D - 1 slots)
-
 template <int N>
 __device__ __forceinline__ void wait_vmn() {
-    static_assert(N == 0 || N == 4 || N == 9 || N == LAT_D - 1, "immediate of s_waitcnt");
+    static_assert(N == 0 || N == 4 || N == 6 || N == 7 || N == 9 || N == 14 || N == 15, "immediate of s_waitcnt");
     if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
 }
-static_assert(LAT_D == 16, "wait_vmn encodes LAT_D - 1 = 15");
 
 // 16-byte LDS read the compiler does not see as one: a plain load from the ring would make it wait
 // for EVERY outstanding LDS-DMA of the same array (vmcnt(0)) in front of each read, i.e. drain the
 // prefetch ring every slot; the explicit vmcnt above is the exact condition.
-__device__ __forceinline__ f32x4 lds_read16_opaque(const float* p) {
+__device__ __forceinline__ f32x4 lds_read16_opaque(const float* p) {   // issue only: lds_wait(v) before v is used
     const unsigned addr = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
     f32x4 v;
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
+__device__ __forceinline__ void lds_wait(f32x4& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory"); }
 
 template <int MAP>
 __device__ __forceinline__ void lat_row_to_pixel(int r, int pc, int& py, int& px) {
@@ -812,7 +813,10 @@ __device__ __forceinline__ void lat_row_to_pixel(int r, int pc, int& py, int& px
     }
 }
 
-template <int EPI, bool UPS>
+// LAT_D = weight ring entries per wave (the DMA of a slot is issued LAT_D - 1 slots before its use, the
+// slot after the current one is already being read from the ring): 16 for grids of at most one
+// workgroup per CU (76-87 KB of LDS), 8 where several workgroups must share a CU (45-53 KB).
+template <int EPI, bool UPS, int LAT_D>
 __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
     constexpr int TS = MAP == MAP_PARITY ? 8 : 4;      // tile footprint in pixels
@@ -929,6 +933,9 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
         else wait_vmn<0>();
         __syncthreads();
         int buf = 0, tb = 0, rb = 0;
+        auto a_off = [&](int st) {
+            return UP ? abase_lo + ((st >> 1) * LWL + (st & 1)) * 16 : abase + ((st / 3) * PWL + (st % 3)) * 16;
+        };
 #pragma unroll 1
         for (int blk = b0; blk < b1; ++blk) {
             if (blk > b0) {
@@ -938,30 +945,47 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
                 buf ^= 1;
             }
             if (blk + 1 < b1) issue_patch(blk + 1, buf ^ 1, UP);
-            const float* pa = sP[buf];
+            if (active) {
+                const float* pa = sP[buf];
+                // operands of the block's first slot (its weights landed LAT_D - 2 DMAs ago at the latest)
+                if (tb + LAT_D - 2 < T) wait_vmn<LAT_D - 2>();
+                else wait_vmn<0>();
+                f32x4 w = lds_read16_opaque(wring + rb * 256 + lane * 4);
+                float fa[4];
 #pragma unroll
-            for (int st = 0; st < SPB; ++st) {
-                if (active) {
+                for (int kk = 0; kk < 4; ++kk) fa[kk] = pa[a_off(0) + 4 * kk];
+                lds_wait(w);
+#pragma unroll
+                for (int st = 0; st < SPB; ++st) {
                     const int t = tb + st;
                     int r = rb + st;
                     if (r >= LAT_D) r -= LAT_D;
+                    int rp = r - 1;                        // the entry consumed by the previous slot
+                    if (rp < 0) rp += LAT_D;
+                    int rn = r + 1;
+                    if (rn >= LAT_D) rn -= LAT_D;
                     if (t + LAT_D - 1 < T) {
-                        int rp = r - 1;                    // the entry consumed by the previous slot
-                        if (rp < 0) rp += LAT_D;
                         glds16(wsrc(t + LAT_D - 1), wring + rp * 256);
-                        wait_vmn<LAT_D - 1>();
+                        wait_vmn<LAT_D - 2>();             // slot t + 1 has landed
                     } else {
                         wait_vmn<0>();
                     }
-                    const f32x4 w = lds_read16_opaque(wring + r * 256 + lane * 4);
-                    int off;
-                    if (UP) off = abase_lo + ((st >> 1) * LWL + (st & 1)) * 16;
-                    else off = abase + ((st / 3) * PWL + (st % 3)) * 16;
-                    float fa[4];
+                    // next slot's operands are read while this slot's MFMAs run
+                    f32x4 wn = w;
+                    float fan[4] = {fa[0], fa[1], fa[2], fa[3]};
+                    if (st + 1 < SPB) {
+                        wn = lds_read16_opaque(wring + rn * 256 + lane * 4);
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) fa[kk] = pa[off + 4 * kk];
+                        for (int kk = 0; kk < 4; ++kk) fan[kk] = pa[a_off(st + 1) + 4 * kk];
+                    }
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kk], w[kk], acc, 0, 0, 0);
+                    if (st + 1 < SPB) {
+                        lds_wait(wn);
+                        w = wn;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) fa[kk] = fan[kk];
+                    }
                 }
             }
             tb += SPB;

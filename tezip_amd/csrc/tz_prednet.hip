@@ -302,9 +302,15 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         const int ltiles = ((a.W + ts - 1) / ts) * ((a.H + ts - 1) / ts) * (ts == 8 ? 4 : 1);
         const int blocks = a.ncb * ltiles * nbatch;
         ps.sub = TZP_CONVLAT;
-        if (epi == EPI_LSTM && ups) hipLaunchKernelGGL((k_convlat<EPI_LSTM, true>), dim3(blocks), dim3(256), 0, ctx->stream, a);
-        else if (epi == EPI_LSTM) hipLaunchKernelGGL((k_convlat<EPI_LSTM, false>), dim3(blocks), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_convlat<EPI_POOL_ERR, false>), dim3(blocks), dim3(256), 0, ctx->stream, a);
+#define TZ_LAT(e, u)                                                                                       \
+    do {                                                                                                   \
+        if (blocks <= 256) hipLaunchKernelGGL((k_convlat<e, u, 16>), dim3(blocks), dim3(256), 0, ctx->stream, a); \
+        else hipLaunchKernelGGL((k_convlat<e, u, 8>), dim3(blocks), dim3(256), 0, ctx->stream, a);         \
+    } while (0)
+        if (epi == EPI_LSTM && ups) TZ_LAT(EPI_LSTM, true);
+        else if (epi == EPI_LSTM) TZ_LAT(EPI_LSTM, false);
+        else TZ_LAT(EPI_POOL_ERR, false);
+#undef TZ_LAT
         TZ_HIP(ctx, hipGetLastError());
         return TZ_OK;
     }
