@@ -914,19 +914,19 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     // wait longer), and a patch, issued one block ahead of that block's SPB weight slots, has landed
     // at vmcnt(SPB).  One barrier per 16-channel block (the patch is shared by the 4 waves).
     int slot0 = 0;
+    static_assert((LAT_D & (LAT_D - 1)) == 0, "ring indices wrap by masking");
     auto run_phase = [&](auto upc, int b0, int b1) {
         constexpr bool UP = decltype(upc)::value;
         constexpr int SPB = UP ? 4 : 9;                   // slots this wave uses per block
         if (b0 >= b1) return;
         const int T = (b1 - b0) * SPB;
-        auto wsrc = [&](int t) {                          // step t of this phase -> its weights
-            const int slot = UP ? slot0 + (t >> 2) * 16 + (t & 3) * 4 + pc : slot0 + t;
-            return wlane + slot * wstride;
-        };
+        // weights of step t: same resolution slot0 + t; upsampled slot0 + 16 (t >> 2) + 4 (t & 3) + class = slot0 + pc + 4 t
+        const long long wstep = (UP ? 4 : 1) * wstride;
+        const float* wptr = wlane + (long long)(slot0 + (UP ? pc : 0)) * wstride;   // next slot to fetch
         __syncthreads();                                  // every wave is done with the previous phase's patches
         issue_patch(b0, 0, UP);
         if (active)
-            for (int j = 0; j < LAT_D - 1 && j < T; ++j) glds16(wsrc(j), wring + j * 256);
+            for (int j = 0; j < LAT_D - 1 && j < T; ++j, wptr += wstep) glds16(wptr, wring + j * 256);
         // the patch is older than those LAT_D - 1 weight slots (a wave without a column tile -- NT = 3 --
         // has issued nothing but its part of the patch)
         if (active && T >= LAT_D - 1) wait_vmn<LAT_D - 1>();
@@ -935,6 +935,56 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
         int buf = 0, tb = 0, rb = 0;
         auto a_off = [&](int st) {
             return UP ? abase_lo + ((st >> 1) * LWL + (st & 1)) * 16 : abase + ((st / 3) * PWL + (st % 3)) * 16;
+        };
+        // One block = SPB slots.  The four MFMAs of a slot form a dependent chain (40 cycles each); the
+        // DMA of the slot LAT_D - 1 ahead, the ring read and the patch reads of the NEXT slot are placed
+        // between them (sched barriers keep them there) so that nothing but the chain is on the wave's
+        // critical path.  STEADY: every slot of the block still has a slot to prefetch.
+        auto block = [&](auto steady) {
+            constexpr bool STEADY = decltype(steady)::value;
+            const float* pa = sP[buf];
+            if (STEADY || tb + LAT_D - 2 < T) wait_vmn<LAT_D - 2>();   // the block's first slot has landed
+            else wait_vmn<0>();
+            f32x4 w = lds_read16_opaque(wring + rb * 256 + lane * 4);
+            float fa[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fa[kk] = pa[a_off(0) + 4 * kk];
+            lds_wait(w);
+#pragma unroll
+            for (int st = 0; st < SPB; ++st) {
+                const int r = (rb + st) & (LAT_D - 1);
+                const int rp = (r + LAT_D - 1) & (LAT_D - 1);          // the entry consumed by the previous slot
+                const int rn = (r + 1) & (LAT_D - 1);
+                const bool more = st + 1 < SPB;
+                f32x4 wn = w;
+                float fan[4] = {fa[0], fa[1], fa[2], fa[3]};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], w[0], acc, 0, 0, 0);
+                if (STEADY || tb + st + LAT_D - 1 < T) {
+                    glds16(wptr, wring + rp * 256);
+                    wptr += wstep;
+                    wait_vmn<LAT_D - 2>();                             // slot t + 1 has landed
+                } else {
+                    wait_vmn<0>();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], w[1], acc, 0, 0, 0);
+                if (more) wn = lds_read16_opaque(wring + rn * 256 + lane * 4);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], w[2], acc, 0, 0, 0);
+                if (more) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) fan[kk] = pa[a_off(st + 1) + 4 * kk];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], w[3], acc, 0, 0, 0);
+                if (more) {
+                    lds_wait(wn);
+                    w = wn;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) fa[kk] = fan[kk];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
 #pragma unroll 1
         for (int blk = b0; blk < b1; ++blk) {
@@ -946,51 +996,11 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
             }
             if (blk + 1 < b1) issue_patch(blk + 1, buf ^ 1, UP);
             if (active) {
-                const float* pa = sP[buf];
-                // operands of the block's first slot (its weights landed LAT_D - 2 DMAs ago at the latest)
-                if (tb + LAT_D - 2 < T) wait_vmn<LAT_D - 2>();
-                else wait_vmn<0>();
-                f32x4 w = lds_read16_opaque(wring + rb * 256 + lane * 4);
-                float fa[4];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) fa[kk] = pa[a_off(0) + 4 * kk];
-                lds_wait(w);
-#pragma unroll
-                for (int st = 0; st < SPB; ++st) {
-                    const int t = tb + st;
-                    int r = rb + st;
-                    if (r >= LAT_D) r -= LAT_D;
-                    int rp = r - 1;                        // the entry consumed by the previous slot
-                    if (rp < 0) rp += LAT_D;
-                    int rn = r + 1;
-                    if (rn >= LAT_D) rn -= LAT_D;
-                    if (t + LAT_D - 1 < T) {
-                        glds16(wsrc(t + LAT_D - 1), wring + rp * 256);
-                        wait_vmn<LAT_D - 2>();             // slot t + 1 has landed
-                    } else {
-                        wait_vmn<0>();
-                    }
-                    // next slot's operands are read while this slot's MFMAs run
-                    f32x4 wn = w;
-                    float fan[4] = {fa[0], fa[1], fa[2], fa[3]};
-                    if (st + 1 < SPB) {
-                        wn = lds_read16_opaque(wring + rn * 256 + lane * 4);
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) fan[kk] = pa[a_off(st + 1) + 4 * kk];
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kk], w[kk], acc, 0, 0, 0);
-                    if (st + 1 < SPB) {
-                        lds_wait(wn);
-                        w = wn;
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) fa[kk] = fan[kk];
-                    }
-                }
+                if (tb + SPB - 1 + LAT_D - 1 < T) block(std::true_type{});
+                else block(std::false_type{});
             }
             tb += SPB;
-            rb += SPB;
-            if (rb >= LAT_D) rb -= LAT_D;
+            rb = (rb + SPB) & (LAT_D - 1);
         }
         slot0 += (b1 - b0) * (UP ? 16 : 9);
     };
