@@ -14,7 +14,7 @@ SOURCES = ["tz_api.hip", "tz_codec.hip", "tz_prednet.hip"]
 HEADERS = ["tz_internal.h", "tz_math.hip.h", "tz_conv_kernels.hip.h", os.path.join("..", "..", "include", "tezip_hip.h")]
 LIB = os.path.join(CSRC, "libtezip_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+FLAGS = (["-D" + d for d in os.environ.get("TEZIP_DEFINES", "").split()] if os.environ.get("TEZIP_DEFINES") else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 

@@ -775,15 +775,20 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
 //   block ahead through registers, one barrier per 16-channel block.
 // Per slot a wave issues 4 dependent MFMAs (the chain), i.e. the K loop runs at the latency of the
 // matrix pipe: 3456/4 k-steps x ~36 cycles = 13 us for the top level instead of 234.
+#ifndef TZ_LAT_VMSCALE
+#define TZ_LAT_VMSCALE 1   // vmcnt events per global_load_lds_dwordx4 (1: verified by experiment)
+#endif
 template <int N>
 __device__ __forceinline__ void wait_vmn() {
-    static_assert(N == 0 || N == 4 || N == 6 || N == 7 || N == 9 || N == 14 || N == 15, "immediate of s_waitcnt");
+    static_assert(N == 0 || N == 4 || N == 6 || N == 7 || N == 9 || N == 14 || N == 15 || N == 24 || N == 56, "immediate of s_waitcnt");
     if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     else if (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (N == 56) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
 }
 
@@ -822,11 +827,18 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     constexpr int TS = MAP == MAP_PARITY ? 8 : 4;      // tile footprint in pixels
     constexpr int PWL = TS + 2, PPL = PWL * PWL;       // same-resolution halo patch
     constexpr int LWL = 6, LPL = LWL * LWL;            // half-resolution patch of an upsampled source
-    constexpr int NPI = (PPL * 4 + 255) / 256;         // patch DMA instructions per wave (items = pixel x channel quad)
-    // LDS: per-wave weight rings (LAT_D x 1 KB each), two patch buffers (16 floats per pixel, as in
-    // memory), the gate exchange of the LSTM epilogue
+    // patch image: QUAD-PLANAR like k_conv16's -- the 16-byte item (pixel slot p, channel quad q) sits at
+    // item index q * NP + p, so that the 16 rows x 4 elements of an A fragment spread over the banks
+    // (the memory layout, 64 bytes per pixel, puts them on 8 banks: 8-way conflicts, 256 LDS cycles per
+    // slot and workgroup, which is what the first version of this kernel ran at); a parity tile stores
+    // its columns evens first so that the pixels of one class are neighbours
+    constexpr int NPS = MAP == MAP_PARITY ? 112 : 48;  // slots per quad plane, same resolution (>= PPL, multiple of 16)
+    constexpr int NPU = 48;                            // ... half resolution
+    constexpr int PCS = NPS * 4 / 64, PCU = NPU * 4 / 64;   // 1 KB pieces (= DMA wave-instructions) per patch
+    constexpr int NPI = (PCS + 3) / 4;                 // patch DMA instructions per wave
+    // LDS: per-wave weight rings (LAT_D x 1 KB each), two patch buffers, the gate exchange of the LSTM epilogue
     __shared__ __attribute__((aligned(16))) float sW[4 * LAT_D * 256];
-    __shared__ __attribute__((aligned(16))) float sP[2][NPI * 256 * 4];
+    __shared__ __attribute__((aligned(16))) float sP[2][PCS * 256];
     __shared__ float sE[4 * 16 * 17];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -848,8 +860,7 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     const bool up0 = UPS && a.src[0].up != 0;
     const int nbe = up0 ? 0 : (UPS && a.nsrc > 1 && a.src[1].up ? nb0 : nblk);  // same-resolution blocks
 
-    // ---- LDS-DMA issue (item i = pixel i>>2, channel quad i&3 -> 16 bytes at float offset 4i: the
-    // patch keeps the memory layout, 16 floats per pixel)
+    // ---- LDS-DMA issue: item i = piece * 64 + lane = quad plane i / NP, slot i % NP
     auto issue_patch = [&](int blk, int buf, bool up) {
         const bool s1 = blk >= nb0;
         const ConvSrc& s = s1 ? a.src[1] : a.src[0];
@@ -857,22 +868,25 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
         const float* base = s.p + (long long)n * s.nstride;
 #pragma unroll
         for (int k = 0; k < NPI; ++k) {
-            const int i = (k * 4 + wv) * 64 + lane, p = i >> 2, q = i & 3;
+            const int piece = k * 4 + wv;
             const float* src = a.zero;
             if (up) {
-                if ((k * 4 + wv) * 64 >= LPL * 4) continue;   // wave-uniform: nothing of this piece is needed
-                const int Y = p / LWL, X = p - Y * LWL;
+                if (piece >= PCU) continue;               // wave-uniform
+                const int i = piece * 64 + lane, q = i / NPU, slot = i - q * NPU;
+                const int Y = slot / LWL, X = slot - Y * LWL;
                 const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
-                if (p < LPL && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1))
+                if (slot < LPL && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1))
                     src = base + ((long long)ly * (a.W >> 1) + lx) * s.pstride + c0 + 4 * q;
             } else {
-                if ((k * 4 + wv) * 64 >= PPL * 4) continue;
-                const int Y = p / PWL, X = p - Y * PWL;
+                if (piece >= PCS) continue;
+                const int i = piece * 64 + lane, q = i / NPS, slot = i - q * NPS;
+                const int Y = slot / PWL, xs = slot - Y * PWL;
+                const int X = MAP == MAP_PARITY ? (xs < PWL / 2 ? 2 * xs : 2 * (xs - PWL / 2) + 1) : xs;
                 const int yy = ty0 - 1 + Y, xx = tx0 - 1 + X;
-                if (p < PPL && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+                if (slot < PPL && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
                     src = base + ((long long)yy * a.W + xx) * s.pstride + c0 + 4 * q;
             }
-            glds16(src, sP[buf] + (k * 4 + wv) * 256);
+            glds16(src, sP[buf] + piece * 256);
         }
     };
 
@@ -899,8 +913,9 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     {
         int py, px;
         lat_row_to_pixel<MAP>(lane & 15, pc, py, px);
-        abase = (py * PWL + px) * 16 + g;
-        abase_lo = (((py >> 1) + (py & 1)) * LWL + (px >> 1) + (px & 1)) * 16 + g;
+        // tap (0,0): patch row py, column px (a parity tile: column slot (px >> 1) + 5 (px & 1))
+        abase = (py * PWL + (MAP == MAP_PARITY ? (px >> 1) + (PWL / 2) * (px & 1) : px)) * 4 + g;
+        abase_lo = (((py >> 1) + (py & 1)) * LWL + (px >> 1) + (px & 1)) * 4 + g;
     }
     const long long wstride = (long long)a.ncb * 1024;                                 // floats between slots of Wlat
     const float* wlane = a.Wlat + ((long long)cb * 4 + (active ? wv : 0)) * 256 + lane * 4;
@@ -933,9 +948,15 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
         else wait_vmn<0>();
         __syncthreads();
         int buf = 0, tb = 0, rb = 0;
+        // slot offset of a tap.  Parity tile: its columns are stored evens first, so one step in x is
+        // +5 from an even column and -4 from an odd one, two steps are +1 (the class is uniform)
         auto a_off = [&](int st) {
-            return UP ? abase_lo + ((st >> 1) * LWL + (st & 1)) * 16 : abase + ((st / 3) * PWL + (st % 3)) * 16;
+            if (UP) return abase_lo + ((st >> 1) * LWL + (st & 1)) * 4;
+            const int dy = st / 3, dx = st % 3;
+            const int xo = MAP == MAP_PARITY ? (dx == 1 ? ((pc & 1) ? 1 - PWL / 2 : PWL / 2) : (dx >> 1)) : dx;
+            return abase + (dy * PWL + xo) * 4;
         };
+        constexpr int KOFF = 4 * (UP ? NPU : NPS);         // floats between the quad planes
         // One block = SPB slots.  The four MFMAs of a slot form a dependent chain (40 cycles each); the
         // DMA of the slot LAT_D - 1 ahead, the ring read and the patch reads of the NEXT slot are placed
         // between them (sched barriers keep them there) so that nothing but the chain is on the wave's
@@ -943,12 +964,12 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
         auto block = [&](auto steady) {
             constexpr bool STEADY = decltype(steady)::value;
             const float* pa = sP[buf];
-            if (STEADY || tb + LAT_D - 2 < T) wait_vmn<LAT_D - 2>();   // the block's first slot has landed
+            if (STEADY || tb + LAT_D - 2 < T) wait_vmn<(LAT_D - 2) * TZ_LAT_VMSCALE>();   // the block's first slot has landed
             else wait_vmn<0>();
             f32x4 w = lds_read16_opaque(wring + rb * 256 + lane * 4);
             float fa[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fa[kk] = pa[a_off(0) + 4 * kk];
+            for (int kk = 0; kk < 4; ++kk) fa[kk] = pa[a_off(0) + KOFF * kk];
             lds_wait(w);
 #pragma unroll
             for (int st = 0; st < SPB; ++st) {
@@ -962,7 +983,7 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
                 if (STEADY || tb + st + LAT_D - 1 < T) {
                     glds16(wptr, wring + rp * 256);
                     wptr += wstep;
-                    wait_vmn<LAT_D - 2>();                             // slot t + 1 has landed
+                    wait_vmn<(LAT_D - 2) * TZ_LAT_VMSCALE>();          // slot t + 1 has landed
                 } else {
                     wait_vmn<0>();
                 }
@@ -973,7 +994,7 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], w[2], acc, 0, 0, 0);
                 if (more) {
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) fan[kk] = pa[a_off(st + 1) + 4 * kk];
+                    for (int kk = 0; kk < 4; ++kk) fan[kk] = pa[a_off(st + 1) + KOFF * kk];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], w[3], acc, 0, 0, 0);
