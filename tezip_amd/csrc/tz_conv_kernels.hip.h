@@ -775,20 +775,17 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
 //   block ahead through registers, one barrier per 16-channel block.
 // Per slot a wave issues 4 dependent MFMAs (the chain), i.e. the K loop runs at the latency of the
 // matrix pipe: 3456/4 k-steps x ~36 cycles = 13 us for the top level instead of 234.
-#ifndef TZ_LAT_VMSCALE
-#define TZ_LAT_VMSCALE 1   // vmcnt events per global_load_lds_dwordx4 (1: verified by experiment)
-#endif
 template <int N>
 __device__ __forceinline__ void wait_vmn() {
-    static_assert(N == 0 || N == 4 || N == 6 || N == 7 || N == 9 || N == 14 || N == 15 || N == 24 || N == 56, "immediate of s_waitcnt");
+    static_assert(N == 0 || N == 4 || N == 5 || N == 6 || N == 7 || N == 9 || N == 13 || N == 14 || N == 15, "immediate of s_waitcnt");
     if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     else if (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else if (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (N == 56) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+    else if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
 }
 
@@ -964,7 +961,7 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
         auto block = [&](auto steady) {
             constexpr bool STEADY = decltype(steady)::value;
             const float* pa = sP[buf];
-            if (STEADY || tb + LAT_D - 2 < T) wait_vmn<(LAT_D - 2) * TZ_LAT_VMSCALE>();   // the block's first slot has landed
+            if (STEADY || tb + LAT_D - 2 < T) wait_vmn<LAT_D - 2>();   // the block's first slot has landed
             else wait_vmn<0>();
             f32x4 w = lds_read16_opaque(wring + rb * 256 + lane * 4);
             float fa[4];
@@ -980,22 +977,24 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
                 f32x4 wn = w;
                 float fan[4] = {fa[0], fa[1], fa[2], fa[3]};
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], w[0], acc, 0, 0, 0);
-                if (STEADY || tb + st + LAT_D - 1 < T) {
-                    glds16(wptr, wring + rp * 256);
-                    wptr += wstep;
-                    wait_vmn<(LAT_D - 2) * TZ_LAT_VMSCALE>();          // slot t + 1 has landed
-                } else {
-                    wait_vmn<0>();
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], w[1], acc, 0, 0, 0);
-                if (more) wn = lds_read16_opaque(wring + rn * 256 + lane * 4);
-                __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], w[2], acc, 0, 0, 0);
+                // the next slot's operands first: their LDS latency hides behind three MFMAs.  Slot t + 1
+                // has landed when at most the LAT_D - 3 DMAs issued after it are outstanding (this
+                // slot's own DMA is issued below)
                 if (more) {
+                    if (STEADY || tb + st + LAT_D - 2 < T) wait_vmn<LAT_D - 3>();
+                    else wait_vmn<0>();
+                    wn = lds_read16_opaque(wring + rn * 256 + lane * 4);
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) fan[kk] = pa[a_off(st + 1) + KOFF * kk];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], w[1], acc, 0, 0, 0);
+                if (STEADY || tb + st + LAT_D - 1 < T) {
+                    glds16(wptr, wring + rp * 256);
+                    wptr += wstep;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], w[2], acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], w[3], acc, 0, 0, 0);
                 if (more) {
