@@ -48,8 +48,8 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
     {
         const char* e = getenv("TEZIP_CONV16");  // diagnostic default of tz_set_conv_impl
         if (e && e[0] == '0') ctx->conv_impl = 0;
-        e = getenv("TEZIP_LAT_MAX_WG");          // 0 = never use k_convlat
-        if (e) ctx->lat_max_wg = atoi(e);
+        e = getenv("TEZIP_LAT");                 // k_convlat: 0 never, 1 cost model (default), 2 wherever eligible
+        if (e) ctx->lat_mode = atoi(e);
     }
     ctx->device = device;
     if (hip_stream) {

@@ -51,7 +51,7 @@ struct tz_ctx {
     // model + rollout state
     tz_model* model = nullptr;
     int conv_impl = 1;                // tz_set_conv_impl: 1 = LDS-DMA kernels where they apply
-    int lat_max_wg = 150;             // k_conv16 grids up to this many workgroups go to k_convlat (TEZIP_LAT_MAX_WG)
+    int lat_mode = 1;                 // k_convlat: 0 never, 1 where the cost model says so, 2 wherever eligible (TEZIP_LAT)
     // rollout-resident data
     int nt = 0, H = 0, W = 0, Hp = 0, Wp = 0, warm_up = 0;
     uint8_t* d_frames = nullptr;      // nt*H*W*3 (encoder: originals; decoder: key stack)

@@ -295,9 +295,23 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         TZ_CASE16B(1, EPI_POOL_ERR, false) TZ_CASE16B(3, EPI_POOL_ERR, false) TZ_CASE16B(4, EPI_POOL_ERR, false)
 #undef TZ_CASE16B
     }
-    // grids that cannot fill the chip: one accumulator tile per wave (k_convlat), see the kernel's header
-    if (a.Wlat && a.nsrc > 0 && fullk && ctx->conv_impl && (NT == 3 || NT == 4) && (epi == EPI_LSTM || epi == EPI_POOL_ERR) &&
-        !(epi == EPI_LSTM && NT != 4) && a.ncb * a.tiles_x * a.tiles_y * nbatch <= ctx->lat_max_wg) {
+    // grids that cannot fill the chip: one accumulator tile per wave (k_convlat), see the kernel's header.
+    // Which kernel is faster is decided by a small cost model fitted to per-launch measurements on the
+    // MI355X (profiles/r02/small_grid.txt): k_conv16 costs about 1.08 us per 16-channel x tap slot for
+    // every workgroup a CU has to run (its K loop is a serial chain of 32-MFMA steps); k_convlat about
+    // 0.15-0.22 us per slot and round, with 256 (ring of 16) or 768 (ring of 8) workgroups per round.
+    if (a.Wlat && a.nsrc > 0 && fullk && ctx->conv_impl && ctx->lat_mode && (NT == 3 || NT == 4) &&
+        (epi == EPI_POOL_ERR || (epi == EPI_LSTM && NT == 4))) {
+        const int ts_ = (epi != EPI_POOL_ERR && ups) ? 8 : 4;
+        const long long wg16 = (long long)a.ncb * a.tiles_x * a.tiles_y * nbatch;
+        const long long wglat = (long long)a.ncb * ((a.W + ts_ - 1) / ts_) * ((a.H + ts_ - 1) / ts_) * (ts_ == 8 ? 4 : 1) * nbatch;
+        int slots = 0;
+        for (int s = 0; s < a.nsrc; ++s) slots += a.src[s].cpt * (a.src[s].up ? 4 : 9);
+        const double t16 = slots * 1.08 * (double)((wg16 + 255) / 256);
+        const double per = slots * (wglat <= 256 ? 0.15 : (ts_ == 8 ? 0.22 : 0.18)) + 2.5;
+        const double tlat = per * (double)(wglat <= 256 ? 1 : (wglat + 767) / 768);
+        const bool use_lat = wg16 <= 768 && (ctx->lat_mode == 2 || tlat < 0.9 * t16);
+        if (!use_lat) goto no_lat;
         const int ts = (epi != EPI_POOL_ERR && ups) ? 8 : 4;
         const int ltiles = ((a.W + ts - 1) / ts) * ((a.H + ts - 1) / ts) * (ts == 8 ? 4 : 1);
         const int blocks = a.ncb * ltiles * nbatch;
@@ -314,6 +328,7 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         TZ_HIP(ctx, hipGetLastError());
         return TZ_OK;
     }
+no_lat:
     if (a.Wimg && a.nsrc > 0 && fullk && ctx->conv_impl) {
 #define TZ_CASE16(nt, e, u)                          \
     if (NT == nt && epi == e && ups == u) {          \
