@@ -299,7 +299,8 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
     // Which kernel is faster is decided by a small cost model fitted to per-launch measurements on the
     // MI355X (profiles/r02/small_grid.txt): k_conv16 costs about 1.08 us per 16-channel x tap slot for
     // every workgroup a CU has to run (its K loop is a serial chain of 32-MFMA steps); k_convlat about
-    // 0.15-0.22 us per slot and round, with 256 (ring of 16) or 768 (ring of 8) workgroups per round.
+    // 0.15 us per slot when every workgroup has a CU to itself (<= 256, ring of 16), 0.25-0.28 us per
+    // slot and round of 768 workgroups otherwise (ring of 8, three workgroups share a CU's matrix pipe).
     if (a.Wlat && a.nsrc > 0 && fullk && ctx->conv_impl && ctx->lat_mode && (NT == 3 || NT == 4) &&
         (epi == EPI_POOL_ERR || (epi == EPI_LSTM && NT == 4))) {
         const int ts_ = (epi != EPI_POOL_ERR && ups) ? 8 : 4;
@@ -308,7 +309,7 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         int slots = 0;
         for (int s = 0; s < a.nsrc; ++s) slots += a.src[s].cpt * (a.src[s].up ? 4 : 9);
         const double t16 = slots * 1.08 * (double)((wg16 + 255) / 256);
-        const double per = slots * (wglat <= 256 ? 0.15 : (ts_ == 8 ? 0.22 : 0.18)) + 2.5;
+        const double per = slots * (wglat <= 256 ? 0.15 : (ts_ == 8 ? 0.28 : 0.25)) + 2.5;
         const double tlat = per * (double)(wglat <= 256 ? 1 : (wglat + 767) / 768);
         const bool use_lat = wg16 <= 768 && (ctx->lat_mode == 2 || tlat < 0.9 * t16);
         if (!use_lat) goto no_lat;
