@@ -85,7 +85,10 @@ int tz_predict_tap(tz_ctx* ctx, int kind, int level, float* out);
 /* Diagnostic: which convolution kernels the predictor launches.  1 (default; env TEZIP_CONV16=0
  * starts a context at 0) = the LDS-DMA kernels k_conv16 / k_conv16b / k_conv_small wherever a
  * convolution qualifies, 0 = the general register-staged kernel k_conv3x3 everywhere.  Both walk
- * the same fmaf chains: results are bit-identical (tests/test_gpu_fullsize.py). */
+ * the same fmaf chains: results are bit-identical (tests/test_gpu_fullsize.py).
+ * Bits 1-2 select the small-grid kernel k_convlat (one accumulator tile per wave): 0 = where a cost
+ * model expects it to be faster (default; env TEZIP_LAT=0|1|2 sets a context's start value),
+ * 1 (value 2) = never, 2 (value 4) = wherever a convolution is eligible. */
 int tz_set_conv_impl(tz_ctx* ctx, int lds_dma);
 
 /* ---- rollout (compress.py:183-268 encoder; decompress.py:115-186 decoder) -----------------

@@ -186,3 +186,22 @@ def test_host_buffers_pinned_pageable_and_device_give_the_same_bytes(ctx):
         for a, b in zip(res["pageable"], res[kind]):
             assert np.array_equal(a, b), kind
     assert int(np.abs(res["pinned"][3].astype(np.int16) - frames.astype(np.int16)).max()) <= 3
+
+
+@pytest.mark.parametrize("h,w,batch,nt,seed", [(128, 160, 4, 13, 21), (512, 512, 1, 3, 22), (61, 90, 2, 9, 23)])
+def test_small_grid_kernel_agrees_with_k_conv16(ctx, h, w, batch, nt, seed):
+    """k_convlat (one accumulator tile per wave, weights streamed per wave, for launches that cannot fill
+    the chip) walks the same fmaf chains as k_conv16: forced on wherever it is eligible -- every level
+    >= 1, also at 512x512 where it runs thousands of workgroups in several rounds with the 8-entry
+    ring -- the whole recursive rollout must equal the k_conv16 result bit for bit, image borders and
+    sizes that are no multiple of its 4x4 / 8x8 tiles included."""
+    frames = synth.turbulence(nt, h, w, seed=seed)
+    ctx.prepare((h + 7) // 8 * 8, (w + 7) // 8 * 8, max_batch=batch)
+    preds = {}
+    for lat in ("never", "always", None):
+        ctx.set_conv_impl(1, lat=lat)
+        ctx.rollout(frames, 0, (nt + batch - 1) // batch)
+        preds[lat] = ctx.get_predictions()
+    ctx.set_conv_impl(1)
+    assert np.array_equal(preds["never"], preds["always"]) and np.array_equal(preds["never"], preds[None])
+    assert preds["never"].std() > 0

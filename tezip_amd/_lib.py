@@ -223,9 +223,11 @@ class Context:
         self._ck(self.lib.tz_predict_tap(self.h, kind, level, out.ctypes.data))
         return out
 
-    def set_conv_impl(self, lds_dma):
-        """Diagnostic: 1 = LDS-DMA convolution kernels where they apply (default), 0 = the general kernel."""
-        self._ck(self.lib.tz_set_conv_impl(self.h, int(bool(lds_dma))))
+    def set_conv_impl(self, lds_dma, lat=None):
+        """Diagnostic: 1 = LDS-DMA convolution kernels where they apply (default), 0 = the general kernel.
+        lat: None = k_convlat where the cost model picks it (default), "never", "always"."""
+        code = {None: 0, "never": 1, "always": 2}[lat]
+        self._ck(self.lib.tz_set_conv_impl(self.h, int(bool(lds_dma)) | (code << 1)))
 
     # ---- rollout + encode / decode
     @staticmethod

@@ -264,7 +264,9 @@ static void launch_conv16_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
 
 extern "C" int tz_set_conv_impl(tz_ctx* ctx, int lds_dma) {
     if (!ctx) return TZ_ERR_INVALID;
-    ctx->conv_impl = lds_dma ? 1 : 0;
+    ctx->conv_impl = (lds_dma & 1) ? 1 : 0;
+    const int lat = lds_dma >> 1;  // 0: cost model (default), 1: never k_convlat, 2: wherever eligible
+    ctx->lat_mode = lat == 1 ? 0 : (lat == 2 ? 2 : 1);
     return TZ_OK;
 }
 
