@@ -817,30 +817,36 @@ __device__ __forceinline__ void lat_row_to_pixel(int r, int pc, int& py, int& px
 
 // LAT_D = weight ring entries per wave (the DMA of a slot is issued LAT_D - 1 slots before its use, the
 // slot after the current one is already being read from the ring): 16 for grids of at most one
-// workgroup per CU (76-87 KB of LDS), 8 where several workgroups must share a CU (45-53 KB).
-template <int EPI, bool UPS, int LAT_D>
+// workgroup per CU, 8 where several workgroups must share a CU.
+// MTL = accumulator tiles per wave: 1 = 16 pixels per workgroup (the latency-bound case: as many SIMDs
+// as possible), 2 = 32 pixels (two tiles side by side, two independent MFMA chains interleaved: for
+// grids of several rounds, where the matrix pipe rather than the chain latency is the limit and
+// half as many workgroups stream the weights).
+template <int EPI, bool UPS, int LAT_D, int MTL>
 __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
-    constexpr int TS = MAP == MAP_PARITY ? 8 : 4;      // tile footprint in pixels
-    constexpr int PWL = TS + 2, PPL = PWL * PWL;       // same-resolution halo patch
-    constexpr int LWL = 6, LPL = LWL * LWL;            // half-resolution patch of an upsampled source
+    constexpr int TS = MAP == MAP_PARITY ? 8 : 4;      // footprint of one accumulator tile in pixels
+    constexpr int TSX = TS * MTL;                      // footprint of the workgroup in x
+    constexpr int PWL = TSX + 2, PHL = TS + 2, PPL = PWL * PHL;   // same-resolution halo patch
+    constexpr int LWL = TSX / 2 + 2, LPL = 6 * LWL;    // half-resolution patch of an upsampled source (parity tiles)
     // patch image: QUAD-PLANAR like k_conv16's -- the 16-byte item (pixel slot p, channel quad q) sits at
     // item index q * NP + p, so that the 16 rows x 4 elements of an A fragment spread over the banks
     // (the memory layout, 64 bytes per pixel, puts them on 8 banks: 8-way conflicts, 256 LDS cycles per
     // slot and workgroup, which is what the first version of this kernel ran at); a parity tile stores
     // its columns evens first so that the pixels of one class are neighbours
-    constexpr int NPS = MAP == MAP_PARITY ? 112 : 48;  // slots per quad plane, same resolution (>= PPL, multiple of 16)
-    constexpr int NPU = 48;                            // ... half resolution
+    constexpr int NPS = (PPL + 15) / 16 * 16;          // slots per quad plane, same resolution
+    constexpr int NPU = (LPL + 15) / 16 * 16;          // ... half resolution
     constexpr int PCS = NPS * 4 / 64, PCU = NPU * 4 / 64;   // 1 KB pieces (= DMA wave-instructions) per patch
     constexpr int NPI = (PCS + 3) / 4;                 // patch DMA instructions per wave
+    static_assert(PCU <= PCS, "the half-resolution patch fits the same buffers");
     // LDS: per-wave weight rings (LAT_D x 1 KB each), two patch buffers, the gate exchange of the LSTM epilogue
     __shared__ __attribute__((aligned(16))) float sW[4 * LAT_D * 256];
     __shared__ __attribute__((aligned(16))) float sP[2][PCS * 256];
-    __shared__ float sE[4 * 16 * 17];
+    __shared__ float sE[EPI == EPI_LSTM ? 4 * 16 * MTL * 17 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NTW = a.ncols / (16 * a.ncb);            // column tiles per block: 3 or 4
-    const int ltx = (a.W + TS - 1) / TS, lty = (a.H + TS - 1) / TS;
+    const int ltx = (a.W + TSX - 1) / TSX, lty = (a.H + TS - 1) / TS;
     const int ntiles = ltx * lty * (MAP == MAP_PARITY ? 4 : 1);
     int bid = blockIdx.x;
     const int cb = bid % a.ncb;
@@ -848,7 +854,7 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     const int tile = bid % ntiles, n = bid / ntiles;
     const int pc = MAP == MAP_PARITY ? (tile & 3) : 0;
     const int reg = MAP == MAP_PARITY ? (tile >> 2) : tile;
-    const int ty0 = (reg / ltx) * TS, tx0 = (reg % ltx) * TS;
+    const int ty0 = (reg / ltx) * TS, tx0 = (reg % ltx) * TSX;
     const int g = lane >> 4;
     const bool active = wv < NTW;
 
@@ -887,44 +893,51 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
         }
     };
 
-    // ---- accumulator: rows 4g..4g+3 of the tile, column lane&15 of this wave's column tile
+    // ---- accumulators: rows 4g..4g+3 of tile m (tile m sits m * TS pixels to the right), column lane&15
+    // of this wave's column tile
     const int col = cb * (NTW * 16) + wv * 16 + (lane & 15);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (active) {
-        if (a.init) {
+    f32x4 acc[MTL];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int py, px;
-                lat_row_to_pixel<MAP>(4 * g + r, pc, py, px);
-                const int y = ty0 + py, x = tx0 + px;
-                const long long pix = (y < a.H && x < a.W) ? (long long)y * a.W + x : 0;
-                acc[r] = a.init[pix * a.ncols + col];
+    for (int m = 0; m < MTL; ++m) {
+        acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            if (a.init) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int py, px;
+                    lat_row_to_pixel<MAP>(4 * g + r, pc, py, px);
+                    const int y = ty0 + py, x = tx0 + m * TS + px;
+                    const long long pix = (y < a.H && x < a.W) ? (long long)y * a.W + x : 0;
+                    acc[m][r] = a.init[pix * a.ncols + col];
+                }
+            } else {
+                const float b = a.bias[col];
+                acc[m] = (f32x4){b, b, b, b};
             }
-        } else {
-            const float b = a.bias[col];
-            acc = (f32x4){b, b, b, b};
         }
     }
     // LDS float offsets of this lane's A row (GEMM row lane&15, element g of a quad) for tap (0,0)
-    int abase, abase_lo;
-    {
+    int abase[MTL], abase_lo[MTL];
+#pragma unroll
+    for (int m = 0; m < MTL; ++m) {
         int py, px;
         lat_row_to_pixel<MAP>(lane & 15, pc, py, px);
-        // tap (0,0): patch row py, column px (a parity tile: column slot (px >> 1) + 5 (px & 1))
-        abase = (py * PWL + (MAP == MAP_PARITY ? (px >> 1) + (PWL / 2) * (px & 1) : px)) * 4 + g;
-        abase_lo = (((py >> 1) + (py & 1)) * LWL + (px >> 1) + (px & 1)) * 4 + g;
+        px += m * TS;
+        // tap (0,0): patch row py, column px (a parity tile: column slot (px >> 1) + (PWL / 2) (px & 1))
+        abase[m] = (py * PWL + (MAP == MAP_PARITY ? (px >> 1) + (PWL / 2) * (px & 1) : px)) * 4 + g;
+        abase_lo[m] = (((py >> 1) + (py & 1)) * LWL + (px >> 1) + (px & 1)) * 4 + g;
     }
     const long long wstride = (long long)a.ncb * 1024;                                 // floats between slots of Wlat
     const float* wlane = a.Wlat + ((long long)cb * 4 + (active ? wv : 0)) * 256 + lane * 4;
     float* wring = sW + wv * (LAT_D * 256);
 
     // The K loop: per slot (16 channels x one tap) the wave reads its four B k-steps (one
-    // ds_read_b128 of its private ring entry) and four A values (patch), issues the DMA of the slot
-    // LAT_D - 1 ahead into the entry it consumed last, and runs 4 dependent MFMAs.  All memory
-    // traffic is LDS-DMA, so the waits are explicit: DMAs of a wave complete in order, hence
-    // vmcnt(LAT_D - 1) = "the slot I am about to read has landed" (younger patch DMAs only make the
-    // wait longer), and a patch, issued one block ahead of that block's SPB weight slots, has landed
-    // at vmcnt(SPB).  One barrier per 16-channel block (the patch is shared by the 4 waves).
+    // ds_read_b128 of its private ring entry) and four A values per tile (patch), issues the DMA of the
+    // slot LAT_D - 1 ahead into the entry it consumed last, and runs 4 dependent MFMAs per tile.  All
+    // memory traffic is LDS-DMA, so the waits are explicit: DMAs of a wave complete in order, hence
+    // vmcnt(N) with N = the number of DMAs known to be younger than the one needed (younger patch DMAs
+    // only make the wait longer); a patch, issued one block ahead of that block's SPB weight slots, has
+    // landed at vmcnt(SPB).  One barrier per 16-channel block (the patch is shared by the 4 waves).
     int slot0 = 0;
     static_assert((LAT_D & (LAT_D - 1)) == 0, "ring indices wrap by masking");
     auto run_phase = [&](auto upc, int b0, int b1) {
@@ -946,27 +959,29 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
         __syncthreads();
         int buf = 0, tb = 0, rb = 0;
         // slot offset of a tap.  Parity tile: its columns are stored evens first, so one step in x is
-        // +5 from an even column and -4 from an odd one, two steps are +1 (the class is uniform)
-        auto a_off = [&](int st) {
-            if (UP) return abase_lo + ((st >> 1) * LWL + (st & 1)) * 4;
+        // +PWL/2 from an even column and 1 - PWL/2 from an odd one, two steps are +1 (the class is uniform)
+        auto t_off = [&](int st) {
+            if (UP) return ((st >> 1) * LWL + (st & 1)) * 4;
             const int dy = st / 3, dx = st % 3;
             const int xo = MAP == MAP_PARITY ? (dx == 1 ? ((pc & 1) ? 1 - PWL / 2 : PWL / 2) : (dx >> 1)) : dx;
-            return abase + (dy * PWL + xo) * 4;
+            return (dy * PWL + xo) * 4;
         };
         constexpr int KOFF = 4 * (UP ? NPU : NPS);         // floats between the quad planes
-        // One block = SPB slots.  The four MFMAs of a slot form a dependent chain (40 cycles each); the
-        // DMA of the slot LAT_D - 1 ahead, the ring read and the patch reads of the NEXT slot are placed
-        // between them (sched barriers keep them there) so that nothing but the chain is on the wave's
-        // critical path.  STEADY: every slot of the block still has a slot to prefetch.
+        // One block = SPB slots.  The MFMAs of a slot form one dependent chain per tile (40 cycles per
+        // link); the ring read and the patch reads of the NEXT slot and the DMA of the slot LAT_D - 1 ahead
+        // are placed between them (sched barriers keep them there) so that nothing but the chain is on
+        // the wave's critical path.  STEADY: every slot of the block still has a slot to prefetch.
         auto block = [&](auto steady) {
             constexpr bool STEADY = decltype(steady)::value;
             const float* pa = sP[buf];
             if (STEADY || tb + LAT_D - 2 < T) wait_vmn<LAT_D - 2>();   // the block's first slot has landed
             else wait_vmn<0>();
             f32x4 w = lds_read16_opaque(wring + rb * 256 + lane * 4);
-            float fa[4];
+            float fa[MTL][4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fa[kk] = pa[a_off(0) + KOFF * kk];
+            for (int m = 0; m < MTL; ++m)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) fa[m][kk] = pa[(UP ? abase_lo[m] : abase[m]) + t_off(0) + KOFF * kk];
             lds_wait(w);
 #pragma unroll
             for (int st = 0; st < SPB; ++st) {
@@ -975,33 +990,45 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
                 const int rn = (r + 1) & (LAT_D - 1);
                 const bool more = st + 1 < SPB;
                 f32x4 wn = w;
-                float fan[4] = {fa[0], fa[1], fa[2], fa[3]};
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], w[0], acc, 0, 0, 0);
-                // the next slot's operands first: their LDS latency hides behind three MFMAs.  Slot t + 1
-                // has landed when at most the LAT_D - 3 DMAs issued after it are outstanding (this
-                // slot's own DMA is issued below)
+                float fan[MTL][4];
+#pragma unroll
+                for (int m = 0; m < MTL; ++m)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) fan[m][kk] = fa[m][kk];
+#pragma unroll
+                for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][0], w[0], acc[m], 0, 0, 0);
+                // the next slot's operands first: their LDS latency hides behind the rest of the chain.
+                // Slot t + 1 has landed when at most the LAT_D - 3 DMAs issued after it are outstanding
+                // (this slot's own DMA is issued below)
                 if (more) {
                     if (STEADY || tb + st + LAT_D - 2 < T) wait_vmn<LAT_D - 3>();
                     else wait_vmn<0>();
                     wn = lds_read16_opaque(wring + rn * 256 + lane * 4);
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) fan[kk] = pa[a_off(st + 1) + KOFF * kk];
+                    for (int m = 0; m < MTL; ++m)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) fan[m][kk] = pa[(UP ? abase_lo[m] : abase[m]) + t_off(st + 1) + KOFF * kk];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], w[1], acc, 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][1], w[1], acc[m], 0, 0, 0);
                 if (STEADY || tb + st + LAT_D - 1 < T) {
                     glds16(wptr, wring + rp * 256);
                     wptr += wstep;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], w[2], acc, 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][2], w[2], acc[m], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], w[3], acc, 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][3], w[3], acc[m], 0, 0, 0);
                 if (more) {
                     lds_wait(wn);
                     w = wn;
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) fa[kk] = fan[kk];
+                    for (int m = 0; m < MTL; ++m)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) fa[m][kk] = fan[m][kk];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1030,47 +1057,58 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
 
     // ---- epilogues: the arithmetic of conv_epilogue, re-distributed
     if (EPI == EPI_LSTM) {
-        // wave w holds gate w (i | f | g | o) of channels cb*16 .. cb*16+15 for the 16 pixels
+        // wave w holds gate w (i | f | g | o) of channels cb*16 .. cb*16+15 for the 16 * MTL pixels
+        constexpr int NR = 16 * MTL;
         if (active) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sE[(wv * 16 + 4 * g + r) * 17 + (lane & 15)] = acc[r];
+            for (int m = 0; m < MTL; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sE[(wv * NR + m * 16 + 4 * g + r) * 17 + (lane & 15)] = acc[m][r];
         }
         __syncthreads();
-        const int row = tid >> 4, j = tid & 15, ch = cb * 16 + j, R = a.Cout;
-        int py, px;
-        lat_row_to_pixel<MAP>(row, pc, py, px);
-        const int y = ty0 + py, x = tx0 + px;
-        if (y < a.H && x < a.W) {
-            const long long pix = (long long)y * a.W + x;
-            const float cp = a.aux ? a.aux[pix * R + ch] : 0.0f;
-            const float gi = tz_hard_sigmoid(sE[(0 * 16 + row) * 17 + j]);
-            const float gf = tz_hard_sigmoid(sE[(1 * 16 + row) * 17 + j]);
-            const float gg = tz_tanh(sE[(2 * 16 + row) * 17 + j]);
-            const float go = tz_hard_sigmoid(sE[(3 * 16 + row) * 17 + j]);
-            const float t1 = gf * cp;
-            const float t2 = gi * gg;
-            const float c = t1 + t2;
-            const float rr = go * tz_tanh(c);
-            a.out0[(long long)n * a.out0_nstride + pix * R + ch] = rr;
-            if (a.out1) a.out1[(long long)n * a.out1_nstride + pix * R + ch] = c;
+        const int j = tid & 15, ch = cb * 16 + j, R = a.Cout;
+#pragma unroll
+        for (int m = 0; m < MTL; ++m) {
+            const int row = tid >> 4;
+            int py, px;
+            lat_row_to_pixel<MAP>(row, pc, py, px);
+            const int y = ty0 + py, x = tx0 + m * TS + px;
+            if (y < a.H && x < a.W) {
+                const long long pix = (long long)y * a.W + x;
+                const int rr_ = m * 16 + row;
+                const float cp = a.aux ? a.aux[pix * R + ch] : 0.0f;
+                const float gi = tz_hard_sigmoid(sE[(0 * NR + rr_) * 17 + j]);
+                const float gf = tz_hard_sigmoid(sE[(1 * NR + rr_) * 17 + j]);
+                const float gg = tz_tanh(sE[(2 * NR + rr_) * 17 + j]);
+                const float go = tz_hard_sigmoid(sE[(3 * NR + rr_) * 17 + j]);
+                const float t1 = gf * cp;
+                const float t2 = gi * gg;
+                const float c = t1 + t2;
+                const float rr = go * tz_tanh(c);
+                a.out0[(long long)n * a.out0_nstride + pix * R + ch] = rr;
+                if (a.out1) a.out1[(long long)n * a.out1_nstride + pix * R + ch] = c;
+            }
         }
     } else if (EPI == EPI_POOL_ERR) {
-        // prednet.py:289-291 then 274-277 of the next level; a lane's 4 registers are window g
+        // prednet.py:289-291 then 274-277 of the next level; a lane's 4 registers of tile m are window g
         const int H2 = a.H >> 1, W2 = a.W >> 1, C = a.Cout;
-        const int yp = (ty0 >> 1) + (g >> 1), xp = (tx0 >> 1) + (g & 1);
-        if (active && col < C && yp < H2 && xp < W2) {
-            const long long pp = (long long)yp * W2 + xp;
-            const float h = a.aux[pp * C + col];
-            float m = tz_relu(acc[0]);
 #pragma unroll
-            for (int r = 1; r < 4; ++r) {
-                const float t = tz_relu(acc[r]);
-                if (t > m) m = t;
+        for (int m = 0; m < MTL; ++m) {
+            const int yp = (ty0 >> 1) + (g >> 1), xp = ((tx0 + m * TS) >> 1) + (g & 1);
+            if (active && col < C && yp < H2 && xp < W2) {
+                const long long pp = (long long)yp * W2 + xp;
+                const float h = a.aux[pp * C + col];
+                float mx = tz_relu(acc[m][0]);
+#pragma unroll
+                for (int r = 1; r < 4; ++r) {
+                    const float t = tz_relu(acc[m][r]);
+                    if (t > mx) mx = t;
+                }
+                const float d1 = h - mx, d2 = mx - h;
+                float* o = a.out0 + (long long)n * a.out0_nstride;
+                o[pp * 2 * C + col] = tz_relu(d1);
+                o[pp * 2 * C + C + col] = tz_relu(d2);
             }
-            const float d1 = h - m, d2 = m - h;
-            float* o = a.out0 + (long long)n * a.out0_nstride;
-            o[pp * 2 * C + col] = tz_relu(d1);
-            o[pp * 2 * C + C + col] = tz_relu(d2);
         }
     }
 }
