@@ -302,8 +302,7 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
     // MI355X (profiles/r02/small_grid.txt): k_conv16 costs about 1.08 us per 16-channel x tap slot for
     // every workgroup a CU has to run (its K loop is a serial chain of 32-MFMA steps); k_convlat about
     // 0.15 us per slot when every workgroup has a CU to itself (<= 256 workgroups of 16 pixels, ring of
-    // 16); beyond that workgroups of 32 pixels (two accumulator chains per wave, ring of 8, two per CU):
-    // about 0.30 us per slot and round of 512.
+    // 16), 0.25-0.28 us per slot and round of 768 beyond that (ring of 8, three workgroups per CU).
     if (a.Wlat && a.nsrc > 0 && fullk && ctx->conv_impl && ctx->lat_mode && (NT == 3 || NT == 4) &&
         (epi == EPI_POOL_ERR || (epi == EPI_LSTM && NT == 4))) {
         const int ts_ = (epi != EPI_POOL_ERR && ups) ? 8 : 4;
@@ -311,19 +310,27 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         const long long rows_ = (a.H + ts_ - 1) / ts_ * (ts_ == 8 ? 4 : 1);
         const long long wglat1 = (long long)a.ncb * ((a.W + ts_ - 1) / ts_) * rows_ * nbatch;          // 16 pixels per workgroup
         const long long wglat2 = (long long)a.ncb * ((a.W + 2 * ts_ - 1) / (2 * ts_)) * rows_ * nbatch;  // 32 pixels
-        const bool wide = wglat1 > 256;   // more workgroups than CUs: two tiles per wave, ring of 8, two workgroups per CU
+        // 32-pixel workgroups (two accumulator chains per wave) only pay where even they run many rounds:
+        // measured at 512x512, B = 1 (profiles/r02/small_grid): 191 / 97 us against 220 / 108 with 16 pixels,
+        // but 98 / 149 us against 84 / 127 on cfg2's grids -- LDS traffic (every wave re-reads the A
+        // fragments, the weights pass through the ring), not the matrix pipe, bounds several workgroups
+        // per CU
+        const bool wide = wglat1 > 2560;
         int slots = 0;
         for (int s = 0; s < a.nsrc; ++s) slots += a.src[s].cpt * (a.src[s].up ? 4 : 9);
         const double t16 = slots * 1.08 * (double)((wg16 + 255) / 256);
-        const double tlat = wide ? (slots * 0.30 + 2.5) * (double)((wglat2 + 511) / 512) : slots * 0.15 + 2.5;
+        const double tlat = wide ? (slots * 0.30 + 2.5) * (double)((wglat2 + 511) / 512)
+                                 : (wglat1 <= 256 ? slots * 0.15 + 2.5
+                                                  : (slots * (ts_ == 8 ? 0.28 : 0.25) + 2.5) * (double)((wglat1 + 767) / 768));
         const bool use_lat = wg16 <= 768 && (ctx->lat_mode == 2 || tlat < 0.9 * t16);
         if (!use_lat) goto no_lat;
         const int blocks = (int)(wide ? wglat2 : wglat1);
         ps.sub = TZP_CONVLAT;
 #define TZ_LAT(e, u)                                                                                          \
     do {                                                                                                      \
-        if (!wide) hipLaunchKernelGGL((k_convlat<e, u, 16, 1>), dim3(blocks), dim3(256), 0, ctx->stream, a);  \
-        else hipLaunchKernelGGL((k_convlat<e, u, 8, 2>), dim3(blocks), dim3(256), 0, ctx->stream, a);         \
+        if (wide) hipLaunchKernelGGL((k_convlat<e, u, 8, 2>), dim3(blocks), dim3(256), 0, ctx->stream, a);    \
+        else if (blocks <= 256) hipLaunchKernelGGL((k_convlat<e, u, 16, 1>), dim3(blocks), dim3(256), 0, ctx->stream, a); \
+        else hipLaunchKernelGGL((k_convlat<e, u, 8, 1>), dim3(blocks), dim3(256), 0, ctx->stream, a);         \
     } while (0)
         if (epi == EPI_LSTM && ups) TZ_LAT(EPI_LSTM, true);
         else if (epi == EPI_LSTM) TZ_LAT(EPI_LSTM, false);
