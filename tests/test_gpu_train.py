@@ -39,7 +39,8 @@ def test_learn_then_compress_then_uncompress_on_the_gpu(tmp_path):
         _write_pngs(str(raw / ("seq%d" % s)), synth.turbulence(10, 61, 90, seed=200 + s))  # pads to 64 x 96
     data = str(tmp_path / "set")
     train_data_create.process_data(str(raw), data, val_folders=["seq4"])
-    X = np.load(os.path.join(data, "X_train.npy"))
+    from tezip_amd import hkl
+    X = hkl.load(os.path.join(data, "X_train.hkl"))
     assert X.shape == (40, 64, 96, 3) and (X[:, 61:] == 0).all() and (X[:, :, 90:] == 0).all()
     mdir = str(tmp_path / "model")
     out = _cli(["-l", mdir, data, "-v"])                       # tezip.py -l model dir (train.py:18)

@@ -53,11 +53,40 @@ def test_data_builder_and_short_training_run(tmp_path):
             Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(d / ("f%02d.png" % t))
     out = str(tmp_path / "set")
     train_data_create.process_data(str(tmp_path / "raw"), out, val_folders=["seq2"])
-    X = np.load(os.path.join(out, "X_train.npy"))
-    assert X.shape == (12, 24, 32, 3) and (X[:, 21:] == 0).all() and (X[:, :, 30:] == 0).all()
-    assert np.load(os.path.join(out, "sources_val.npy")).tolist() == ["val-seq2"] * 6
+    from tezip_amd import hkl
+    assert sorted(os.listdir(out)) == ["X_train.hkl", "X_val.hkl", "sources_train.hkl", "sources_val.hkl"]  # train.py:24-27
+    X = hkl.load(os.path.join(out, "X_train.hkl"))
+    assert X.dtype == np.uint8 and X.shape == (12, 24, 32, 3) and (X[:, 21:] == 0).all() and (X[:, :, 30:] == 0).all()
+    assert hkl.load(os.path.join(out, "sources_val.hkl")) == ["val-seq2"] * 6
     mdir = str(tmp_path / "model")
     hist = train.run(mdir, out, False, nb_epoch=6, samples_per_epoch=4, stack_sizes=(3, 16), device="cpu")
     assert hist[-1][0] < hist[0][0] and np.isfinite(hist).all()
     cfg, w, shape = weights.load_model(mdir)
     assert cfg.stack_sizes == (3, 16) and shape == (24, 32) and len(w) == 22
+
+
+def test_hickle_layout_files_open_with_real_h5py(tmp_path):
+    """X_*.hkl / sources_*.hkl written by tezip_amd/hkl.py, opened by libhdf5 through h5py (conda
+    interpreter of the build container; hickle itself is installable nowhere here, so its layout --
+    /data dataset + HICKLE_VERSION / base_type / type attributes -- is restated, parity unpinned)."""
+    import subprocess
+    from tezip_amd import hkl
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py) or subprocess.run([py, "-c", "import h5py"], capture_output=True).returncode != 0:
+        pytest.skip("no interpreter with h5py on this machine")
+    X = np.random.default_rng(5).integers(0, 256, (9, 16, 24, 3)).astype(np.uint8)
+    names = ["train-a"] * 5 + ["train-longer-name"] * 4
+    hkl.dump(X, str(tmp_path / "X.hkl"))
+    hkl.dump(names, str(tmp_path / "s.hkl"))
+    code = ("import h5py, numpy as np, sys, hashlib\n"
+            "f = h5py.File(sys.argv[1], 'r'); d = f['data']\n"
+            "print(f.attrs['HICKLE_VERSION'].decode(), d.attrs['base_type'].decode(), d.dtype, d.shape, hashlib.sha1(np.asarray(d).tobytes()).hexdigest())\n"
+            "g = h5py.File(sys.argv[2], 'r')['data']\n"
+            "print(g.attrs['base_type'].decode(), g.attrs['str_type'].decode(), '|'.join(x.decode() for x in np.asarray(g)))\n")
+    r = subprocess.run([py, "-c", code, str(tmp_path / "X.hkl"), str(tmp_path / "s.hkl")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import hashlib
+    l1, l2 = r.stdout.strip().splitlines()
+    assert l1 == "4.0.1 ndarray uint8 (9, 16, 24, 3) " + hashlib.sha1(X.tobytes()).hexdigest()
+    assert l2 == "list <class 'str'> " + "|".join(names)
+    assert (hkl.load(str(tmp_path / "X.hkl")) == X).all() and hkl.load(str(tmp_path / "s.hkl")) == names

@@ -16,8 +16,12 @@ UNDEF = 0xFFFFFFFFFFFFFFFF
 
 class H5File:
     def __init__(self, path):
+        import mmap
         with open(path, "rb") as f:
-            self.b = f.read()
+            try:  # datasets of training sets are GBs: map the file instead of reading it
+                self.b = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+            except (ValueError, OSError):
+                self.b = f.read()
         off = 0
         while self.b[off:off + 8] != SIG:  # the superblock may sit at 0, 512, 1024, ...
             off = 512 if off == 0 else off * 2
@@ -71,7 +75,7 @@ class H5File:
         if self.b[p:p + 4] != b"HEAP":
             raise ValueError("bad local heap")
         data = self._u(p + 24, 8) + self.base
-        end = self.b.index(b"\x00", data + off)
+        end = self.b.find(b"\x00", data + off)
         return self.b[data + off:end].decode()
 
     def _btree_entries(self, addr, heap):
@@ -114,9 +118,14 @@ class H5File:
                 shape = tuple(self._u(q + 8 * i, 8) for i in range(rank))
             elif mtype == 0x03:  # datatype
                 cls, bits0, sz = self.b[data] & 0x0F, self.b[data + 1], self._u(data + 4, 4)
-                if cls != 1 or (bits0 & 1) or sz not in (4, 8):
-                    raise NotImplementedError("only little-endian IEEE float datasets")
-                dtype = np.dtype("<f%d" % sz)
+                if cls == 1 and not (bits0 & 1) and sz in (4, 8):
+                    dtype = np.dtype("<f%d" % sz)
+                elif cls == 0 and not (bits0 & 1) and sz in (1, 2, 4, 8):  # fixed point: bit 3 = signed
+                    dtype = np.dtype("<%s%d" % ("i" if bits0 & 8 else "u", sz))
+                elif cls == 3:                                             # fixed-length string
+                    dtype = np.dtype("S%d" % sz)
+                else:
+                    raise NotImplementedError("only little-endian float / integer and fixed-length string datasets")
             elif mtype == 0x08:  # layout
                 ver, lclass = self.b[data], self.b[data + 1]
                 if ver != 3:
@@ -191,8 +200,14 @@ class Group:
         g = self.children[name] = Group(attrs)
         return g
 
-    def dataset(self, name, arr):
-        self.children[name] = np.ascontiguousarray(arr)
+    def dataset(self, name, arr, attrs=None):
+        arr = np.ascontiguousarray(arr)
+        self.children[name] = Dataset(arr, attrs) if attrs else arr
+
+
+class Dataset:
+    def __init__(self, arr, attrs=None):
+        self.arr, self.attrs = np.ascontiguousarray(arr), dict(attrs or {})
 
 
 def _pad8(b):
@@ -209,6 +224,10 @@ def _float_dtype(itemsize):
         return bytes([0x11, 0x20, 31, 0]) + struct.pack("<I", 4) + prop
     prop = struct.pack("<HHBBBBI", 0, 64, 52, 11, 0, 52, 1023)
     return bytes([0x11, 0x20, 63, 0]) + struct.pack("<I", 8) + prop
+
+
+def _int_dtype(dt):
+    return bytes([0x10, 0x08 if dt.kind == "i" else 0x00, 0, 0]) + struct.pack("<IHH", dt.itemsize, 0, 8 * dt.itemsize)
 
 
 def _dataspace(shape):
@@ -256,13 +275,26 @@ class _Writer:
     def put(self, off, data):
         self.buf[off:off + len(data)] = data
 
-    def write_dataset(self, arr):
-        if arr.dtype not in (np.float32, np.float64):
-            raise NotImplementedError("only float32/float64 datasets")
-        raw = self.alloc(arr.astype(arr.dtype.newbyteorder("<")).tobytes()) if arr.size else UNDEF
-        msgs = [(0x01, _dataspace(arr.shape)), (0x03, _float_dtype(arr.dtype.itemsize)),
+    def write_dataset(self, arr, attrs=None):
+        if arr.dtype in (np.float32, np.float64):
+            dt = _float_dtype(arr.dtype.itemsize)
+        elif arr.dtype.kind in "iu" and arr.dtype.itemsize in (1, 2, 4, 8):
+            dt = _int_dtype(arr.dtype)
+        elif arr.dtype.kind == "S":
+            dt = _string_dtype(arr.dtype.itemsize)
+        else:
+            raise NotImplementedError("dataset dtype %s" % arr.dtype)
+        if arr.dtype.kind != "S" and arr.dtype.byteorder == ">":
+            arr = arr.astype(arr.dtype.newbyteorder("<"))
+        raw = UNDEF
+        if arr.size:
+            raw = len(self.buf)
+            self.buf += memoryview(arr).cast("B")   # one copy, no intermediate bytes object
+            self.buf += b"\x00" * (-len(self.buf) % 8)
+        msgs = [(0x01, _dataspace(arr.shape)), (0x03, dt),
                 (0x05, bytes([2, 2, 2, 0])),  # fill value v2: late allocation, written if set, none defined
                 (0x08, bytes([3, 1]) + struct.pack("<QQ", raw, arr.nbytes))]
+        msgs += [_attr_message(k, v) for k, v in (attrs or {}).items()]
         return self.alloc(_object_header(msgs))
 
     def write_group(self, g):
@@ -273,7 +305,12 @@ class _Writer:
         kids = {}
         for n in names:  # children first: their addresses go into the symbol table node
             c = g.children[n]
-            kids[n] = self.write_group(c) if isinstance(c, Group) else (self.write_dataset(c), None, None)
+            if isinstance(c, Group):
+                kids[n] = self.write_group(c)
+            elif isinstance(c, Dataset):
+                kids[n] = (self.write_dataset(c.arr, c.attrs), None, None)
+            else:
+                kids[n] = (self.write_dataset(c), None, None)
         heap_data, offs = bytearray(8), {}
         for n in names:
             offs[n] = len(heap_data)

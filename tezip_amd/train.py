@@ -8,7 +8,7 @@ means, Adam (lr 1e-3, 1e-4 from epoch 75; Keras defaults beta 0.9/0.999, eps 1e-
 consecutive frames of one source, start drawn from all valid starts (data_utils.py:29-30).
 The forward pass here is ordinary torch conv2d (any device torch has); it is the same function
 as the inference path's TZ-PA1 arithmetic up to float32 summation order, which training does
-not need bit for bit.  Output: prednet_model.json + prednet_weights.hdf5 in WEIGHTS_DIR (the
+not need bit for bit.  Data: X_train.hkl etc. (hickle layout, tezip_amd/hkl.py) or .npy stacks.  Output: prednet_model.json + prednet_weights.hdf5 in WEIGHTS_DIR (the
 reference's own two files, Keras layout: tezip_amd/weights.py), readable by compress.run /
 decompress.run here and by the reference's compress.py:143-173.  Data: X_train.npy etc. from tezip_amd.train_data_create.
 """
@@ -109,13 +109,18 @@ def l0_loss(errors, nt):
 def run(WEIGHTS_DIR, DATA_DIR, VERBOSE, nb_epoch=100, samples_per_epoch=5, N_seq_val=2, nt=2, seed=123,
         stack_sizes=(3, 48, 96, 192), device=None):
     import torch
+    def load(name):
+        """The reference's hickle files (train.py:24-29, data_utils.py:14-15) or .npy stacks."""
+        h = os.path.join(DATA_DIR, name + ".hkl")
+        if os.path.exists(h):
+            from . import hkl
+            return hkl.load(h)
+        return np.load(os.path.join(DATA_DIR, name + ".npy"), mmap_mode="r" if name.startswith("X_") else None)
+
     try:
-        X = np.load(os.path.join(DATA_DIR, "X_train.npy"), mmap_mode="r")
-        src = np.load(os.path.join(DATA_DIR, "sources_train.npy"))
-        Xv = np.load(os.path.join(DATA_DIR, "X_val.npy"), mmap_mode="r")
-        srcv = np.load(os.path.join(DATA_DIR, "sources_val.npy"))
+        X, src, Xv, srcv = load("X_train"), np.asarray(load("sources_train")), load("X_val"), np.asarray(load("sources_val"))
     except (OSError, ValueError) as e:
-        print("ERROR: No such file or directory:", os.path.join(DATA_DIR, "X_train.npy"))
+        print("ERROR: No such file or directory:", os.path.join(DATA_DIR, "X_train.hkl"))
         print("(build the training set with `python -m tezip_amd.train_data_create`)")
         print("\nORIGINAL ERROR MESSAGE:", e)
         exit()

@@ -1,9 +1,11 @@
 """Training-set builder: same job as the reference's train_data_create.py (a folder of
 time-series sub-folders of images -> zero-padded uint8 stacks + a per-image source label,
 random ~10 % of the folders held out for validation unless given), written for this build:
-the stacks are saved as .npy (the reference uses hickle, which is not available here):
-    X_train.npy  (N, Hp, Wp, 3) uint8      sources_train.npy  (N,) str
-    X_val.npy    ...                        sources_val.npy
+the stacks are saved under the reference's names and in its container, hickle 4.0.1 files
+(train_data_create.py:82-83; written by tezip_amd/hkl.py on the built-in HDF5 writer, since hickle
+is not installable here -- layout restated from knowledge of that version, parity unpinned):
+    X_train.hkl  (N, Hp, Wp, 3) uint8      sources_train.hkl  list of N str
+    X_val.hkl    ...                        sources_val.hkl
 Usage: python -m tezip_amd.train_data_create DATA_DIR OUTPUT_DIR [-v VAL_FOLDER ...]"""
 import argparse
 import os
@@ -11,6 +13,7 @@ import random
 
 import numpy as np
 
+from . import hkl
 from .data_utils import padding_shape
 
 
@@ -47,8 +50,8 @@ def process_data(data_dir, output_dir, val_folders=None, seed=None):
             for i, p in enumerate(paths):
                 im = np.array(Image.open(p).convert("RGB"))
                 X[i, : im.shape[0], : im.shape[1]] = im
-            np.save(os.path.join(output_dir, "X_%s.npy" % name), X)
-            np.save(os.path.join(output_dir, "sources_%s.npy" % name), np.array(sources))
+            hkl.dump(X, os.path.join(output_dir, "X_%s.hkl" % name))
+            hkl.dump(sources, os.path.join(output_dir, "sources_%s.hkl" % name))
     except (PermissionError, IndexError, UnidentifiedImageError):
         print("ERROR: Contains non-image files or inappropriate folders.")
         exit()
