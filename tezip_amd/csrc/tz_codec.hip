@@ -165,27 +165,42 @@ __global__ __launch_bounds__(256) void k_q_init(int16_t* __restrict__ tmp, const
         if (!skip[i / frame_elems]) tmp[i] = TZ_SENTINEL;
 }
 
-// Wave-parallel exact greedy segmentation.  One workgroup (16 waves) per (frame, channel)
-// chain; the chain is walked in chunks of 64 elements (lane i <-> element).  A run started at s
-// breaks at the first i with min(Du[s..i]) < max(Dl[s..i]) (compress.py:60 -- a-b<0 <=> a<b in
-// IEEE), which is monotone in i, so per chunk:
-//   WORKER waves 1..15 (carry independent, one chunk each per round):
+// Wave-parallel exact greedy segmentation.  The chain of a (frame, channel) is walked in chunks of
+// 64 elements (lane i <-> element).  A run started at s breaks at the first i with
+// min(Du[s..i]) < max(Dl[s..i]) (compress.py:60 -- a-b<0 <=> a<b in IEEE), which is monotone in i, so
+// per chunk:
+//   WORKER waves (carry independent, one chunk each per round; q_chunk):
 //   1. range tables T_k[i] = (min Du, max Dl) over [i, i+2^k) by shuffles (k = 0..5),
 //   2. nxt[s] = first break after s for EVERY s (fresh start) by binary lifting over T_k,
 //      together with the run's (u, l) up to the break,
-//   3. inclusive prefix (min Du, max Dl) from the chunk start; all of it goes to an LDS slot.
-//   RESOLVER wave 0 (sequential over chunks, one round behind the workers):
+//   3. inclusive prefix (min Du, max Dl) from the chunk start,
+//   2b. heads[s] = bit mask of the run heads reached from a start at s (pointer doubling).
+//   RESOLVER wave (sequential over chunks, one round behind the workers):
 //   4. the run carried in from earlier chunks breaks at the first i with
 //      min(u, P_u[i]) < max(l, P_l[i])  (ballot); the true heads are the nxt-chain from that
-//      break, which the workers have already expanded into a bit mask per start (pointer
-//      doubling), so this is one LDS lookup,
+//      break, which the workers have already expanded into a bit mask per start: one lookup,
 //   5. every head whose run closes inside the chunk stores trunc((u+l)/2) (compress.py:61,
 //      truncation by the int64 store) at the head position of `tmp`; the last head carries on.
-// Rounds are double-buffered in LDS with one barrier per round.  Nothing depends on run
-// lengths; elements past the chain end are (+inf, -inf) and can neither break nor tighten a run.
+// The walk of the resolver is the serial critical path (about 0.3 us per chunk, 4096 chunks per
+// 512x512 chain), so the chain is cut into QSEG SEGMENTS that are walked concurrently, each from a
+// fresh start at its first element (round 2; one workgroup of 1 + QW waves per segment, eight of them
+// share a CU).  A fresh start is a guess -- the true run entering a segment began earlier -- and
+// k_q_stitch repairs it exactly: two greedy chains over the same data never cross and coincide from
+// their first common head on, so the true chain is followed from the segment start only until it
+// hits a head of the speculative chain (typically within the first chunk); the speculative heads
+// before that point are erased, the true ones written, everything behind it is already right.
+// Nothing depends on run lengths; elements past the chain end are (+inf, -inf) and can neither
+// break nor tighten a run.
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
-static constexpr int QW = 15;  // worker waves per chain (+1 resolver wave = 1024 threads)
+static constexpr int QW = 3;     // worker waves per segment (+1 resolver wave = 256 threads)
+static constexpr int QSEG = 8;   // segments per chain
+
+struct QChunk {
+    double cu, cl, pu, pl;
+    unsigned long long heads;
+    int nxt;
+};
 
 struct QSlot {
     double cu[64], cl[64], pu[64], pl[64];
@@ -193,10 +208,96 @@ struct QSlot {
     int nxt[64];
 };
 
-__global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ orig, const int16_t* __restrict__ diff,
-                                                 const uint8_t* __restrict__ skip, int HW, QParams qp,
-                                                 const double* __restrict__ Echain, int16_t* __restrict__ tmp) {
-    const int f = blockIdx.x / 3, c = blockIdx.x % 3;
+struct QState {  // the run that is open at a segment boundary
+    double u, l;
+    int head, pad;
+};
+
+// steps 1-3 and 2b for chunk `ch` of channel c (every lane returns its element's entries)
+__device__ __forceinline__ QChunk q_chunk(const uint8_t* __restrict__ o, const int16_t* __restrict__ d, int c, int ch, int HW,
+                                          const QParams& qp, double E, int lane) {
+    const double inf = __builtin_huge_val();
+    const int idx = ch * 64 + lane;
+    double du = inf, dl = -inf;
+    if (idx < HW) {
+        double e = qp.mode == TZ_MODE_PWREL ? (double)o[(size_t)idx * 3 + c] * qp.b0 : E;
+        double df = (double)d[(size_t)idx * 3 + c];
+        du = df + e;
+        dl = df - e;
+    }
+    // 1. range tables (level 0 is the element itself); shfl_down past lane 63 returns
+    //    the caller's own value, which clamps the range at the chunk end
+    double tu[6], tl[6];
+    tu[0] = du;
+    tl[0] = dl;
+#pragma unroll
+    for (int k = 1; k < 6; ++k) {
+        double a = __shfl_down(tu[k - 1], 1 << (k - 1), 64), b = __shfl_down(tl[k - 1], 1 << (k - 1), 64);
+        tu[k] = tu[k - 1] < a ? tu[k - 1] : a;
+        tl[k] = tl[k - 1] > b ? tl[k - 1] : b;
+    }
+    // 3. inclusive prefix from the chunk start
+    double pu = du, pl = dl;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        double a = __shfl_up(pu, sft, 64), b = __shfl_up(pl, sft, 64);
+        if (lane >= sft) {
+            pu = pu < a ? pu : a;
+            pl = pl > b ? pl : b;
+        }
+    }
+    // 2. binary lifting: longest break-free extension of a run that starts at this lane
+    double cu = du, cl = dl;
+    int pos = lane + 1;
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+        const int step = 1 << k;
+        int src = pos < 63 ? pos : 63;
+        double xu = shfl_d(tu[k], src), xl = shfl_d(tl[k], src);
+        double nu = cu < xu ? cu : xu, nl = cl > xl ? cl : xl;
+        bool ok = (pos + step <= 64) && !(nu - nl < 0.0);
+        if (ok) {
+            cu = nu;
+            cl = nl;
+            pos += step;
+        }
+    }
+    // 2b. pointer doubling: the set of run heads reached from a start at this lane
+    unsigned long long M = 1ull << lane;
+    int J = pos;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int src = J < 64 ? J : lane;
+        unsigned long long Mj = __shfl(M, src, 64);
+        int Jj = __shfl(J, src, 64);
+        if (J < 64) {
+            M |= Mj;
+            J = Jj;
+        }
+    }
+    return QChunk{cu, cl, pu, pl, M, pos};  // nxt in [lane+1, 64]; 64 = the run leaves the chunk
+}
+
+__device__ __forceinline__ double q_rl_d(double v, int src) {  // src is wave-uniform
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ unsigned long long q_rl_u64(unsigned long long v, int src) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src) << 32) |
+           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+}
+
+// Speculative walk of segment `seg` of every chain (blockIdx.x = (frame * 3 + channel) * QSEG + seg):
+// fresh start at the segment's first element.  spec[chain][chunk] receives the heads the walk put into
+// each chunk, seg_out[chain][seg] the run left open at the segment end.
+__global__ __launch_bounds__(64 * (QW + 1)) void k_q_heads(const uint8_t* __restrict__ orig, const int16_t* __restrict__ diff,
+                                                         const uint8_t* __restrict__ skip, int HW, QParams qp,
+                                                         const double* __restrict__ Echain, int16_t* __restrict__ tmp,
+                                                         unsigned long long* __restrict__ spec, QState* __restrict__ seg_out) {
+    const int chain = blockIdx.x / QSEG, seg = blockIdx.x % QSEG;
+    const int f = chain / 3, c = chain % 3;
     if (skip[f]) return;
     __shared__ QSlot slots[2][QW];
     const int16_t* d = diff + (size_t)f * HW * 3;
@@ -205,88 +306,37 @@ __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ or
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double E = 0.0;
     if (qp.mode == TZ_MODE_ABS) E = fabs(qp.b0);
-    else if (qp.mode != TZ_MODE_PWREL) E = Echain[f * 3 + c];
+    else if (qp.mode != TZ_MODE_PWREL) E = Echain[chain];
     const double inf = __builtin_huge_val();
     const int nch = (HW + 63) >> 6;
-    const int nrounds = (nch + QW - 1) / QW;
-    double u = inf, l = -inf;  // resolver: state of the run that is open at the chunk boundary
-    int chead = 0;             // resolver: its head (chain index)
+    const int cps = (nch + QSEG - 1) / QSEG;          // chunks per segment
+    const int c0 = seg * cps, c1 = min(nch, c0 + cps);
+    unsigned long long* sp = spec + (size_t)chain * nch;
+    if (c0 >= c1) {                                    // empty segment (short chain): passes the state on untouched
+        if (threadIdx.x == 0) seg_out[chain * QSEG + seg] = QState{inf, -inf, -1, 0};
+        return;
+    }
+    const int nrounds = (c1 - c0 + QW - 1) / QW;
+    double u = inf, l = -inf;      // resolver: state of the run that is open at the chunk boundary
+    int chead = c0 * 64;           // resolver: its head (chain index): the fresh start
     for (int r = 0; r <= nrounds; ++r) {
         if (wv > 0 && r < nrounds) {
-            const int ch = r * QW + (wv - 1);
-            if (ch < nch) {
-                const int idx = ch * 64 + lane;
-                double du = inf, dl = -inf;
-                if (idx < HW) {
-                    double e = qp.mode == TZ_MODE_PWREL ? (double)o[(size_t)idx * 3 + c] * qp.b0 : E;
-                    double df = (double)d[(size_t)idx * 3 + c];
-                    du = df + e;
-                    dl = df - e;
-                }
-                // 1. range tables (level 0 is the element itself); shfl_down past lane 63 returns
-                //    the caller's own value, which clamps the range at the chunk end
-                double tu[6], tl[6];
-                tu[0] = du;
-                tl[0] = dl;
-#pragma unroll
-                for (int k = 1; k < 6; ++k) {
-                    double a = __shfl_down(tu[k - 1], 1 << (k - 1), 64), b = __shfl_down(tl[k - 1], 1 << (k - 1), 64);
-                    tu[k] = tu[k - 1] < a ? tu[k - 1] : a;
-                    tl[k] = tl[k - 1] > b ? tl[k - 1] : b;
-                }
-                // 3. inclusive prefix from the chunk start
-                double pu = du, pl = dl;
-#pragma unroll
-                for (int sft = 1; sft < 64; sft <<= 1) {
-                    double a = __shfl_up(pu, sft, 64), b = __shfl_up(pl, sft, 64);
-                    if (lane >= sft) {
-                        pu = pu < a ? pu : a;
-                        pl = pl > b ? pl : b;
-                    }
-                }
-                // 2. binary lifting: longest break-free extension of a run that starts at this lane
-                double cu = du, cl = dl;
-                int pos = lane + 1;
-#pragma unroll
-                for (int k = 5; k >= 0; --k) {
-                    const int step = 1 << k;
-                    int src = pos < 63 ? pos : 63;
-                    double xu = shfl_d(tu[k], src), xl = shfl_d(tl[k], src);
-                    double nu = cu < xu ? cu : xu, nl = cl > xl ? cl : xl;
-                    bool ok = (pos + step <= 64) && !(nu - nl < 0.0);
-                    if (ok) {
-                        cu = nu;
-                        cl = nl;
-                        pos += step;
-                    }
-                }
+            const int ch = c0 + r * QW + (wv - 1);
+            if (ch < c1) {
+                const QChunk q = q_chunk(o, d, c, ch, HW, qp, E, lane);
                 QSlot& sl = slots[r & 1][wv - 1];
-                sl.cu[lane] = cu;
-                sl.cl[lane] = cl;
-                sl.pu[lane] = pu;
-                sl.pl[lane] = pl;
-                sl.nxt[lane] = pos;  // in [lane+1, 64]; 64 = the run leaves the chunk
-                // 2b. pointer doubling: the set of run heads reached from a start at this lane
-                unsigned long long M = 1ull << lane;
-                int J = pos;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    int src = J < 64 ? J : lane;
-                    unsigned long long Mj = __shfl(M, src, 64);
-                    int Jj = __shfl(J, src, 64);
-                    if (J < 64) {
-                        M |= Mj;
-                        J = Jj;
-                    }
-                }
-                sl.heads[lane] = M;
+                sl.cu[lane] = q.cu;
+                sl.cl[lane] = q.cl;
+                sl.pu[lane] = q.pu;
+                sl.pl[lane] = q.pl;
+                sl.nxt[lane] = q.nxt;
+                sl.heads[lane] = q.heads;
             }
         } else if (wv == 0 && r > 0) {
-            // The walk over the chunks is the serial critical path of the whole kernel (the workers
-            // run 15 chunks in parallel, this wave one after the other), so nothing that does not
-            // depend on the carried (u, l) may sit on it: every LDS operand of chunk w+1 is loaded
-            // while chunk w resolves, and the lookups at the wave-uniform positions j0 / last are
-            // register reads (v_readlane), not LDS permutes.
+            // The walk over the chunks is the serial critical path, so nothing that does not depend on
+            // the carried (u, l) may sit on it: every LDS operand of chunk w+1 is loaded while chunk w
+            // resolves, and the lookups at the wave-uniform positions j0 / last are register reads
+            // (v_readlane), not LDS permutes.
             struct Pre {
                 double pu, pl, cu, cl;
                 unsigned long long hd;
@@ -296,23 +346,19 @@ __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ or
                 const QSlot& sl = slots[(r - 1) & 1][w];
                 return Pre{sl.pu[lane], sl.pl[lane], sl.cu[lane], sl.cl[lane], sl.heads[lane], sl.nxt[lane]};
             };
-            auto rl_d = [](double v, int src) {  // src is wave-uniform
-                const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
-                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
-                return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-            };
             Pre cur = load(0), nx = cur;
             for (int w = 0; w < QW; ++w) {
-                const int ch = (r - 1) * QW + w;
-                if (ch >= nch) break;
-                if (w + 1 < QW && ch + 1 < nch) nx = load(w + 1);
+                const int ch = c0 + (r - 1) * QW + w;
+                if (ch >= c1) break;
+                if (w + 1 < QW && ch + 1 < c1) nx = load(w + 1);
                 // 4. where does the carried run break?
                 const double eu = u < cur.pu ? u : cur.pu, el = l > cur.pl ? l : cur.pl;
                 const unsigned long long brk = __ballot(eu - el < 0.0);
+                const unsigned long long first = ch == c0 ? 1ull : 0ull;   // the fresh start is a head of the guess
                 if (brk == 0ull) {
-                    u = rl_d(eu, 63);
-                    l = rl_d(el, 63);
+                    u = q_rl_d(eu, 63);
+                    l = q_rl_d(el, 63);
+                    if (lane == 0) sp[ch] = first;
                     cur = nx;
                     continue;
                 }
@@ -320,27 +366,102 @@ __global__ __launch_bounds__(1024) void k_q_heads(const uint8_t* __restrict__ or
                 {
                     double uc = u, lc = l;
                     if (j0 > 0) {
-                        uc = rl_d(eu, j0 - 1);
-                        lc = rl_d(el, j0 - 1);
+                        uc = q_rl_d(eu, j0 - 1);
+                        lc = q_rl_d(el, j0 - 1);
                     }
                     if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
                 }
-                const unsigned long long heads =
-                    ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cur.hd >> 32), j0) << 32) |
-                    (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cur.hd, j0);
+                const unsigned long long heads = q_rl_u64(cur.hd, j0);
                 const int last = 63 - __clzll((long long)heads);
                 // 5. closed runs store their value at their head; the last head carries on
                 if (((heads >> lane) & 1ull) && cur.nx < 64)
                     t[(size_t)(ch * 64 + lane) * 3 + c] = (int16_t)(long long)((cur.cu + cur.cl) / 2);
-                u = rl_d(cur.cu, last);
-                l = rl_d(cur.cl, last);
+                if (lane == 0) sp[ch] = heads | first;
+                u = q_rl_d(cur.cu, last);
+                l = q_rl_d(cur.cl, last);
                 chead = ch * 64 + last;
                 cur = nx;
             }
         }
         __syncthreads();
     }
-    if (wv == 0 && lane == 0 && HW > 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((u + l) / 2);
+    if (wv == 0 && lane == 0) seg_out[chain * QSEG + seg] = QState{u, l, chead, 0};
+}
+
+// Exact repair of the segment guesses, one wave per chain, segments in order.  `st` is the TRUE open run
+// entering segment k.  It is walked through the segment's chunks (tables recomputed by this wave) until
+// the true chain shares a head with the guessed one (mask spec[chunk]): guessed heads before that point
+// are erased (sentinel), true ones written; from the common head on the guess is right, so the true
+// state leaving the segment is the guessed one.  A segment without any common head is walked to
+// its end (worst case: the serial walk of round 1).  Finally the run open at the chain end is closed.
+__global__ __launch_bounds__(64) void k_q_stitch(const uint8_t* __restrict__ orig, const int16_t* __restrict__ diff,
+                                               const uint8_t* __restrict__ skip, int HW, QParams qp,
+                                               const double* __restrict__ Echain, int16_t* __restrict__ tmp,
+                                               const unsigned long long* __restrict__ spec, const QState* __restrict__ seg_out) {
+    const int chain = blockIdx.x, f = chain / 3, c = chain % 3;
+    if (skip[f] || HW <= 0) return;
+    const int16_t* d = diff + (size_t)f * HW * 3;
+    const uint8_t* o = orig + (size_t)f * HW * 3;
+    int16_t* t = tmp + (size_t)f * HW * 3;
+    const int lane = threadIdx.x;
+    double E = 0.0;
+    if (qp.mode == TZ_MODE_ABS) E = fabs(qp.b0);
+    else if (qp.mode != TZ_MODE_PWREL) E = Echain[chain];
+    const int nch = (HW + 63) >> 6;
+    const int cps = (nch + QSEG - 1) / QSEG;
+    const unsigned long long* sp = spec + (size_t)chain * nch;
+    QState st = seg_out[chain * QSEG];          // segment 0 starts where the chain starts: its guess is the truth
+    double u = st.u, l = st.l;
+    int chead = st.head;
+    for (int k = 1; k < QSEG; ++k) {
+        const int c0 = k * cps, c1 = min(nch, c0 + cps);
+        if (c0 >= c1) break;
+        bool merged = false;
+        for (int ch = c0; ch < c1 && !merged; ++ch) {
+            const QChunk q = q_chunk(o, d, c, ch, HW, qp, E, lane);
+            const unsigned long long S = sp[ch];
+            const double eu = u < q.pu ? u : q.pu, el = l > q.pl ? l : q.pl;
+            const unsigned long long brk = __ballot(eu - el < 0.0);
+            if (brk == 0ull) {                  // the true run swallows the chunk: every guessed head in it is wrong
+                if ((S >> lane) & 1ull) t[(size_t)(ch * 64 + lane) * 3 + c] = TZ_SENTINEL;
+                u = q_rl_d(eu, 63);
+                l = q_rl_d(el, 63);
+                continue;
+            }
+            const int j0 = __ffsll((long long)brk) - 1;
+            double uc = u, lc = l;
+            if (j0 > 0) {
+                uc = q_rl_d(eu, j0 - 1);
+                lc = q_rl_d(el, j0 - 1);
+            }
+            const unsigned long long T = q_rl_u64(q.heads, j0);          // true heads of this chunk
+            const unsigned long long common = T & S;
+            const int m = common ? __ffsll((long long)common) - 1 : 64;  // first common head
+            const unsigned long long below = m >= 64 ? ~0ull : ((1ull << m) - 1ull);
+            const bool mine = (below >> lane) & 1ull;
+            if (mine && ((S >> lane) & 1ull) && !((T >> lane) & 1ull)) t[(size_t)(ch * 64 + lane) * 3 + c] = TZ_SENTINEL;
+            if (mine && ((T >> lane) & 1ull) && q.nxt < 64)
+                t[(size_t)(ch * 64 + lane) * 3 + c] = (int16_t)(long long)((q.cu + q.cl) / 2);
+            // the carried run closes at j0 (written after the erasures: its head may be a guessed head of this chunk)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
+            if (common) {
+                merged = true;
+            } else {
+                const int last = 63 - __clzll((long long)T);
+                u = q_rl_d(q.cu, last);
+                l = q_rl_d(q.cl, last);
+                chead = ch * 64 + last;
+            }
+        }
+        if (merged) {
+            st = seg_out[chain * QSEG + k];
+            u = st.u;
+            l = st.l;
+            chead = st.head;
+        }
+    }
+    if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((u + l) / 2);
 }
 
 static constexpr int QFB = 2048;  // pixels per fill block
@@ -434,12 +555,15 @@ int tzk_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8
     int HW = H * W;
     size_t fe = (size_t)HW * 3;
     int nblk = (HW + QFB - 1) / QFB;
-    void *d_skip, *d_E, *d_tmp, *d_carry, *d_mm;
+    void *d_skip, *d_E, *d_tmp, *d_carry, *d_mm, *d_spec, *d_seg;
     TZ_TRY(tz_pool_alloc(ctx, nframes, &d_skip));
     TZ_TRY(tz_pool_alloc(ctx, sizeof(double) * 3 * nframes, &d_E));
     TZ_TRY(tz_pool_alloc(ctx, sizeof(int) * 6 * nframes, &d_mm));
     TZ_TRY(tz_pool_alloc(ctx, fe * nframes * 2, &d_tmp));
     TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * nblk * 3 * 2, &d_carry));
+    const int nch = (HW + 63) / 64;
+    TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * 3 * nch * sizeof(unsigned long long), &d_spec));
+    TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * 3 * QSEG * sizeof(QState), &d_seg));
     TZ_TRY(tz_upload(ctx, d_skip, h_skip, nframes));
     QParams qp{mode, b0, b1};
     tz_prof_scope ps(ctx, TZP_QUANT);
@@ -452,8 +576,12 @@ int tzk_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8
     }
     hipLaunchKernelGGL(k_q_init, dim3(grid_for(fe * nframes, 256)), dim3(256), 0, ctx->stream, (int16_t*)d_tmp,
                        (const uint8_t*)d_skip, fe, nframes);
-    hipLaunchKernelGGL(k_q_heads, dim3(nframes * 3), dim3(64 * (QW + 1)), 0, ctx->stream, orig, (const int16_t*)diff,
-                       (const uint8_t*)d_skip, HW, qp, (const double*)d_E, (int16_t*)d_tmp);
+    hipLaunchKernelGGL(k_q_heads, dim3(nframes * 3 * QSEG), dim3(64 * (QW + 1)), 0, ctx->stream, orig, (const int16_t*)diff,
+                       (const uint8_t*)d_skip, HW, qp, (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec,
+                       (QState*)d_seg);
+    hipLaunchKernelGGL(k_q_stitch, dim3(nframes * 3), dim3(64), 0, ctx->stream, orig, (const int16_t*)diff,
+                       (const uint8_t*)d_skip, HW, qp, (const double*)d_E, (int16_t*)d_tmp, (const unsigned long long*)d_spec,
+                       (const QState*)d_seg);
     hipLaunchKernelGGL(k_q_last, dim3(nblk, nframes), dim3(256), 0, ctx->stream, (const int16_t*)d_tmp,
                        (const uint8_t*)d_skip, HW, nblk, (int16_t*)d_carry);
     hipLaunchKernelGGL(k_q_carry, dim3((nframes * 3 + 63) / 64), dim3(64), 0, ctx->stream, (int16_t*)d_carry,
