@@ -213,57 +213,112 @@ struct QState {  // the run that is open at a segment boundary
     int head, pad;
 };
 
-// steps 1-3 and 2b for chunk `ch` of channel c (every lane returns its element's entries)
+// steps 1-3 and 2b for chunk `ch` of channel c (every lane returns its element's entries).
+//
+// The cross-lane traffic of these steps is what the quantiser costs: a 64-bit shuffle is two
+// ds_bpermute_b32, and with (min Du, max Dl) as two doubles a chunk took 86 of them -- 1.1 ms of LDS
+// crossbar per 4096-chunk chain and CU, which is the 1.29 ms k_q_heads ran at in round 1 (cutting the
+// resolver's walk into segments alone changed nothing: profiles/r02/quantiser.md).  For abs / rel /
+// absrel the tolerance E is one constant per chain, so Du = fl(d + E) and Dl = fl(d - E) are monotone
+// in the integer delta d: min Du = fl(min d + E), max Dl = fl(max d - E) EXACTLY.  The tables, the
+// prefix and the lifting therefore run on (min d, max d) packed as two int16 in ONE 32-bit word (35
+// shuffles per chunk), and the doubles the reference compares (compress.py:55-60) are formed from
+// them only where a break is tested or a run value is produced.  pwrel (E = orig * b per element)
+// keeps the double tables.
+__device__ __forceinline__ int q_pack(int mn, int mx) { return (mn & 0xFFFF) | (mx << 16); }
+__device__ __forceinline__ int q_lo(int p) { return (int)(short)(p & 0xFFFF); }
+__device__ __forceinline__ int q_hi(int p) { return p >> 16; }
+
+template <bool PW>
 __device__ __forceinline__ QChunk q_chunk(const uint8_t* __restrict__ o, const int16_t* __restrict__ d, int c, int ch, int HW,
                                           const QParams& qp, double E, int lane) {
-    const double inf = __builtin_huge_val();
     const int idx = ch * 64 + lane;
-    double du = inf, dl = -inf;
-    if (idx < HW) {
-        double e = qp.mode == TZ_MODE_PWREL ? (double)o[(size_t)idx * 3 + c] * qp.b0 : E;
-        double df = (double)d[(size_t)idx * 3 + c];
-        du = df + e;
-        dl = df - e;
-    }
-    // 1. range tables (level 0 is the element itself); shfl_down past lane 63 returns
-    //    the caller's own value, which clamps the range at the chunk end
-    double tu[6], tl[6];
-    tu[0] = du;
-    tl[0] = dl;
-#pragma unroll
-    for (int k = 1; k < 6; ++k) {
-        double a = __shfl_down(tu[k - 1], 1 << (k - 1), 64), b = __shfl_down(tl[k - 1], 1 << (k - 1), 64);
-        tu[k] = tu[k - 1] < a ? tu[k - 1] : a;
-        tl[k] = tl[k - 1] > b ? tl[k - 1] : b;
-    }
-    // 3. inclusive prefix from the chunk start
-    double pu = du, pl = dl;
-#pragma unroll
-    for (int sft = 1; sft < 64; sft <<= 1) {
-        double a = __shfl_up(pu, sft, 64), b = __shfl_up(pl, sft, 64);
-        if (lane >= sft) {
-            pu = pu < a ? pu : a;
-            pl = pl > b ? pl : b;
-        }
-    }
-    // 2. binary lifting: longest break-free extension of a run that starts at this lane
-    double cu = du, cl = dl;
+    unsigned long long M = 1ull << lane;
     int pos = lane + 1;
+    QChunk out;
+    if (!PW) {
+        // past the chain end: (min, max) = (+32767, -32768) can neither break nor tighten a run
+        int mn = 32767, mx = -32768;
+        if (idx < HW) mn = mx = (int)d[(size_t)idx * 3 + c];
+        int tb[6];
+        tb[0] = q_pack(mn, mx);
 #pragma unroll
-    for (int k = 5; k >= 0; --k) {
-        const int step = 1 << k;
-        int src = pos < 63 ? pos : 63;
-        double xu = shfl_d(tu[k], src), xl = shfl_d(tl[k], src);
-        double nu = cu < xu ? cu : xu, nl = cl > xl ? cl : xl;
-        bool ok = (pos + step <= 64) && !(nu - nl < 0.0);
-        if (ok) {
-            cu = nu;
-            cl = nl;
-            pos += step;
+        for (int k = 1; k < 6; ++k) {  // shfl_down past lane 63 returns the caller's own value
+            const int q = __shfl_down(tb[k - 1], 1 << (k - 1), 64);
+            tb[k] = q_pack(min(q_lo(tb[k - 1]), q_lo(q)), max(q_hi(tb[k - 1]), q_hi(q)));
         }
+        int pp = tb[0];
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int q = __shfl_up(pp, sft, 64);
+            if (lane >= sft) pp = q_pack(min(q_lo(pp), q_lo(q)), max(q_hi(pp), q_hi(q)));
+        }
+        int cmn = mn, cmx = mx;
+#pragma unroll
+        for (int k = 5; k >= 0; --k) {
+            const int step = 1 << k;
+            const int src = pos < 63 ? pos : 63;
+            const int q = __shfl(tb[k], src, 64);
+            const int nmn = min(cmn, q_lo(q)), nmx = max(cmx, q_hi(q));
+            const double nu = (double)nmn + E, nl = (double)nmx - E;
+            const bool ok = (pos + step <= 64) && !(nu - nl < 0.0);
+            if (ok) {
+                cmn = nmn;
+                cmx = nmx;
+                pos += step;
+            }
+        }
+        out.cu = (double)cmn + E;
+        out.cl = (double)cmx - E;
+        out.pu = (double)q_lo(pp) + E;
+        out.pl = (double)q_hi(pp) - E;
+    } else {
+        const double inf = __builtin_huge_val();
+        double du = inf, dl = -inf;
+        if (idx < HW) {
+            const double e = (double)o[(size_t)idx * 3 + c] * qp.b0;
+            const double df = (double)d[(size_t)idx * 3 + c];
+            du = df + e;
+            dl = df - e;
+        }
+        double tu[6], tl[6];
+        tu[0] = du;
+        tl[0] = dl;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) {
+            double a = __shfl_down(tu[k - 1], 1 << (k - 1), 64), b = __shfl_down(tl[k - 1], 1 << (k - 1), 64);
+            tu[k] = tu[k - 1] < a ? tu[k - 1] : a;
+            tl[k] = tl[k - 1] > b ? tl[k - 1] : b;
+        }
+        double pu = du, pl = dl;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            double a = __shfl_up(pu, sft, 64), b = __shfl_up(pl, sft, 64);
+            if (lane >= sft) {
+                pu = pu < a ? pu : a;
+                pl = pl > b ? pl : b;
+            }
+        }
+        double cu = du, cl = dl;
+#pragma unroll
+        for (int k = 5; k >= 0; --k) {
+            const int step = 1 << k;
+            int src = pos < 63 ? pos : 63;
+            double xu = shfl_d(tu[k], src), xl = shfl_d(tl[k], src);
+            double nu = cu < xu ? cu : xu, nl = cl > xl ? cl : xl;
+            bool ok = (pos + step <= 64) && !(nu - nl < 0.0);
+            if (ok) {
+                cu = nu;
+                cl = nl;
+                pos += step;
+            }
+        }
+        out.cu = cu;
+        out.cl = cl;
+        out.pu = pu;
+        out.pl = pl;
     }
     // 2b. pointer doubling: the set of run heads reached from a start at this lane
-    unsigned long long M = 1ull << lane;
     int J = pos;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -275,7 +330,9 @@ __device__ __forceinline__ QChunk q_chunk(const uint8_t* __restrict__ o, const i
             J = Jj;
         }
     }
-    return QChunk{cu, cl, pu, pl, M, pos};  // nxt in [lane+1, 64]; 64 = the run leaves the chunk
+    out.heads = M;
+    out.nxt = pos;  // in [lane+1, 64]; 64 = the run leaves the chunk
+    return out;
 }
 
 __device__ __forceinline__ double q_rl_d(double v, int src) {  // src is wave-uniform
@@ -323,7 +380,8 @@ __global__ __launch_bounds__(64 * (QW + 1)) void k_q_heads(const uint8_t* __rest
         if (wv > 0 && r < nrounds) {
             const int ch = c0 + r * QW + (wv - 1);
             if (ch < c1) {
-                const QChunk q = q_chunk(o, d, c, ch, HW, qp, E, lane);
+                const QChunk q = qp.mode == TZ_MODE_PWREL ? q_chunk<true>(o, d, c, ch, HW, qp, E, lane)
+                                                          : q_chunk<false>(o, d, c, ch, HW, qp, E, lane);
                 QSlot& sl = slots[r & 1][wv - 1];
                 sl.cu[lane] = q.cu;
                 sl.cl[lane] = q.cl;
@@ -418,7 +476,8 @@ __global__ __launch_bounds__(64) void k_q_stitch(const uint8_t* __restrict__ ori
         if (c0 >= c1) break;
         bool merged = false;
         for (int ch = c0; ch < c1 && !merged; ++ch) {
-            const QChunk q = q_chunk(o, d, c, ch, HW, qp, E, lane);
+            const QChunk q = qp.mode == TZ_MODE_PWREL ? q_chunk<true>(o, d, c, ch, HW, qp, E, lane)
+                                                      : q_chunk<false>(o, d, c, ch, HW, qp, E, lane);
             const unsigned long long S = sp[ch];
             const double eu = u < q.pu ? u : q.pu, el = l > q.pl ? l : q.pl;
             const unsigned long long brk = __ballot(eu - el < 0.0);
