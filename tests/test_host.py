@@ -230,3 +230,109 @@ def test_hdf5_written_here_is_read_by_real_h5py(tmp_path):
     # and the built-in reader returns the same arrays from the same file
     _, back, _ = weights.load_model(str(tmp_path))
     assert all((a == b).all() for a, b in zip(w, back))
+
+
+def test_frame_source_streams_in_order_and_rejects_what_the_reference_rejects(tmp_path):
+    """compress.py:97-131 as a stream: windows of frames in sorted-name order through a ring of three
+    buffers, grayscale expanded to RGB, and the reference's messages for empty directories, non-image
+    files, other modes and mixed sizes."""
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    fr = rng.integers(0, 256, (11, 9, 14, 3)).astype(np.uint8)
+    d = tmp_path / "rgb"
+    d.mkdir()
+    for t in range(11):
+        Image.fromarray(fr[t]).save(d / ("f%02d.png" % (10 - t)))      # reversed names: order comes from sorted()
+    src = compress.FrameSource(str(d))
+    assert (src.nt, src.H, src.W, src.is_rgb) == (11, 9, 14, True) and src.files[0] == "f00.png"
+    with ThreadPoolExecutor(4) as pool:
+        seen = [(f0, v.copy()) for f0, v in src.chunks(4, pool)]
+    assert [f0 for f0, _ in seen] == [0, 4, 8] and [v.shape[0] for _, v in seen] == [4, 4, 3]
+    assert np.array_equal(np.concatenate([v for _, v in seen]), fr[::-1])
+    g = tmp_path / "gray"
+    g.mkdir()
+    for t in range(3):
+        Image.fromarray(fr[t, :, :, 0], mode="L").save(g / ("g%d.png" % t))
+    gs = compress.FrameSource(str(g))
+    with ThreadPoolExecutor(2) as pool:
+        got = np.concatenate([v.copy() for _, v in gs.chunks(2, pool)])
+    assert not gs.is_rgb and np.array_equal(got, np.repeat(fr[:3, :, :, :1], 3, axis=-1))   # compress.py:114
+
+    def messages(fn):
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            with pytest.raises(SystemExit):
+                fn()
+        return buf.getvalue()
+
+    assert "is an empty or non-existent directory" in messages(lambda: compress.FrameSource(str(tmp_path / "none")))
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    Image.fromarray(fr[0]).save(bad / "a.png")
+    (bad / "b.png").write_bytes(b"not an image")
+
+    def consume(path):
+        s = compress.FrameSource(str(path))
+        with ThreadPoolExecutor(2) as pool:
+            list(s.chunks(4, pool))
+    assert "contains files or folders that are not images" in messages(lambda: consume(bad))
+    mixed = tmp_path / "mixed"
+    mixed.mkdir()
+    Image.fromarray(fr[0]).save(mixed / "a.png")
+    Image.fromarray(fr[1][:5]).save(mixed / "b.png")
+    assert "contains files or folders that are not images" in messages(lambda: consume(mixed))
+    rgba = tmp_path / "rgba"
+    rgba.mkdir()
+    Image.fromarray(np.dstack([fr[0], fr[0][..., :1]]), mode="RGBA").save(rgba / "a.png")
+    assert "Only RGB and grayscale are supported" in messages(lambda: compress.FrameSource(str(rgba)))
+
+
+def test_zstd_streaming_frames_are_what_the_reference_reads(tmp_path):
+    """ZSTD_compressStream2 with a pledged size: ONE standard frame with the content size in its
+    header (the reference's zstd.decompress needs it), identical content, decodable piece by piece."""
+    a = (np.random.default_rng(1).integers(0, 30, 3_000_001)).astype(np.int16)
+    p = tmp_path / "s.zst"
+    with open(p, "wb") as f:
+        sc = zstd.StreamCompressor(f, a.nbytes, 9, 4)
+        for i in range(0, a.size, 700_000):
+            sc.write(a[i:i + 700_000])
+        n = sc.close()
+    blob = open(p, "rb").read()
+    assert n == len(blob) and blob[:4] == b"\x28\xb5\x2f\xfd" and zstd.content_size(blob[:32]) == a.nbytes
+    assert zstd.decompress(blob) == a.tobytes()
+    with open(p, "rb") as f:
+        pieces = [(size, bytes(piece)) for size, piece in zstd.stream_decompress(f, piece_bytes=1 << 20, read_bytes=1 << 16)]
+    assert all(s == a.nbytes for s, _ in pieces) and b"".join(x for _, x in pieces) == a.tobytes()
+    with pytest.raises(RuntimeError):
+        list(zstd.stream_decompress(io.BytesIO(blob[: len(blob) // 2])))
+    with open(tmp_path / "bad.zst", "wb") as f:
+        sc = zstd.StreamCompressor(f, 100, 9, 0)
+        sc.write(np.zeros(10, np.uint8))
+        with pytest.raises(RuntimeError):
+            sc.close()   # fewer bytes than pledged: libzstd refuses to end the frame
+
+
+def test_h5lite_writer_limits_and_dtypes(tmp_path):
+    from tezip_amd import h5lite
+    root = h5lite.Group({"note": b"x"})
+    g = root.group("g")
+    for i in range(2 * h5lite.LEAF_K + 1):
+        g.dataset("d%02d" % i, np.zeros(1, np.float32))
+    with pytest.raises(NotImplementedError):
+        h5lite.write_file(str(tmp_path / "big.h5"), root)
+    root = h5lite.Group()
+    root.dataset("u8", np.arange(6, dtype=np.uint8).reshape(2, 3), {"tag": b"bytes\x00inside"})
+    root.dataset("i4", np.array([-5, 7], np.int32))
+    root.dataset("f8", np.array([1.5, -2.25]))
+    root.dataset("s", np.array([b"ab", b"c"], dtype="S2"))
+    root.dataset("empty", np.zeros((0, 4), np.float32))
+    h5lite.write_file(str(tmp_path / "t.h5"), root)
+    back = h5lite.H5File(str(tmp_path / "t.h5")).walk()
+    assert back["/u8"].dtype == np.uint8 and back["/u8"].tolist() == [[0, 1, 2], [3, 4, 5]]
+    assert back["/i4"].tolist() == [-5, 7] and back["/f8"].tolist() == [1.5, -2.25]
+    assert back["/s"].tolist() == [b"ab", b"c"] and back["/empty"].shape == (0, 4)
+    with pytest.raises(NotImplementedError):
+        r2 = h5lite.Group()
+        r2.dataset("c", np.zeros(2, np.complex64))
+        h5lite.write_file(str(tmp_path / "c.h5"), r2)
