@@ -13,7 +13,8 @@ N>1    : one process per GPU.  `python bench.py --gpus N` starts the N ranks its
          (WORLD_SIZE set) it is one of the ranks.  The job is ONE sequence of 80*N frames whose
          windows are sharded over the ranks (tezip_amd/dist.py: no data-path collective; one small
          all_gather for the shard-boundary carries, an all-reduce of 2111 histogram counters, and
-         the payload shards sent point to point to rank 0) => weak scaling, 4 windows per GPU.
+         the payload shards sent point to point to rank 0, in flight while the next step rolls out; the
+         clock stops only after the last shards have landed) => weak scaling, 4 windows per GPU.
          The sharded result is checked byte-identical to a single-GPU run of the same sequence
          (untimed).  `--mode replicas` (every rank its own 80-frame sequence, nothing exchanged)
          is kept and is reported as an extra key of the same line.
@@ -206,14 +207,19 @@ class Job:
             self.dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(self, step, steps, warmup):
-        """W untimed + K timed steps between barrier + synchronize; MAX over ranks (seconds)."""
+    def timed(self, step, steps, warmup, drain=None):
+        """W untimed + K timed steps between barrier + synchronize; MAX over ranks (seconds).
+        drain: completes whatever the last step left in flight, inside the timed region."""
         for _ in range(warmup):
             step()
+        if drain:
+            drain()
         self.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        if drain:
+            drain()
         self.barrier()
         elapsed = time.perf_counter() - t0
         if self.dist:
@@ -234,10 +240,21 @@ def sharded_step_fn(job, ctx, engine, fetch, nt_total, warm_up, window, mode, bo
             _, table, _ = ctx.encode(mode, bound, True, payload=state["payload"])
             state["key"], state["table"] = key, table
     else:
+        # the payload shards of step k travel to rank 0 while step k + 1 rolls out (fresh output buffers
+        # every step); drain() lands the last ones before the clock stops
+        def drain():
+            p = state.pop("pending", None)
+            if p is not None:
+                res = p.wait()
+                if res is not None:
+                    state["payload"], state["table"], state["key"] = res
+
         def step():
-            res = tzdist.compress_sharded(engine, fetch, warm_up, window, mode, bound, True, nt=nt_total, to_host=False)
-            if res is not None:
-                state["payload"], state["table"], state["key"] = res
+            nxt = tzdist.compress_sharded(engine, fetch, warm_up, window, mode, bound, True, nt=nt_total, to_host=False,
+                                          wait=False)
+            drain()
+            state["pending"] = nxt
+        step.drain = drain
     return step
 
 
@@ -331,7 +348,7 @@ def main():
             key, _ = ctx.rollout(frames, WARM_UP, WINDOW)
             _, table, _ = ctx.encode(MODE, BOUND, True, payload=state["payload"])
             state["key"], state["table"] = key, table
-    elapsed = job.timed(step, args.steps, args.warmup)
+    elapsed = job.timed(step, args.steps, args.warmup, drain=getattr(step, "drain", None))
     total_frames = (nt_total if sharded else nt_rank * world) * args.steps
     value = total_frames / elapsed
 
@@ -524,7 +541,7 @@ def cfg4_sharded(job, ctx, engine, cfg, rank, world, dev):
 
     step = sharded_step_fn(job, ctx, engine, fetch, nt, 0, window, mode, bound, state)
     steps = 2
-    el = job.timed(step, steps, 1)
+    el = job.timed(step, steps, 1, drain=getattr(step, "drain", None))
     out = {"workload": "ONE 1024x1024x1(->3) detector sequence, 320 frames, SWP 40-frame windows, lossy abs 2, "
                        "windows sharded over %d rank(s)" % world,
            "frames_per_s": nt * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "scaling": "strong"}

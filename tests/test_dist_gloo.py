@@ -126,6 +126,17 @@ def _worker(rank, world, port, p, window, mode, bound, entropy):
             assert (table is None) == (ref_table is None) and (table is None or (table == ref_table).all())
         else:
             assert res is None
+        # pipelined form: two sequences in flight, the gather of the first behind the compute of the second
+        p1 = tzdist.compress_sharded(eng, frames, p, window, mode, bound, entropy, wait=False)
+        p2 = tzdist.compress_sharded(eng, frames[::-1].copy() if window > 1 else frames, p, window, mode, bound, entropy, wait=False)
+        r1, r2 = p1.wait(), p2.wait()
+        if rank == 0:
+            assert (r1[0] == ref_payload).all() and (r1[2] == ref["key"]).all()
+            if window > 1:
+                ref2 = O.compress_oracle(frames[::-1].copy(), p, window, None, mode, bound, pred, entropy)
+                assert (r2[0] == O.parse_stream(ref2["stream"])[0]).all()
+        else:
+            assert r1 is None and r2 is None
         key_stack = ref["key_frame"].reshape(frames.shape)
         dec = tzdist.decompress_sharded(eng, key_stack, ref_payload, ref_table, p)
         if rank == 0:

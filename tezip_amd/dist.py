@@ -201,18 +201,30 @@ def _comm_tensor(engine, buf, dev):
     return torch.from_numpy(np.ascontiguousarray(buf).reshape(-1).view(np.uint8))
 
 
-def _gather_shards(engine, buf, nbytes, dist, dst=0):
+class PendingGather:
+    """A point-to-point gather in flight: the requests plus every buffer they touch.  wait() returns
+    the assembled uint8 tensor on `dst` (None elsewhere)."""
+
+    def __init__(self, reqs, full, keep):
+        self.reqs, self.full, self.keep = reqs, full, keep
+
+    def wait(self):
+        for q in self.reqs:
+            q.wait()
+        self.reqs, self.keep = [], None
+        return self.full
+
+
+def _gather_shards_begin(engine, buf, nbytes, dist, dst=0):
     """Point-to-point gather of the per-rank byte shards (sizes `nbytes`, known to everyone from
     the shard plan) into one buffer on `dst`: peers send, `dst` receives each shard straight into
-    its slice.  Returns a uint8 tensor on the communication device (dst) / None (others)."""
+    its slice.  Returns a PendingGather: the transfers run behind whatever the caller does next."""
     import torch
     rank, dev = dist.get_rank(), _device(dist)
     mine = _comm_tensor(engine, buf, dev) if nbytes[rank] else None
     if rank != dst:
-        if nbytes[rank]:
-            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, dst)]):
-                q.wait()
-        return None
+        reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, dst)]) if nbytes[rank] else []
+        return PendingGather(reqs, None, mine)
     offs = np.concatenate([[0], np.cumsum(nbytes)]).astype(np.int64)
     full = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)
     # ONE group of receives: the shards arrive concurrently over their own xGMI links
@@ -221,9 +233,11 @@ def _gather_shards(engine, buf, nbytes, dist, dst=0):
     reqs = dist.batch_isend_irecv(ops) if ops else []
     if nbytes[rank]:
         full[int(offs[rank]): int(offs[rank + 1])].copy_(mine)
-    for q in reqs:
-        q.wait()
-    return full
+    return PendingGather(reqs, full, mine)
+
+
+def _gather_shards(engine, buf, nbytes, dist, dst=0):
+    return _gather_shards_begin(engine, buf, nbytes, dist, dst).wait()
 
 
 def _typed(full_u8, dtype, to_host):
@@ -242,12 +256,28 @@ def _raise_if_any_failed(oks, what):
         raise RuntimeError("%s failed on rank(s) %s (see that rank's log)" % (what, bad))
 
 
-def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True, nt=None, to_host=True):
+class PendingCompress:
+    """compress_sharded(..., wait=False): everything but the arrival of the payload shards on rank 0 is
+    done; wait() returns what compress_sharded returns."""
+
+    def __init__(self, gather, rank, table, keys, to_host):
+        self.gather, self.rank, self.table, self.keys, self.to_host = gather, rank, table, keys, to_host
+
+    def wait(self):
+        full = self.gather.wait()
+        if self.rank != 0:
+            return None
+        return _typed(full, np.int16, self.to_host), self.table, self.keys
+
+
+def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True, nt=None, to_host=True, wait=True):
     """Every rank passes the same arguments.  `frames` is the full (nt,H,W,3) stack (anything whose
     [f0:f1] slice yields frames) or, with `nt` given, a callable (f0, f1) -> this rank's frames
     (a rank then never sees the others' frames).  Returns (payload, table|None, key_mask) on rank
     0, None elsewhere; the payload is a numpy array (to_host) or stays in rank 0's HBM.  The result
-    is byte-identical to a single-GPU tz_rollout + tz_encode."""
+    is byte-identical to a single-GPU tz_rollout + tz_encode.  wait=False returns a PendingCompress
+    instead: the point-to-point gather is still in flight, so a caller that compresses one sequence
+    after the other overlaps it with the next rollout (outputs are fresh buffers every call)."""
     import torch
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -291,11 +321,10 @@ def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True,
         table = engine.build_table(h.cpu().numpy().astype(np.uint64))
         if f1 > f0:
             y = engine.remap(y, table)
-    full = _gather_shards(engine, y, [(b - a) * fe * 2 for a, b in shards], dist)
-    if rank != 0:
-        return None
+    gather = _gather_shards_begin(engine, y, [(b - a) * fe * 2 for a, b in shards], dist)
     keys = np.concatenate([np.asarray(i[4: 4 + (b - a)]) for i, (a, b) in zip(infos, shards)]).astype(bool)
-    return _typed(full, np.int16, to_host), table, keys
+    pending = PendingCompress(gather, rank, table, keys, to_host)
+    return pending.wait() if wait else pending
 
 
 def engine_last(engine, buf):
