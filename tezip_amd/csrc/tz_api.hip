@@ -457,6 +457,8 @@ struct DwpState {
     double run;    // squared-error sum of the open window
 };
 
+static constexpr int kDwpLds = 2048;  // partial sums staged per pass of k_dwp_decide (16 KB)
+
 __global__ void k_dwp_init(DwpState* st, int p, int nt, int* idx_table, int stride, uint8_t* key) {
     st->key_idx = p + 1;
     st->run = 0.0;
@@ -471,13 +473,19 @@ __global__ void k_dwp_init(DwpState* st, int p, int nt, int* idx_table, int stri
 __global__ void k_dwp_decide(DwpState* st, const double* __restrict__ part, int nblk, int idx, int nt, double fe_pad,
                              double threshold, int* idx_table, int stride, uint8_t* key, uint8_t* gfirst, double* mse,
                              int* c0_flag) {
-    // all lanes fetch the partials at once (one memory round trip), lane 0 adds them in order
-    extern __shared__ double s_part[];
-    for (int b = threadIdx.x; b < nblk; b += blockDim.x) s_part[b] = part[b];
-    __syncthreads();
-    if (threadIdx.x != 0) return;
+    // all lanes fetch the partials at once (one memory round trip per kDwpLds of them), lane 0 adds
+    // them in order
+    __shared__ double s_part[kDwpLds];
     double t = 0.0;
-    for (int b = 0; b < nblk; ++b) t = t + s_part[b];
+    for (int b0 = 0; b0 < nblk; b0 += kDwpLds) {
+        const int nb = min(kDwpLds, nblk - b0);
+        __syncthreads();
+        for (int b = threadIdx.x; b < nb; b += blockDim.x) s_part[b] = part[b0 + b];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int b = 0; b < nb; ++b) t = t + s_part[b];
+    }
+    if (threadIdx.x != 0) return;
     int key_idx = st->key_idx;
     double run = st->run + t;
     const double stop = run / ((double)(idx - key_idx + 1) * fe_pad);   // compress.py:246
@@ -832,7 +840,7 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
             rc = tzk_sse_launch(ctx, ctx->d_frames + (size_t)idx * H * W * 3, ctx->d_pred + (size_t)idx * fe_pad, 1, H, W,
                                 ctx->Hp, ctx->Wp, (double*)d_part);
             if (rc != TZ_OK) break;
-            hipLaunchKernelGGL(k_dwp_decide, dim3(1), dim3(256), sizeof(double) * nblk, ctx->stream, (DwpState*)d_state, (const double*)d_part, nblk,
+            hipLaunchKernelGGL(k_dwp_decide, dim3(1), dim3(256), 0, ctx->stream, (DwpState*)d_state, (const double*)d_part, nblk,
                                idx, nt, (double)fe_pad, threshold, ctx->d_sched, maxB, (uint8_t*)d_key, (uint8_t*)d_gf,
                                (double*)d_mse, (int*)d_flag);
             // slot 0 of the new group holds C0 (258); the last frame keeps its prediction (260-262)
@@ -851,6 +859,10 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
     }
     for (int i = 0; i < nt; ++i)
         if (gfirst[i]) qskip[i] = 1;
+    if (rc != TZ_OK) {  // nothing of a failed rollout may still read the caller's frames when we return
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        ctx->pending_src = nullptr;
+    }
     if (rc == TZ_OK) {
         ctx->key_mask = key;
         ctx->group_first = gfirst;
