@@ -201,3 +201,41 @@ def test_host_memory_does_not_grow_with_the_number_of_frames(tmp_path):
     decompress.run(mdir, str(tmp_path / "comp256"), str(tmp_path / "out"), True, False)
     got = np.stack([np.array(Image.open(os.path.join(str(tmp_path / "out"), "frame_%03d.png" % t))) for t in (0, 100, 255)])
     assert np.array_equal(got, frames[[0, 100, 255]])
+
+
+def test_streaming_decompress_rejects_damaged_files(tmp_path):
+    """decompress.run reads both files piece by piece straight into HBM; a truncated zstd frame, an
+    entropy.dat whose trailer does not fit its payload and a key_frame.dat of another size must raise
+    (the reference fails at its reshapes, decompress.py:115,240) -- before any kernel sees them."""
+    cfg = PredNetConfig(stack_sizes=(3, 16, 32))
+    nt, h, w = 9, 24, 40
+    frames = synth.translating_scene(nt, h, w, seed=8)
+    mdir = str(tmp_path / "model")
+    weights.save_model(mdir, cfg, cfg.init_weights(seed=8, bias_scale=0.1), 24, 40)
+    ddir = _write(tmp_path, frames, False)
+    good = str(tmp_path / "good")
+    compress.run(mdir, ddir, good, 0, 4, None, "abs", [0.0], True, False, True)
+    names = ("entropy.dat", "filename.txt", "key_frame.dat")
+
+    def variant(name, **repl):
+        d = tmp_path / name
+        d.mkdir()
+        for n in names:
+            data = open(os.path.join(good, n), "rb").read()
+            (d / n).write_bytes(repl.get(n, data))
+        return str(d)
+
+    ent = open(os.path.join(good, "entropy.dat"), "rb").read()
+    key = open(os.path.join(good, "key_frame.dat"), "rb").read()
+    stream = np.frombuffer(zstd.decompress(ent), "<i2")
+    cases = {
+        "cut_zstd": {"entropy.dat": ent[: len(ent) // 2]},
+        "short_payload": {"entropy.dat": zstd.compress_array(np.ascontiguousarray(stream[40:]), 9)},
+        "one_channel": {"entropy.dat": zstd.compress_array(np.concatenate([stream[:-2], [1, stream[-1]]]).astype("<i2"), 9)},
+        "other_key_size": {"key_frame.dat": zstd.compress_array(np.zeros(nt * h * w * 3 - 3, np.uint8), 9)},
+        "cut_key": {"key_frame.dat": key[: len(key) // 2]},
+    }
+    for name, repl in cases.items():
+        with pytest.raises((ValueError, RuntimeError)):
+            decompress.run(mdir, variant(name, **repl), str(tmp_path / ("out_" + name)), True, False)
+    decompress.run(mdir, good, str(tmp_path / "out_good"), True, False)   # the context is still usable afterwards

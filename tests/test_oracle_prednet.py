@@ -39,7 +39,7 @@ def test_c_oracle_matches_numpy_restatement(cfg, hp, wp):
     np.testing.assert_array_equal(o1, net.next(f))
 
 
-@pytest.mark.parametrize("cfg,hp,wp,seed", [(SMALL, 24, 16, 9), (CFG, 16, 16, 10)])
+@pytest.mark.parametrize("cfg,hp,wp,seed", [(SMALL, 24, 16, 9), (CFG, 16, 16, 10), (CFG, 64, 96, 11)])
 def test_c_oracle_matches_torch_restatement(cfg, hp, wp, seed):
     """oracle/prednet_torch.py evaluates the LITERAL graph: two timesteps from zero state, the
     upsampled tensor materialised and convolved with the full 3x3 kernel on the concatenated input.
