@@ -5,6 +5,7 @@
 // in tz_prednet.hip), so they are interchangeable bit for bit:
 //   k_conv16     sources with a multiple of 16 channels: all staging by LDS-DMA (levels >= 1)
 //   k_conv16b    the level-0 convolutions as block steps (6-channel source stored 8 wide)
+//   k_convlat    the k_conv16 convolutions for grids that cannot fill the chip: one accumulator tile per wave
 //   k_conv_small the 3 -> 3 prediction convolution as a direct VALU kernel
 //   k_conv3x3    the general kernel (any channel count, register-staged): prepare-time work,
 //                other model shapes, and the tz_set_conv_impl(0) cross-check
