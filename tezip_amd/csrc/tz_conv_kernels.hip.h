@@ -998,6 +998,7 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
                     for (int kk = 0; kk < 4; ++kk) fan[m][kk] = fa[m][kk];
 #pragma unroll
                 for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][0], w[0], acc[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);   // (else hipcc hoists the reads below above this MFMA and waits for them in front of it)
                 // the next slot's operands first: their LDS latency hides behind the rest of the chain.
                 // Slot t + 1 has landed when at most the LAT_D - 3 DMAs issued after it are outstanding
                 // (this slot's own DMA is issued below)
@@ -1023,6 +1024,7 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][3], w[3], acc[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (more) {
                     lds_wait(wn);
                     w = wn;
