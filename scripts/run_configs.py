@@ -15,7 +15,7 @@ from tezip_amd import _lib, synth  # noqa: E402
 from tezip_amd.prednet import PredNetConfig  # noqa: E402
 
 
-def run(name, frames, p, window, thr, mode, bound, max_batch, repeat=2):
+def run(name, frames, p, window, thr, mode, bound, max_batch, repeat=3):
     nt, h, w = frames.shape[:3]
     cfg = PredNetConfig()
     ctx = _lib.Context(0)
