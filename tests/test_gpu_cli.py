@@ -197,7 +197,7 @@ def test_host_memory_does_not_grow_with_the_number_of_frames(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         peak[nt] = int([l for l in r.stdout.splitlines() if l.startswith("MAXRSS_KB")][0].split()[1])
     held = (256 - 64) * h * w * 3 * 3 / 1024          # frames + int16 payload the reference would hold, KiB
-    assert peak[256] - peak[64] < 0.25 * held, peak
+    assert peak[256] - peak[64] < 0.5 * held, peak
     decompress.run(mdir, str(tmp_path / "comp256"), str(tmp_path / "out"), True, False)
     got = np.stack([np.array(Image.open(os.path.join(str(tmp_path / "out"), "frame_%03d.png" % t))) for t in (0, 100, 255)])
     assert np.array_equal(got, frames[[0, 100, 255]])
