@@ -770,12 +770,11 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
 //   an upsampled source depend on the parity class);
 //   B fragments never touch LDS: the weights are packed a third time, per (slot, column block,
 //   column tile) as [lane][k-step], so a lane's four k-steps of a slot are ONE 16-byte global load,
-//   prefetched LAT_D slots ahead in registers (nothing is shared between waves, hence no barrier);
-//   A fragments come from a halo patch in LDS (6x6 / 10x10 pixels x 16 channels per block,
-//   channels stored [element][k-step] so that a lane's four k-steps are one ds_read_b128), staged one
-//   block ahead through registers, one barrier per 16-channel block.
+//   prefetched one block (9 or 4 slots) ahead in registers (nothing is shared between waves);
+//   A fragments come from a halo patch in LDS (6x6 / 10x10 pixels x 16 channels per block, quad-planar),
+//   staged one block ahead by LDS-DMA, one barrier per 16-channel block.
 // Per slot a wave issues 4 dependent MFMAs (the chain), i.e. the K loop runs at the latency of the
-// matrix pipe: 3456/4 k-steps x ~36 cycles = 13 us for the top level instead of 234.
+// matrix pipe: 32 cycles per MFMA measured (scripts/microbench/mfma_chain.hip), 54 ns per slot at best.
 template <int N>
 __device__ __forceinline__ void wait_vmn() {
     static_assert(N == 0 || N == 4 || N == 5 || N == 6 || N == 7 || N == 9 || N == 13 || N == 14 || N == 15, "immediate of s_waitcnt");
@@ -800,6 +799,27 @@ __device__ __forceinline__ f32x4 lds_read16_opaque(const float* p) {   // issue 
     return v;
 }
 __device__ __forceinline__ void lds_wait(f32x4& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory"); }
+// LDS-DMA hipcc does not see as one: global_load_lds is a FLAT instruction that touches both memories, and
+// with one outstanding every later wait for an ordinary load becomes vmcnt(0) (no in-order assumption),
+// which would drain k_convlat's register ring at each block.  Unseen, it only makes hipcc's own
+// vmcnt(N) wait for more than it has to (N counts the loads it knows; ours are extra).
+__device__ __forceinline__ void glds16_opaque(const float* g, const float* l) {   // l: wave-uniform
+    const unsigned la = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)l;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory");   // (m0 is reserved: hipcc sets it in front of each of its own uses)
+}
+// two floats O0 and O1 x 64 dwords behind a byte address, same reason
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int O0, int O1>
+__device__ __forceinline__ f32x2 lds_read2st64_opaque(unsigned addr) {
+    static_assert(O0 >= 0 && O1 < 256, "8-bit offsets");
+    f32x2 v;
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
+__device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b, f32x2& c, f32x2& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
 
 template <int MAP>
 __device__ __forceinline__ void lat_row_to_pixel(int r, int pc, int& py, int& px) {
@@ -816,14 +836,11 @@ __device__ __forceinline__ void lat_row_to_pixel(int r, int pc, int& py, int& px
     }
 }
 
-// LAT_D = weight ring entries per wave (the DMA of a slot is issued LAT_D - 1 slots before its use, the
-// slot after the current one is already being read from the ring): 16 for grids of at most one
-// workgroup per CU, 8 where several workgroups must share a CU.
 // MTL = accumulator tiles per wave: 1 = 16 pixels per workgroup (the latency-bound case: as many SIMDs
 // as possible), 2 = 32 pixels (two tiles side by side, two independent MFMA chains interleaved: for
 // grids of several rounds, where the matrix pipe rather than the chain latency is the limit and
 // half as many workgroups stream the weights).
-template <int EPI, bool UPS, int LAT_D, int MTL>
+template <int EPI, bool UPS, int MTL>
 __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
     constexpr int TS = MAP == MAP_PARITY ? 8 : 4;      // footprint of one accumulator tile in pixels
@@ -840,8 +857,7 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     constexpr int PCS = NPS * 4 / 64, PCU = NPU * 4 / 64;   // 1 KB pieces (= DMA wave-instructions) per patch
     constexpr int NPI = (PCS + 3) / 4;                 // patch DMA instructions per wave
     static_assert(PCU <= PCS, "the half-resolution patch fits the same buffers");
-    // LDS: per-wave weight rings (LAT_D x 1 KB each), two patch buffers, the gate exchange of the LSTM epilogue
-    __shared__ __attribute__((aligned(16))) float sW[4 * LAT_D * 256];
+    // LDS: two patch buffers, the gate exchange of the LSTM epilogue
     __shared__ __attribute__((aligned(16))) float sP[2][PCS * 256];
     __shared__ float sE[EPI == EPI_LSTM ? 4 * 16 * MTL * 17 : 1];
 
@@ -890,7 +906,7 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
                 if (slot < PPL && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
                     src = base + ((long long)yy * a.W + xx) * s.pstride + c0 + 4 * q;
             }
-            glds16(src, sP[buf] + piece * 256);
+            glds16_opaque(src, sP[buf] + piece * 256);
         }
     };
 
@@ -929,36 +945,39 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
         abase_lo[m] = (((py >> 1) + (py & 1)) * LWL + (px >> 1) + (px & 1)) * 4 + g;
     }
     const long long wstride = (long long)a.ncb * 1024;                                 // floats between slots of Wlat
-    const float* wlane = a.Wlat + ((long long)cb * 4 + (active ? wv : 0)) * 256 + lane * 4;
-    float* wring = sW + wv * (LAT_D * 256);
+    const float* wbase = a.Wlat + ((long long)cb * 4 + wv) * 256;                      // wave-uniform
+    const unsigned wlane = lane * 16;                                                  // bytes
+    auto ldw = [&](const float* u) { return *(const f32x4*)((const char*)u + wlane); };
 
-    // The K loop: per slot (16 channels x one tap) the wave reads its four B k-steps (one
-    // ds_read_b128 of its private ring entry) and four A values per tile (patch), issues the DMA of the
-    // slot LAT_D - 1 ahead into the entry it consumed last, and runs 4 dependent MFMAs per tile.  All
-    // memory traffic is LDS-DMA, so the waits are explicit: DMAs of a wave complete in order, hence
-    // vmcnt(N) with N = the number of DMAs known to be younger than the one needed (younger patch DMAs
-    // only make the wait longer); a patch, issued one block ahead of that block's SPB weight slots, has
-    // landed at vmcnt(SPB).  One barrier per 16-channel block (the patch is shared by the 4 waves).
+    // The K loop: per slot (16 channels x one tap) the wave takes its four B k-steps from a REGISTER ring
+    // (one global_load_dwordx4 per slot, issued one block = SPB slots ahead into the entry the slot just
+    // consumed; hipcc counts those loads itself) and four A values per tile from the patch, and runs 4
+    // dependent MFMAs per tile.  The patch travels by LDS-DMA, whose waits are explicit: memory operations
+    // of a wave complete in order, so a patch issued at the start of a block, in front of that block's SPB
+    // weight loads, has landed at vmcnt(SPB).  One barrier per 16-channel block (the patch is shared by
+    // the 4 waves).  Why registers: scripts/microbench/lat_slot2.hip -- with ONE wave per SIMD every memory
+    // instruction between the MFMAs of the chain costs the wave 15-70 cycles that nothing overlaps; a ring
+    // in LDS (DMA + ds_read_b128 per slot, the first version) ran at 142 ns per slot, this one at ~90.
     int slot0 = 0;
-    static_assert((LAT_D & (LAT_D - 1)) == 0, "ring indices wrap by masking");
     auto run_phase = [&](auto upc, int b0, int b1) {
         constexpr bool UP = decltype(upc)::value;
         constexpr int SPB = UP ? 4 : 9;                   // slots this wave uses per block
         if (b0 >= b1) return;
-        const int T = (b1 - b0) * SPB;
         // weights of step t: same resolution slot0 + t; upsampled slot0 + 16 (t >> 2) + 4 (t & 3) + class = slot0 + pc + 4 t
         const long long wstep = (UP ? 4 : 1) * wstride;
-        const float* wptr = wlane + (long long)(slot0 + (UP ? pc : 0)) * wstride;   // next slot to fetch
+        const float* wblk = wbase + (long long)(slot0 + (UP ? pc : 0)) * wstride;   // first slot of the current block
         __syncthreads();                                  // every wave is done with the previous phase's patches
         issue_patch(b0, 0, UP);
-        if (active)
-            for (int j = 0; j < LAT_D - 1 && j < T; ++j, wptr += wstep) glds16(wptr, wring + j * 256);
-        // the patch is older than those LAT_D - 1 weight slots (a wave without a column tile -- NT = 3 --
-        // has issued nothing but its part of the patch)
-        if (active && T >= LAT_D - 1) wait_vmn<LAT_D - 1>();
-        else wait_vmn<0>();
+        f32x4 wr[SPB];
+        if (active) {
+#pragma unroll
+            for (int st = 0; st < SPB; ++st) wr[st] = ldw(wblk + st * wstep);
+            wait_vmn<SPB>();
+        } else {  // a wave without a column tile (NT = 3) has issued nothing but its part of the patches
+            wait_vmn<0>();
+        }
         __syncthreads();
-        int buf = 0, tb = 0, rb = 0;
+        int buf = 0;
         // slot offset of a tap.  Parity tile: its columns are stored evens first, so one step in x is
         // +PWL/2 from an even column and 1 - PWL/2 from an odd one, two steps are +1 (the class is uniform)
         auto t_off = [&](int st) {
@@ -968,70 +987,57 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
             return (dy * PWL + xo) * 4;
         };
         constexpr int KOFF = 4 * (UP ? NPU : NPS);         // floats between the quad planes
-        // One block = SPB slots.  The MFMAs of a slot form one dependent chain per tile (40 cycles per
-        // link); the ring read and the patch reads of the NEXT slot and the DMA of the slot LAT_D - 1 ahead
-        // are placed between them (sched barriers keep them there) so that nothing but the chain is on
-        // the wave's critical path.  STEADY: every slot of the block still has a slot to prefetch.
-        auto block = [&](auto steady) {
-            constexpr bool STEADY = decltype(steady)::value;
-            const float* pa = sP[buf];
-            if (STEADY || tb + LAT_D - 2 < T) wait_vmn<LAT_D - 2>();   // the block's first slot has landed
-            else wait_vmn<0>();
-            f32x4 w = lds_read16_opaque(wring + rb * 256 + lane * 4);
-            float fa[MTL][4];
+        // One block = SPB slots.  The MFMAs of a slot form one dependent chain per tile (32 cycles per link);
+        // the patch reads of the NEXT slot sit behind the first MFMA and the reload of the ring entry
+        // behind the last (sched barriers keep them there).
+        auto block = [&](const float* wnext) {
+            // the patch is read by instructions hipcc does not see as LDS reads: in front of one it knows
+            // it waits for EVERY outstanding LDS-DMA (vmcnt(0): the next block's patch and with it the
+            // whole weight ring); the explicit vmcnt(SPB) in front of the barrier is the exact condition
+            const unsigned pa = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)sP[buf];
+            static_assert(KOFF % 64 == 0 && 3 * KOFF / 64 < 256, "the four k-steps of a lane are two ds_read2st64_b32");
+            auto read_a = [&](int st, f32x2 (&f)[MTL][2]) {
 #pragma unroll
-            for (int m = 0; m < MTL; ++m)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) fa[m][kk] = pa[(UP ? abase_lo[m] : abase[m]) + t_off(0) + KOFF * kk];
-            lds_wait(w);
+                for (int m = 0; m < MTL; ++m) {
+                    const unsigned ad = pa + 4 * ((UP ? abase_lo[m] : abase[m]) + t_off(st));
+                    f[m][0] = lds_read2st64_opaque<0, KOFF / 64>(ad);
+                    f[m][1] = lds_read2st64_opaque<2 * KOFF / 64, 3 * KOFF / 64>(ad);
+                }
+            };
+            auto wait_a = [&](f32x2 (&f)[MTL][2]) {
+                if constexpr (MTL == 1) lds_wait(f[0][0], f[0][1]);
+                else lds_wait(f[0][0], f[0][1], f[1][0], f[1][1]);
+            };
+            f32x2 fa[MTL][2];
+            read_a(0, fa);
+            wait_a(fa);
 #pragma unroll
             for (int st = 0; st < SPB; ++st) {
-                const int r = (rb + st) & (LAT_D - 1);
-                const int rp = (r + LAT_D - 1) & (LAT_D - 1);          // the entry consumed by the previous slot
-                const int rn = (r + 1) & (LAT_D - 1);
                 const bool more = st + 1 < SPB;
-                f32x4 wn = w;
-                float fan[MTL][4];
+                const f32x4 w = wr[st];
+                f32x2 fan[MTL][2];
 #pragma unroll
-                for (int m = 0; m < MTL; ++m)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) fan[m][kk] = fa[m][kk];
-#pragma unroll
-                for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][0], w[0], acc[m], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);   // (else hipcc hoists the reads below above this MFMA and waits for them in front of it)
-                // the next slot's operands first: their LDS latency hides behind the rest of the chain.
-                // Slot t + 1 has landed when at most the LAT_D - 3 DMAs issued after it are outstanding
-                // (this slot's own DMA is issued below)
-                if (more) {
-                    if (STEADY || tb + st + LAT_D - 2 < T) wait_vmn<LAT_D - 3>();
-                    else wait_vmn<0>();
-                    wn = lds_read16_opaque(wring + rn * 256 + lane * 4);
-#pragma unroll
-                    for (int m = 0; m < MTL; ++m)
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) fan[m][kk] = pa[(UP ? abase_lo[m] : abase[m]) + t_off(st + 1) + KOFF * kk];
-                }
+                for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][0][0], w[0], acc[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) read_a(st + 1, fan);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][1], w[1], acc[m], 0, 0, 0);
-                if (STEADY || tb + st + LAT_D - 1 < T) {
-                    glds16(wptr, wring + rp * 256);
-                    wptr += wstep;
-                }
+                for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][0][1], w[1], acc[m], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][2], w[2], acc[m], 0, 0, 0);
+                for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][1][0], w[2], acc[m], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][3], w[3], acc[m], 0, 0, 0);
+                for (int m = 0; m < MTL; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][1][1], w[3], acc[m], 0, 0, 0);
+                wr[st] = ldw(wnext + st * wstep);    // the same slot of the next block (of this one again at the end: never used)
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
-                    lds_wait(wn);
-                    w = wn;
+                    wait_a(fan);
 #pragma unroll
-                    for (int m = 0; m < MTL; ++m)
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) fa[m][kk] = fan[m][kk];
+                    for (int m = 0; m < MTL; ++m) {
+                        fa[m][0] = fan[m][0];
+                        fa[m][1] = fan[m][1];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1039,18 +1045,16 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
 #pragma unroll 1
         for (int blk = b0; blk < b1; ++blk) {
             if (blk > b0) {
-                if (active && tb + LAT_D - 2 < T) wait_vmn<SPB>();  // all SPB slots of the previous block issued a DMA behind the patch
+                if (active) wait_vmn<SPB>();   // the SPB reloads of the previous block were issued behind this block's patch
                 else wait_vmn<0>();
                 __syncthreads();
                 buf ^= 1;
             }
-            if (blk + 1 < b1) issue_patch(blk + 1, buf ^ 1, UP);
-            if (active) {
-                if (tb + SPB - 1 + LAT_D - 1 < T) block(std::true_type{});
-                else block(std::false_type{});
-            }
-            tb += SPB;
-            rb = (rb + SPB) & (LAT_D - 1);
+            const bool last = blk + 1 == b1;
+            if (!last) issue_patch(blk + 1, buf ^ 1, UP);
+            const float* wnext = wblk + (last ? 0 : SPB * wstep);
+            if (active) block(wnext);
+            wblk = wnext;
         }
         slot0 += (b1 - b0) * (UP ? 16 : 9);
     };

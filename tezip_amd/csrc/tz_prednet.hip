@@ -299,10 +299,11 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
     }
     // grids that cannot fill the chip: one accumulator tile per wave (k_convlat), see the kernel's header.
     // Which kernel is faster is decided by a small cost model fitted to per-launch measurements on the
-    // MI355X (profiles/r02/small_grid.txt): k_conv16 costs about 1.08 us per 16-channel x tap slot for
-    // every workgroup a CU has to run (its K loop is a serial chain of 32-MFMA steps); k_convlat about
-    // 0.15 us per slot when every workgroup has a CU to itself (<= 256 workgroups of 16 pixels, ring of
-    // 16), 0.25-0.28 us per slot and round of 768 beyond that (ring of 8, three workgroups per CU).
+    // MI355X (profiles/r02/small_grid/): k_conv16 costs about 1.08 us per 16-channel x tap slot for
+    // every workgroup a CU has to run (its K loop is a serial chain of 32-MFMA steps); k_convlat 0.105 us
+    // per slot while the chain latency bounds it (one workgroup of 16 pixels per CU), 0.078 us per slot and
+    // workgroup of a CU once the matrix pipe does (0.143 for the 32-pixel workgroups), upsampled sources
+    // about a tenth more (4-slot blocks: a barrier per 4 slots instead of 9), plus 2.5 us per launch.
     if (a.Wlat && a.nsrc > 0 && fullk && ctx->conv_impl && ctx->lat_mode && (NT == 3 || NT == 4) &&
         (epi == EPI_POOL_ERR || (epi == EPI_LSTM && NT == 4))) {
         const int ts_ = (epi != EPI_POOL_ERR && ups) ? 8 : 4;
@@ -310,27 +311,23 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         const long long rows_ = (a.H + ts_ - 1) / ts_ * (ts_ == 8 ? 4 : 1);
         const long long wglat1 = (long long)a.ncb * ((a.W + ts_ - 1) / ts_) * rows_ * nbatch;          // 16 pixels per workgroup
         const long long wglat2 = (long long)a.ncb * ((a.W + 2 * ts_ - 1) / (2 * ts_)) * rows_ * nbatch;  // 32 pixels
-        // 32-pixel workgroups (two accumulator chains per wave) only pay where even they run many rounds:
-        // measured at 512x512, B = 1 (profiles/r02/small_grid): 191 / 97 us against 220 / 108 with 16 pixels,
-        // but 98 / 149 us against 84 / 127 on cfg2's grids -- LDS traffic (every wave re-reads the A
-        // fragments, the weights pass through the ring), not the matrix pipe, bounds several workgroups
-        // per CU
-        const bool wide = wglat1 > 2560;
+        // 32-pixel workgroups (two accumulator chains per wave, half as many workgroups streaming the weights)
+        // pay where the matrix pipe is the limit: 178 / 92 us against 191 / 99 with 16 pixels at 512x512, B = 1
+        static const long long wide_min = getenv("TEZIP_LAT_WIDE_MIN") ? atoll(getenv("TEZIP_LAT_WIDE_MIN")) : 2560;  // diagnostic
+        const bool wide = wglat1 > wide_min;
         int slots = 0;
         for (int s = 0; s < a.nsrc; ++s) slots += a.src[s].cpt * (a.src[s].up ? 4 : 9);
         const double t16 = slots * 1.08 * (double)((wg16 + 255) / 256);
-        const double tlat = wide ? (slots * 0.30 + 2.5) * (double)((wglat2 + 511) / 512)
-                                 : (wglat1 <= 256 ? slots * 0.15 + 2.5
-                                                  : (slots * (ts_ == 8 ? 0.28 : 0.25) + 2.5) * (double)((wglat1 + 767) / 768));
+        const double per_slot = wide ? 0.143 * (double)((wglat2 + 255) / 256) : std::max(0.105, 0.078 * (double)((wglat1 + 255) / 256));
+        const double tlat = slots * per_slot * (ts_ == 8 ? 1.1 : 1.0) + 2.5;
         const bool use_lat = wg16 <= 768 && (ctx->lat_mode == 2 || tlat < 0.9 * t16);
         if (!use_lat) goto no_lat;
         const int blocks = (int)(wide ? wglat2 : wglat1);
         ps.sub = TZP_CONVLAT;
 #define TZ_LAT(e, u)                                                                                          \
     do {                                                                                                      \
-        if (wide) hipLaunchKernelGGL((k_convlat<e, u, 8, 2>), dim3(blocks), dim3(256), 0, ctx->stream, a);    \
-        else if (blocks <= 256) hipLaunchKernelGGL((k_convlat<e, u, 16, 1>), dim3(blocks), dim3(256), 0, ctx->stream, a); \
-        else hipLaunchKernelGGL((k_convlat<e, u, 8, 1>), dim3(blocks), dim3(256), 0, ctx->stream, a);         \
+        if (wide) hipLaunchKernelGGL((k_convlat<e, u, 2>), dim3(blocks), dim3(256), 0, ctx->stream, a);       \
+        else hipLaunchKernelGGL((k_convlat<e, u, 1>), dim3(blocks), dim3(256), 0, ctx->stream, a);            \
     } while (0)
         if (epi == EPI_LSTM && ups) TZ_LAT(EPI_LSTM, true);
         else if (epi == EPI_LSTM) TZ_LAT(EPI_LSTM, false);
