@@ -22,22 +22,30 @@ def run(name, frames, p, window, thr, mode, bound, max_batch, repeat=3):
     ctx.load_model(cfg, cfg.init_weights(seed=123))
     ctx.prepare(_lib.pad8(h), _lib.pad8(w), max_batch)
     enc = dec = 1e9
+    parts = None
     for _ in range(repeat):
         t0 = time.perf_counter()
         key, _ = ctx.rollout(frames, p, window, thr)
+        t1 = time.perf_counter()
         payload, table, _ = ctx.encode(mode, bound, True)
-        enc = min(enc, time.perf_counter() - t0)
+        t2 = time.perf_counter()
+        if t2 - t0 < enc:
+            enc, parts = t2 - t0, [t1 - t0, t2 - t1]
     key_stack = np.zeros_like(frames)
     key_stack[key] = frames[key]
     for _ in range(repeat):
         t0 = time.perf_counter()
         ctx.rollout_decode(key_stack, p)
+        t1 = time.perf_counter()
         out = ctx.decode(payload, table)
-        dec = min(dec, time.perf_counter() - t0)
+        t2 = time.perf_counter()
+        if t2 - t0 < dec:
+            dec, dparts = t2 - t0, [t1 - t0, t2 - t1]
     err = int(np.abs(out.astype(np.int16) - frames.astype(np.int16)).max())
     ctx.close()
     row = dict(config=name, frames=nt, size="%dx%d" % (h, w), keys=int(key.sum()), compress_fps=nt / enc,
-               decompress_fps=nt / dec, max_abs_err=err, table=len(table))
+               decompress_fps=nt / dec, max_abs_err=err, table=len(table),
+               ms=[round(1e3 * v, 2) for v in parts + dparts])  # rollout, encode, rollout_decode, decode
     print(json.dumps(row), flush=True)
     return row
 
@@ -50,7 +58,7 @@ def main():
     rows.append(run("cfg3 512x512 turbulence, w=20, rel 1e-3", f3, 0, 20, None, "rel", [1e-3], 4))
     rows.append(run("cfg3b 512x512 turbulence, w=20, abs 2", f3, 0, 20, None, "abs", [2.0], 4))
     rows.append(run("cfg4 1024x1024 detector, w=40, abs 2 (one GPU share: 2 windows)", synth.detector(80, 1024, 1024), 0, 40,
-                    None, "abs", [2.0], 2, repeat=1))
+                    None, "abs", [2.0], 2, repeat=2))
     # cfg5: DWP with a threshold inside the observed MSE range + an SWP sweep point
     ctx = _lib.Context(0)
     cfg = PredNetConfig()
@@ -59,8 +67,8 @@ def main():
     _, mse = ctx.rollout(f3[:40], 0, None, 1e9, want_mse=True)
     ctx.close()
     thr = float(np.sort(mse[1:])[10])
-    rows.append(run("cfg5 512x512 DWP -t %.4g, lossless" % thr, f3, 0, None, thr, "abs", [0.0], 1, repeat=1))
-    rows.append(run("cfg5 512x512 SWP w=5 (sweep point), lossless", f3, 0, 5, None, "abs", [0.0], 16, repeat=1))
+    rows.append(run("cfg5 512x512 DWP -t %.4g, lossless" % thr, f3, 0, None, thr, "abs", [0.0], 1, repeat=2))
+    rows.append(run("cfg5 512x512 SWP w=5 (sweep point), lossless", f3, 0, 5, None, "abs", [0.0], 16, repeat=2))
     print("| config | frames | keys | compress frames/s | decompress frames/s | max abs err |")
     print("|---|---|---|---|---|---|")
     for r in rows:

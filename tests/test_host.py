@@ -336,3 +336,31 @@ def test_h5lite_writer_limits_and_dtypes(tmp_path):
         r2 = h5lite.Group()
         r2.dataset("c", np.zeros(2, np.complex64))
         h5lite.write_file(str(tmp_path / "c.h5"), r2)
+
+
+def test_result_pool_recycles_blocks():
+    """_lib._ResultPool: big results come from recycled host blocks (no page faults on the second call);
+    a block returns when the last view of it is dropped, never while a view is alive."""
+    from tezip_amd import _lib
+    pool = _lib._ResultPool()
+    a = pool.empty((3, 1 << 20), np.int16)
+    assert a.shape == (3, 1 << 20) and a.dtype == np.int16 and not pool.free
+    a[...] = 7
+    view, addr = a[1], a.ctypes.data
+    del a
+    assert not pool.free and (view == 7).all()       # the view keeps the block out of the pool
+    del view
+    assert len(pool.free) == 1
+    b = pool.empty(5 << 20, np.uint8)                # 5 MB fits the 6 MB block (at most twice the size asked for)
+    assert b.ctypes.data == addr and not pool.free
+    c = pool.empty(1 << 20, np.uint8)                # a second request while b is out: a new block
+    assert c.ctypes.data != addr
+    del b, c
+    assert len(pool.free) == 2
+    small = pool.empty(100, np.uint8)                # small results are ordinary arrays
+    assert small.base is None and len(pool.free) == 2
+    for _ in range(10):                              # the pool keeps a bounded number of blocks
+        del small
+        small = [pool.empty((1 << 20) * (k + 1), np.uint8) for k in range(8)]
+    del small
+    assert len(pool.free) <= pool.MAX_FREE

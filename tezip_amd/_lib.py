@@ -11,6 +11,7 @@ context on torch's stream (`Context(dev, stream=torch.cuda.current_stream().cuda
 bench.py does) or synchronise both sides explicitly."""
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -142,6 +143,62 @@ def pinned_copy(arr):
     out = pinned_empty(arr.shape, arr.dtype)
     out[...] = arr
     return out
+
+
+class _ResultPool:
+    """Recycled host buffers for the big results (payload, decoded frames).  A fresh np.empty costs a
+    page fault per 4 KB while the staging threads fill it (126 MB payload of cfg3: 10 ms, as long as
+    everything the GPU does in tz_encode); a block that comes back when the caller drops the array
+    has its pages already.  (Page-locked blocks would save 1-2 ms more per call but cost 85 ms per
+    500 MB the first time; callers who want that pass their own pinned_empty buffer.)  The MAX_FREE /
+    MAX_FREE_BYTES most recently returned blocks are kept.  TEZIP_RESULT_POOL=0 turns the pool off."""
+    MIN_BYTES, MAX_FREE, MAX_FREE_BYTES = 1 << 20, 6, 3 << 30
+
+    def __init__(self):
+        self.free = []                       # [uint8 base arrays], newest last
+        self.lock = threading.RLock()        # (a finaliser may run inside empty())
+        self.on = os.environ.get("TEZIP_RESULT_POOL", "1") != "0"
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if not self.on or nbytes < self.MIN_BYTES:
+            return np.empty(shape, dtype)
+        base = None
+        with self.lock:
+            best = None
+            for i, b in enumerate(self.free):
+                if nbytes <= b.size <= 2 * nbytes and (best is None or b.size < self.free[best].size):
+                    best = i
+            if best is not None:
+                base = self.free.pop(best)
+        if base is None:
+            base = np.empty((nbytes + (1 << 21) - 1) >> 21 << 21, np.uint8)
+        return np.asarray(_Pooled(self, base))[:nbytes].view(dtype).reshape(shape)
+
+    def give(self, base):
+        with self.lock:
+            self.free.append(base)
+            while len(self.free) > self.MAX_FREE or sum(b.size for b in self.free) > self.MAX_FREE_BYTES:
+                self.free.pop(0)
+
+
+class _Pooled:
+    """Owner of a pooled block: the arrays handed out are views of it; when the last one goes, the block
+    returns to the pool."""
+
+    def __init__(self, pool, base):
+        self.pool, self.base = pool, base
+        self.__array_interface__ = {"data": (base.ctypes.data, False), "shape": (base.size,), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        try:
+            self.pool.give(self.base)
+        except Exception:
+            pass
+
+
+_RESULTS = _ResultPool()
 
 
 def _ptr(x, dtype=None):
@@ -330,7 +387,7 @@ class Context:
         if resident:
             payload = None
         elif payload is None:
-            payload = np.empty(nt * h * w * 3, np.int16)
+            payload = _RESULTS.empty(nt * h * w * 3, np.int16)
         table = np.zeros(TZ_MAX_TABLE, np.int16)
         tlen = C.c_int(0)
         delta = np.empty((nt, h, w, 3), np.int16) if want_delta else None
@@ -367,7 +424,7 @@ class Context:
         if resident:
             out = None
         elif out is None:
-            out = np.empty((nt, h, w, 3), np.uint8)
+            out = _RESULTS.empty((nt, h, w, 3), np.uint8)
         tl = -1 if table is None else len(table)
         tb = None if table is None else np.ascontiguousarray(table, np.int16)
         self._ck(self.lib.tz_decode(self.h, None if payload is None else _ptr(payload), n, _ptr(tb), tl, _ptr(out)))

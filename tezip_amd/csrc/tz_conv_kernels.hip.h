@@ -642,33 +642,41 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
         }
     };
 
-    // ---- accumulators (as in k_conv3x3)
+    // ---- accumulators (as in k_conv3x3).  The kind of initial value is tested OUTSIDE the tile loops: inside,
+    // hipcc keeps one branch diamond per tile and waits for each tile's load at its join (vmcnt(0) x 8,
+    // eight memory latencies in a row at the head of every workgroup)
     f32x4 acc[MT][NT];
     {
         const int col0 = cb * (NT * 16) + (lane & 15);
+        if (a.initf) {
+            // one coalesced 16-byte load per tile (1 KB per wave-instruction) instead of four
+            // 64-byte segments per element: the prologue's G0 read was 20+ us under load
+            const float* f = a.initf + ((((long long)tile * a.ncb + cb) * 8 + wv) * MT * NT) * 256 + lane * 4;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = *(const f32x4*)(f + (mt * NT + nt) * 256);
+        } else if (a.init) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // (clamped address instead of a bounds branch: rows outside the image are never stored)
+                    int py, px;
+                    row_to_patch<MAP>(wv * 32 + mt * 16 + g * 4 + r, py, px);
+                    const int y = ty0 + py, x = tx0 + px;
+                    const long long pix = (y < a.H && x < a.W) ? (long long)y * a.W + x : 0;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = a.init[pix * a.ncols + col0 + nt * 16];
+                }
+        } else {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if (a.initf) {
-                    // one coalesced 16-byte load per tile (1 KB per wave-instruction) instead of four
-                    // 64-byte segments per element: the prologue's G0 read was 20+ us under load
-                    acc[mt][nt] = *(const f32x4*)(a.initf + (((((long long)tile * a.ncb + cb) * 8 + wv) * MT + mt) * NT + nt) * 256 + lane * 4);
-                } else if (a.init) {
-                    // (clamped address instead of a bounds branch: rows outside the image are never stored)
+                const float b = a.bias[col0 + nt * 16];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int py, px;
-                        row_to_patch<MAP>(wv * 32 + mt * 16 + g * 4 + r, py, px);
-                        const int y = ty0 + py, x = tx0 + px;
-                        const long long pix = (y < a.H && x < a.W) ? (long long)y * a.W + x : 0;
-                        acc[mt][nt][r] = a.init[pix * a.ncols + col0 + nt * 16];
-                    }
-                } else {
-                    const float b = a.bias[col0 + nt * 16];
-                    acc[mt][nt] = (f32x4){b, b, b, b};
-                }
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = (f32x4){b, b, b, b};
             }
+        }
     }
 
     // float index of this lane's A row (tile pixel of GEMM row lane&15, element g of the quad) in
