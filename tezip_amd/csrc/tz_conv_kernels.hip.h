@@ -44,6 +44,8 @@ struct ConvArgs {
     int ncols;
     const float* bias;  // [ncols]
     const float* init;  // [H*W][ncols] accumulator start (G0), or null -> bias
+    long long init_nstride;  // k_convlat: elements between batch items of init (0 = the same for every item)
+    int slot0;          // k_convlat: first weight slot of this launch (a launch over the tail of the source list)
     const float* initf; // the same values in accumulator-fragment order (k_to_fragments), or null
     const float* auxf;  // EPI_LSTM: `aux` in fragment order, or null
     int Cout;
@@ -849,7 +851,7 @@ __device__ __forceinline__ void lat_row_to_pixel(int r, int pc, int& py, int& px
 // grids of several rounds, where the matrix pipe rather than the chain latency is the limit and
 // half as many workgroups stream the weights).
 template <int EPI, bool UPS, int MTL>
-__global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
+__device__ __forceinline__ void convlat_body(const ConvArgs& a, int bid) {
     constexpr int MAP = EPI == EPI_POOL_ERR ? MAP_POOL : (UPS ? MAP_PARITY : MAP_LINEAR);
     constexpr int TS = MAP == MAP_PARITY ? 8 : 4;      // footprint of one accumulator tile in pixels
     constexpr int TSX = TS * MTL;                      // footprint of the workgroup in x
@@ -873,7 +875,6 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     const int NTW = a.ncols / (16 * a.ncb);            // column tiles per block: 3 or 4
     const int ltx = (a.W + TSX - 1) / TSX, lty = (a.H + TS - 1) / TS;
     const int ntiles = ltx * lty * (MAP == MAP_PARITY ? 4 : 1);
-    int bid = blockIdx.x;
     const int cb = bid % a.ncb;
     bid /= a.ncb;
     const int tile = bid % ntiles, n = bid / ntiles;
@@ -933,7 +934,7 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
                     lat_row_to_pixel<MAP>(4 * g + r, pc, py, px);
                     const int y = ty0 + py, x = tx0 + m * TS + px;
                     const long long pix = (y < a.H && x < a.W) ? (long long)y * a.W + x : 0;
-                    acc[m][r] = a.init[pix * a.ncols + col];
+                    acc[m][r] = a.init[(long long)n * a.init_nstride + pix * a.ncols + col];
                 }
             } else {
                 const float b = a.bias[col];
@@ -966,7 +967,7 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
     // the 4 waves).  Why registers: scripts/microbench/lat_slot2.hip -- with ONE wave per SIMD every memory
     // instruction between the MFMAs of the chain costs the wave 15-70 cycles that nothing overlaps; a ring
     // in LDS (DMA + ds_read_b128 per slot, the first version) ran at 142 ns per slot, this one at ~90.
-    int slot0 = 0;
+    int slot0 = a.slot0;
     auto run_phase = [&](auto upc, int b0, int b1) {
         constexpr bool UP = decltype(upc)::value;
         constexpr int SPB = UP ? 4 : 9;                   // slots this wave uses per block
@@ -1104,6 +1105,22 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
                 if (a.out1) a.out1[(long long)n * a.out1_nstride + pix * R + ch] = c;
             }
         }
+    } else if (EPI == EPI_RAW) {
+        // the accumulators as they are, [pixel][column]: the first part of a convolution whose sources
+        // become available at different times (the launch over the remaining sources starts from them
+        // through `init`: the same chain, cut at a source boundary)
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < MTL; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int py, px;
+                    lat_row_to_pixel<MAP>(4 * g + r, pc, py, px);
+                    const int y = ty0 + py, x = tx0 + m * TS + px;
+                    if (y < a.H && x < a.W)
+                        a.out0[(long long)n * a.out0_nstride + ((long long)y * a.W + x) * a.ncols + col] = acc[m][r];
+                }
+        }
     } else if (EPI == EPI_POOL_ERR) {
         // prednet.py:289-291 then 274-277 of the next level; a lane's 4 registers of tile m are window g
         const int H2 = a.H >> 1, W2 = a.W >> 1, C = a.Cout;
@@ -1126,6 +1143,20 @@ __global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
             }
         }
     }
+}
+
+template <int EPI, bool UPS, int MTL>
+__global__ __launch_bounds__(256) void k_convlat(const ConvArgs a) {
+    convlat_body<EPI, UPS, MTL>(a, blockIdx.x);
+}
+
+// Two independent small-grid convolutions in ONE launch (workgroups [0, na) run `a`, the rest `b`): the A
+// convolution of a level beside the first part of that level's gate convolution -- both read E_l only --
+// so that the gate convolution's chain over E_l leaves the critical path of the top-down pass.
+template <int EA, int EB>
+__global__ __launch_bounds__(256) void k_convlat_pair(const ConvArgs a, const ConvArgs b, int na) {
+    if ((int)blockIdx.x < na) convlat_body<EA, false, 1>(a, blockIdx.x);
+    else convlat_body<EB, false, 1>(b, blockIdx.x - na);
 }
 
 // ------------------------------------------------------------------------------------------

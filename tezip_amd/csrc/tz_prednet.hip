@@ -50,6 +50,7 @@ struct tz_model {
     float *R0[TZ_MAX_LEVELS] = {0}, *C0[TZ_MAX_LEVELS] = {0}, *Ahat0[TZ_MAX_LEVELS] = {0}, *G0[TZ_MAX_LEVELS] = {0};
     float *G0f[TZ_MAX_LEVELS] = {0}, *C0f[TZ_MAX_LEVELS] = {0};  // G0 / C0 in accumulator-fragment order (k_to_fragments)
     float *E[TZ_MAX_LEVELS] = {0}, *R1[TZ_MAX_LEVELS] = {0};
+    float* P[TZ_MAX_LEVELS] = {0};   // gate accumulators after the E_l part of the chain (split launches of small grids), or null
     PackedConv a_conv[TZ_MAX_LEVELS], gate_t1[TZ_MAX_LEVELS], ahat0_t1;
     float* d_zero = nullptr;  // zero page for LDS-DMA halo pixels
     int e0s = 0;              // floats per pixel of E[0]: 2*stack[0] rounded up to 8 (k_conv16b reads 16-byte quads)
@@ -270,6 +271,41 @@ extern "C" int tz_set_conv_impl(tz_ctx* ctx, int lds_dma) {
     return TZ_OK;
 }
 
+// grids that cannot fill the chip: one accumulator tile per wave (k_convlat), see the kernel's header.
+// Which kernel is faster is decided by a small cost model fitted to per-launch measurements on the
+// MI355X (profiles/r02/small_grid/): k_conv16 costs about 1.08 us per 16-channel x tap slot for
+// every workgroup a CU has to run (its K loop is a serial chain of 32-MFMA steps); k_convlat 0.105 us
+// per slot while the chain latency bounds it (one workgroup of 16 pixels per CU), 0.078 us per slot and
+// workgroup of a CU once the matrix pipe does (0.143 for the 32-pixel workgroups), upsampled sources
+// about a tenth more (4-slot blocks: a barrier per 4 slots instead of 9), plus 2.5 us per launch.
+struct LatPlan {
+    bool use, wide;
+    int blocks;
+};
+static LatPlan lat_plan(const tz_ctx* ctx, int NT, int epi, bool ups, bool fullk, const ConvArgs& a, int nbatch) {
+    LatPlan lp = {false, false, 0};
+    if (!(a.Wlat && a.nsrc > 0 && fullk && ctx->conv_impl && ctx->lat_mode && (NT == 3 || NT == 4) &&
+          (epi == EPI_POOL_ERR || (epi == EPI_LSTM && NT == 4))))
+        return lp;
+    const int ts_ = (epi != EPI_POOL_ERR && ups) ? 8 : 4;
+    const long long wg16 = (long long)a.ncb * a.tiles_x * a.tiles_y * nbatch;
+    const long long rows_ = (a.H + ts_ - 1) / ts_ * (ts_ == 8 ? 4 : 1);
+    const long long wglat1 = (long long)a.ncb * ((a.W + ts_ - 1) / ts_) * rows_ * nbatch;          // 16 pixels per workgroup
+    const long long wglat2 = (long long)a.ncb * ((a.W + 2 * ts_ - 1) / (2 * ts_)) * rows_ * nbatch;  // 32 pixels
+    // 32-pixel workgroups (two accumulator chains per wave, half as many workgroups streaming the weights)
+    // pay where the matrix pipe is the limit: 178 / 92 us against 191 / 99 with 16 pixels at 512x512, B = 1
+    static const long long wide_min = getenv("TEZIP_LAT_WIDE_MIN") ? atoll(getenv("TEZIP_LAT_WIDE_MIN")) : 2560;  // diagnostic
+    lp.wide = wglat1 > wide_min;
+    int slots = 0;
+    for (int s = 0; s < a.nsrc; ++s) slots += a.src[s].cpt * (a.src[s].up ? 4 : 9);
+    const double t16 = slots * 1.08 * (double)((wg16 + 255) / 256);
+    const double per_slot = lp.wide ? 0.143 * (double)((wglat2 + 255) / 256) : std::max(0.105, 0.078 * (double)((wglat1 + 255) / 256));
+    const double tlat = slots * per_slot * (ts_ == 8 ? 1.1 : 1.0) + 2.5;
+    lp.use = wg16 <= 768 && (ctx->lat_mode == 2 || tlat < 0.9 * t16);
+    lp.blocks = (int)(lp.wide ? wglat2 : wglat1);
+    return lp;
+}
+
 static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbatch) {
     tz_prof_scope ps(ctx, TZP_CONV);
     bool ups = false, fullk = true;
@@ -297,32 +333,11 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         TZ_CASE16B(1, EPI_POOL_ERR, false) TZ_CASE16B(3, EPI_POOL_ERR, false) TZ_CASE16B(4, EPI_POOL_ERR, false)
 #undef TZ_CASE16B
     }
-    // grids that cannot fill the chip: one accumulator tile per wave (k_convlat), see the kernel's header.
-    // Which kernel is faster is decided by a small cost model fitted to per-launch measurements on the
-    // MI355X (profiles/r02/small_grid/): k_conv16 costs about 1.08 us per 16-channel x tap slot for
-    // every workgroup a CU has to run (its K loop is a serial chain of 32-MFMA steps); k_convlat 0.105 us
-    // per slot while the chain latency bounds it (one workgroup of 16 pixels per CU), 0.078 us per slot and
-    // workgroup of a CU once the matrix pipe does (0.143 for the 32-pixel workgroups), upsampled sources
-    // about a tenth more (4-slot blocks: a barrier per 4 slots instead of 9), plus 2.5 us per launch.
-    if (a.Wlat && a.nsrc > 0 && fullk && ctx->conv_impl && ctx->lat_mode && (NT == 3 || NT == 4) &&
-        (epi == EPI_POOL_ERR || (epi == EPI_LSTM && NT == 4))) {
-        const int ts_ = (epi != EPI_POOL_ERR && ups) ? 8 : 4;
-        const long long wg16 = (long long)a.ncb * a.tiles_x * a.tiles_y * nbatch;
-        const long long rows_ = (a.H + ts_ - 1) / ts_ * (ts_ == 8 ? 4 : 1);
-        const long long wglat1 = (long long)a.ncb * ((a.W + ts_ - 1) / ts_) * rows_ * nbatch;          // 16 pixels per workgroup
-        const long long wglat2 = (long long)a.ncb * ((a.W + 2 * ts_ - 1) / (2 * ts_)) * rows_ * nbatch;  // 32 pixels
-        // 32-pixel workgroups (two accumulator chains per wave, half as many workgroups streaming the weights)
-        // pay where the matrix pipe is the limit: 178 / 92 us against 191 / 99 with 16 pixels at 512x512, B = 1
-        static const long long wide_min = getenv("TEZIP_LAT_WIDE_MIN") ? atoll(getenv("TEZIP_LAT_WIDE_MIN")) : 2560;  // diagnostic
-        const bool wide = wglat1 > wide_min;
-        int slots = 0;
-        for (int s = 0; s < a.nsrc; ++s) slots += a.src[s].cpt * (a.src[s].up ? 4 : 9);
-        const double t16 = slots * 1.08 * (double)((wg16 + 255) / 256);
-        const double per_slot = wide ? 0.143 * (double)((wglat2 + 255) / 256) : std::max(0.105, 0.078 * (double)((wglat1 + 255) / 256));
-        const double tlat = slots * per_slot * (ts_ == 8 ? 1.1 : 1.0) + 2.5;
-        const bool use_lat = wg16 <= 768 && (ctx->lat_mode == 2 || tlat < 0.9 * t16);
-        if (!use_lat) goto no_lat;
-        const int blocks = (int)(wide ? wglat2 : wglat1);
+    {
+        const LatPlan lp = lat_plan(ctx, NT, epi, ups, fullk, a, nbatch);
+        if (!lp.use) goto no_lat;
+        const bool wide = lp.wide;
+        const int blocks = lp.blocks;
         ps.sub = TZP_CONVLAT;
 #define TZ_LAT(e, u)                                                                                          \
     do {                                                                                                      \
@@ -481,6 +496,9 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         const int ec = l == 0 ? (m->e0s = (2 * m->stack[0] + 7) / 8 * 8) : 2 * m->stack[l];
         TZ_TRY(dmalloc(ctx, m, (void**)&m->E[l], (size_t)max_batch * npx * ec * 4));
         TZ_TRY(dmalloc(ctx, m, (void**)&m->R1[l], (size_t)max_batch * npx * R * 4));
+        // split gate launches (small grids only, see tz_model_predict_batch_dev): [item][pixel][4R] accumulators
+        if (l >= 1 && l < L - 1 && (size_t)max_batch * npx * 4 * R * 4 <= ((size_t)64 << 20))
+            TZ_TRY(dmalloc(ctx, m, (void**)&m->P[l], (size_t)max_batch * npx * 4 * R * 4));
     }
     TZ_TRY(dmalloc(ctx, m, (void**)&m->d_idx, sizeof(int) * 3 * max_batch));
     TZ_TRY(dmalloc(ctx, m, (void**)&m->d_zero, 256));
@@ -625,24 +643,13 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
                            d_idx + stride, m->Ahat0[0], Hp, Wp, m->stack[0], m->e0s, m->E[0]);
         TZ_HIP(ctx, hipGetLastError());
     }
-    for (int l = 0; l < L - 1; ++l) {  // t0 bottom-up
-        const PackedConv& pc = m->a_conv[l];
-        ConvArgs a;
-        memset(&a, 0, sizeof(a));
-        const float* ptrs[2] = {m->E[l], nullptr};
-        const int ec = l == 0 ? m->e0s : 2 * m->stack[l];  // floats per pixel of E[l]
-        long long ns[2] = {npx(l) * ec, 0};
-        fill_srcs(a, pc, ptrs, ns, ec);
-        set_geom(a, hl(l), wl(l));
-        a.Cout = m->stack[l + 1];
-        a.aux = m->Ahat0[l + 1];
-        a.out0 = m->E[l + 1];
-        a.out0_nstride = npx(l + 1) * 2 * m->stack[l + 1];
-        TZ_TRY(launch_conv(ctx, pc.NT, EPI_POOL_ERR, a, n));
-    }
-    for (int l = L - 1; l >= 0; --l) {  // t1 top-down
+    // Small grids (64x64-class frames): the launches of a step are latency chains on a mostly idle chip,
+    // so the gate convolution of level l is cut at its source boundary: the part over E_l runs in the
+    // SAME launch as A_l (both only need E_l), leaves its accumulators in P_l, and the top-down pass
+    // continues the chain over up(R_{l+1}) from there -- same fmaf chain, same bits, 108 + 54 slots off
+    // the critical path of a cfg1 step.
+    auto gate_args = [&](int l, ConvArgs& a) {
         const PackedConv& pc = m->gate_t1[l];
-        ConvArgs a;
         memset(&a, 0, sizeof(a));
         const float* ptrs[2] = {m->E[l], l < L - 1 ? m->R1[l + 1] : nullptr};
         const int ec = l == 0 ? m->e0s : 2 * m->stack[l];
@@ -657,6 +664,71 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         a.auxf = m->C0f[l];
         a.out0 = m->R1[l];
         a.out0_nstride = npx(l) * m->rstack[l];
+    };
+    auto aconv_args = [&](int l, ConvArgs& a) {
+        const PackedConv& pc = m->a_conv[l];
+        memset(&a, 0, sizeof(a));
+        const float* ptrs[2] = {m->E[l], nullptr};
+        const int ec = l == 0 ? m->e0s : 2 * m->stack[l];  // floats per pixel of E[l]
+        long long ns[2] = {npx(l) * ec, 0};
+        fill_srcs(a, pc, ptrs, ns, ec);
+        set_geom(a, hl(l), wl(l));
+        a.Cout = m->stack[l + 1];
+        a.aux = m->Ahat0[l + 1];
+        a.out0 = m->E[l + 1];
+        a.out0_nstride = npx(l + 1) * 2 * m->stack[l + 1];
+    };
+    bool split[TZ_MAX_LEVELS] = {false};
+    for (int l = 0; l < L - 1; ++l) {  // t0 bottom-up
+        const PackedConv& pc = m->a_conv[l];
+        ConvArgs a;
+        aconv_args(l, a);
+        if (m->P[l] && m->gate_t1[l].NT == 4 && m->gate_t1[l].segs.size() == 2) {
+            ConvArgs ge;
+            gate_args(l, ge);
+            ge.nsrc = 1;                      // the chain over E_l only
+            ge.initf = nullptr;
+            ge.out0 = m->P[l];
+            ge.out0_nstride = npx(l) * ge.ncols;
+            ConvArgs gu;
+            gate_args(l, gu);
+            gu.src[0] = gu.src[1];
+            gu.nsrc = 1;
+            const LatPlan pa = lat_plan(ctx, pc.NT, EPI_POOL_ERR, false, a.src[0].C % 16 == 0, a, n);
+            const LatPlan pe = lat_plan(ctx, 4, EPI_LSTM, false, ge.src[0].C % 16 == 0, ge, n);
+            const LatPlan pu = lat_plan(ctx, 4, EPI_LSTM, true, gu.src[0].C % 16 == 0, gu, n);
+            static const bool split_on = !getenv("TEZIP_LAT_SPLIT") || atoi(getenv("TEZIP_LAT_SPLIT")) != 0;  // diagnostic
+            if (split_on && pa.use && pe.use && pu.blocks > 0 && !pa.wide && !pe.wide && pa.blocks + pe.blocks <= 1024) {
+                tz_prof_scope ps(ctx, TZP_CONV);
+                ps.sub = TZP_CONVLAT;
+                hipLaunchKernelGGL((k_convlat_pair<EPI_POOL_ERR, EPI_RAW>), dim3(pa.blocks + pe.blocks), dim3(256), 0, ctx->stream, a, ge,
+                                   pa.blocks);
+                TZ_HIP(ctx, hipGetLastError());
+                split[l] = true;
+                continue;
+            }
+        }
+        TZ_TRY(launch_conv(ctx, pc.NT, EPI_POOL_ERR, a, n));
+    }
+    for (int l = L - 1; l >= 0; --l) {  // t1 top-down
+        const PackedConv& pc = m->gate_t1[l];
+        ConvArgs a;
+        gate_args(l, a);
+        if (split[l]) {  // continue the chain behind the E_l part
+            a.slot0 = a.src[0].cpt * 9;
+            a.src[0] = a.src[1];
+            a.nsrc = 1;
+            a.init = m->P[l];
+            a.init_nstride = npx(l) * a.ncols;
+            a.initf = nullptr;
+            const LatPlan pu = lat_plan(ctx, 4, EPI_LSTM, true, a.src[0].C % 16 == 0, a, n);
+            tz_prof_scope ps(ctx, TZP_CONV);
+            ps.sub = TZP_CONVLAT;
+            if (pu.wide) hipLaunchKernelGGL((k_convlat<EPI_LSTM, true, 2>), dim3(pu.blocks), dim3(256), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((k_convlat<EPI_LSTM, true, 1>), dim3(pu.blocks), dim3(256), 0, ctx->stream, a);
+            TZ_HIP(ctx, hipGetLastError());
+            continue;
+        }
         TZ_TRY(launch_conv(ctx, pc.NT, pc.NT == 4 ? EPI_LSTM : EPI_LSTM_PACKED, a, n));
     }
     {  // Ahat_0 at t1 = the prediction (prednet.py:268-271, 293-295)
