@@ -188,13 +188,15 @@ def test_host_buffers_pinned_pageable_and_device_give_the_same_bytes(ctx):
     assert int(np.abs(res["pinned"][3].astype(np.int16) - frames.astype(np.int16)).max()) <= 3
 
 
-@pytest.mark.parametrize("h,w,batch,nt,seed", [(128, 160, 4, 13, 21), (512, 512, 1, 3, 22), (61, 90, 2, 9, 23)])
+@pytest.mark.parametrize("h,w,batch,nt,seed", [(128, 160, 4, 13, 21), (512, 512, 1, 3, 22), (61, 90, 2, 9, 23), (40, 56, 2, 7, 24)])
 def test_small_grid_kernel_agrees_with_k_conv16(ctx, h, w, batch, nt, seed):
-    """k_convlat (one accumulator tile per wave, weights streamed per wave, for launches that cannot fill
-    the chip) walks the same fmaf chains as k_conv16: forced on wherever it is eligible -- every level
-    >= 1, also at 512x512 where it runs thousands of workgroups in several rounds with the 8-entry
-    ring -- the whole recursive rollout must equal the k_conv16 result bit for bit, image borders and
-    sizes that are no multiple of its 4x4 / 8x8 tiles included."""
+    """k_convlat (one accumulator tile per wave, weights streamed per wave through a register ring, for
+    launches that cannot fill the chip) walks the same fmaf chains as k_conv16: forced on wherever it is
+    eligible -- every level >= 1, also at 512x512 where it runs thousands of 32-pixel workgroups in
+    several rounds -- the whole recursive rollout must equal the k_conv16 result bit for bit, image
+    borders and sizes that are no multiple of its 4x4 / 8x8 tiles included (40x56: 10x14 and 20x28
+    levels).  The two small cases also take the split gate launches (E part beside the A convolution,
+    accumulators through HBM, upsampled part behind: tz_model_predict_batch_dev)."""
     frames = synth.turbulence(nt, h, w, seed=seed)
     ctx.prepare((h + 7) // 8 * 8, (w + 7) // 8 * 8, max_batch=batch)
     preds = {}
