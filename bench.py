@@ -193,7 +193,14 @@ def spawn_ranks(n, argv):
         env.setdefault("TEZIP_BENCH_BACKEND", "gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
-    return subprocess.run(cmd, env=env).returncode
+    # the ranks' stdout passes through a filter: ONE JSON line is the contract, and libraries (gloo: "[Gloo] Rank 0
+    # is connected to ...") write to stdout too -- everything that is not the bench line goes to stderr
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in p.stdout:
+        is_line = line.startswith('{"metric"')
+        (sys.stdout if is_line else sys.stderr).write(line)
+        (sys.stdout if is_line else sys.stderr).flush()
+    return p.wait()
 
 
 # ------------------------------------------------------------------------------ timing helper

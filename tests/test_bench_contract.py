@@ -18,17 +18,22 @@ def bench(monkeypatch):
     return importlib.reload(b)
 
 
-def test_gpus_flag_spawns_the_ranks(bench, monkeypatch):
+class _FakeRanks:
+    """Stands in for the torch.distributed.run child: records the command, 'prints' the given stdout lines."""
     calls = {}
+    lines = []
 
-    class R:
-        returncode = 0
+    def __init__(self, cmd, env=None, **kw):
+        _FakeRanks.calls = {"cmd": cmd, "env": env, "kw": kw}
+        self.stdout = iter(_FakeRanks.lines)
 
-    def fake_run(cmd, env=None, **kw):
-        calls["cmd"], calls["env"] = cmd, env
-        return R()
+    def wait(self):
+        return 0
 
-    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+
+def test_gpus_flag_spawns_the_ranks(bench, monkeypatch, capsys):
+    _FakeRanks.lines = ["[Gloo] Rank 0 is connected to 7 peer ranks.\n", '{"metric": "m", "value": 1}\n']
+    monkeypatch.setattr(bench.subprocess, "Popen", _FakeRanks)
     monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
     monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: pytest.fail("the parent must not initialise the GPU"))
     monkeypatch.delenv("WORLD_SIZE", raising=False)
@@ -36,6 +41,7 @@ def test_gpus_flag_spawns_the_ranks(bench, monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 0
+    calls = _FakeRanks.calls
     cmd = calls["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
@@ -44,19 +50,18 @@ def test_gpus_flag_spawns_the_ranks(bench, monkeypatch):
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
     assert calls["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
     assert "TEZIP_BENCH_SINGLE_DEVICE" not in calls["env"]           # 8 GPUs visible: one rank per GPU over RCCL
+    out = capsys.readouterr()                                         # stdout carries the bench line and nothing else
+    assert out.out == '{"metric": "m", "value": 1}\n' and "[Gloo]" in out.err
 
 
 def test_fewer_gpus_than_ranks_rehearses_on_one_device_over_gloo(bench, monkeypatch):
-    calls = {}
-
-    class R:
-        returncode = 0
-
-    monkeypatch.setattr(bench.subprocess, "run", lambda cmd, env=None, **kw: calls.update(cmd=cmd, env=env) or R())
+    _FakeRanks.lines = []
+    monkeypatch.setattr(bench.subprocess, "Popen", _FakeRanks)
     monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.delenv("TEZIP_BENCH_BACKEND", raising=False)
     assert bench.spawn_ranks(2, ["--gpus", "2"]) == 0
+    calls = _FakeRanks.calls
     assert calls["env"]["TEZIP_BENCH_SINGLE_DEVICE"] == "1" and calls["env"]["TEZIP_BENCH_BACKEND"] == "gloo"
 
 
