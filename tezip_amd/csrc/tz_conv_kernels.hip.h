@@ -867,9 +867,11 @@ __device__ __forceinline__ void convlat_body(const ConvArgs& a, int bid) {
     constexpr int PCS = NPS * 4 / 64, PCU = NPU * 4 / 64;   // 1 KB pieces (= DMA wave-instructions) per patch
     constexpr int NPI = (PCS + 3) / 4;                 // patch DMA instructions per wave
     static_assert(PCU <= PCS, "the half-resolution patch fits the same buffers");
-    // LDS: two patch buffers, the gate exchange of the LSTM epilogue
-    __shared__ __attribute__((aligned(16))) float sP[2][PCS * 256];
-    __shared__ float sE[EPI == EPI_LSTM ? 4 * 16 * MTL * 17 : 1];
+    // LDS: two patch buffers
+    constexpr int SE = EPI == EPI_LSTM ? 4 * 16 * MTL * 17 : 0;          // gate exchange of the LSTM epilogue
+    constexpr int PBUF = PCS * 256 > (SE + 1) / 2 ? PCS * 256 : ((SE + 1) / 2 + 3) / 4 * 4;
+    __shared__ __attribute__((aligned(16))) float sP[2][PBUF];
+    float* const sE = &sP[0][0];   // (re-uses the patch buffers: the K loop ends with a barrier)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NTW = a.ncols / (16 * a.ncb);            // column tiles per block: 3 or 4
