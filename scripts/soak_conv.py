@@ -19,18 +19,20 @@ ctx.load_model(cfg, cfg.init_weights(seed=123, bias_scale=0.1))
 t0 = time.time()
 runs = bad = 0
 MULT = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-for (h, w, batch, reps) in ((512, 512, 4, 24), (376, 1248, 2, 8), (128, 160, 4, 16), (1024, 1024, 2, 4), (64, 64, 2, 16)):
+# (the small and odd sizes run k_convlat -- register weight ring, asm LDS-DMA -- and its split gate launches)
+for (h, w, batch, reps) in ((512, 512, 4, 24), (376, 1248, 2, 8), (128, 160, 4, 16), (1024, 1024, 2, 4), (64, 64, 2, 16),
+                            (40, 56, 2, 8), (61, 90, 3, 8), (24, 16, 1, 8), (96, 72, 5, 8), (200, 120, 1, 8), (512, 512, 1, 6)):
     ctx.prepare((h + 7) // 8 * 8, (w + 7) // 8 * 8, max_batch=batch)
     for rep in range(reps * MULT):
         nt = 3 * batch
         frames = synth.turbulence(nt, h, w, seed=1000 + runs)
         out = []
-        for impl in (1, 0, 1):
-            ctx.set_conv_impl(impl)
+        for impl, lat in ((1, None), (0, None), (1, None), (1, "always")):
+            ctx.set_conv_impl(impl, lat=lat)
             ctx.rollout(frames, 0, 3)
             out.append(ctx.get_predictions())
         ctx.set_conv_impl(1)
-        ok = np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+        ok = all(np.array_equal(out[0], o) for o in out[1:])
         runs += 1
         bad += not ok
         if not ok:
