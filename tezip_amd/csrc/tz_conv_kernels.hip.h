@@ -814,7 +814,7 @@ __device__ __forceinline__ void lds_wait(f32x4& v) { asm volatile("s_waitcnt lgk
 // which would drain k_convlat's register ring at each block.  Unseen, it only makes hipcc's own
 // vmcnt(N) wait for more than it has to (N counts the loads it knows; ours are extra).
 __device__ __forceinline__ void glds16_opaque(const float* g, const float* l) {   // l: wave-uniform
-    const unsigned la = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)l;
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)l);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory");   // (m0 is reserved: hipcc sets it in front of each of its own uses)
 }
 // two floats O0 and O1 x 64 dwords behind a byte address, same reason
@@ -958,7 +958,15 @@ __device__ __forceinline__ void convlat_body(const ConvArgs& a, int bid) {
     const long long wstride = (long long)a.ncb * 1024;                                 // floats between slots of Wlat
     const float* wbase = a.Wlat + ((long long)cb * 4 + wv) * 256;                      // wave-uniform
     const unsigned wlane = lane * 16;                                                  // bytes
-    auto ldw = [&](const float* u) { return *(const f32x4*)((const char*)u + wlane); };
+    // scalar base + 32-bit lane offset (global_load ... v_off, s[base]): half the address registers of the
+    // 64-bit form -- a kilobyte of VMEM traffic costs the SIMD's matrix pipe 20-30 cycles, less in this form
+    // (scripts/microbench/lat_occ.hip).  The offset is laundered per use: hoisted out of the block as a
+    // 64-bit pair, instruction selection no longer sees the zero-extension and falls back to v[lo:hi], off.
+    auto ldw = [&](const float* u) {
+        unsigned o = wlane;
+        asm volatile("" : "+v"(o));
+        return *(const f32x4*)((const char*)u + o);
+    };
 
     // The K loop: per slot (16 channels x one tap) the wave takes its four B k-steps from a REGISTER ring
     // (one global_load_dwordx4 per slot, issued one block = SPB slots ahead into the entry the slot just
