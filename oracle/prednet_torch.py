@@ -8,7 +8,7 @@ the upsampled r_{l+1} is materialised (prednet.py:264) and convolved with the fu
 the concatenated input [r, e, r_up] -- no folding of constants, no collapsed taps, the library's
 own summation order.  It therefore plays the part of a "foreign" decoder (TensorFlow, another
 GPU library) when the cross-decoder deviation of the HIP path is measured
-(scripts/cross_decoder_deviation.py), and it cross-checks the tap-collapse algebra
+(tests/cross_decoder_deviation.py), and it cross-checks the tap-collapse algebra
 of the canonical oracle / the kernels.
 """
 import numpy as np

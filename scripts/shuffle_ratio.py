@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tezip_amd import _lib, compress, synth, zstd  # noqa: E402
 from tezip_amd.prednet import PredNetConfig  # noqa: E402
-from scripts.cross_decoder_deviation import trained_weights  # noqa: E402
+from scripts.trained_model import trained_weights  # noqa: E402
 
 
 def sizes(ctx, frames, mode, bound, entropy):

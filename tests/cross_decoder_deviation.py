@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Cross-decoder deviation of the HIP predictor (SURVEY.md §7 hard part 1).
+A measurement that uses the oracle package as the foreign decoder, hence kept under tests/ (run it as
+`python tests/cross_decoder_deviation.py` on the GPU box; pytest does not collect it).
 
 Lossless decoding rebuilds  recon = trunc(pred*255) - (trunc(pred_enc*255) - orig)
 (decompress.py:252-253), so a decoder whose predictor sums in another order than the encoder's
@@ -32,21 +34,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from oracle import prednet_torch  # noqa: E402
-from tezip_amd import _lib, synth, train, weights  # noqa: E402
+from scripts.trained_model import trained_weights  # noqa: E402
+from tezip_amd import _lib, synth  # noqa: E402
 from tezip_amd.prednet import PredNetConfig  # noqa: E402
-
-
-def trained_weights(epochs):
-    tmp = tempfile.mkdtemp(prefix="tz_dev_")
-    data = os.path.join(tmp, "set")
-    os.makedirs(data)
-    seqs = [synth.turbulence(12, 128, 128, seed=100 + s) for s in range(10)]
-    np.save(os.path.join(data, "X_train.npy"), np.concatenate(seqs[:9]))
-    np.save(os.path.join(data, "sources_train.npy"), np.repeat(["train-%d" % s for s in range(9)], 12))
-    np.save(os.path.join(data, "X_val.npy"), seqs[9])
-    np.save(os.path.join(data, "sources_val.npy"), np.repeat(["val-9"], 12))
-    train.run(os.path.join(tmp, "model"), data, False, nb_epoch=epochs)
-    return weights.load_model(os.path.join(tmp, "model"))[1]
 
 
 def measure(cfg, wts, frames, window, foreign, max_windows):
