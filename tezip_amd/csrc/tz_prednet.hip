@@ -276,7 +276,7 @@ extern "C" int tz_set_conv_impl(tz_ctx* ctx, int lds_dma) {
 // MI355X (profiles/r02/small_grid/): k_conv16 costs about 1.08 us per 16-channel x tap slot for
 // every workgroup a CU has to run (its K loop is a serial chain of 32-MFMA steps); k_convlat 0.105 us
 // per slot while the chain latency bounds it (one workgroup of 16 pixels per CU), 0.078 us per slot and
-// workgroup of a CU once the matrix pipe does (0.143 for the 32-pixel workgroups), upsampled sources
+// workgroup of a CU once the matrix pipe does (0.134 for the 32-pixel workgroups), upsampled sources
 // about a tenth more (4-slot blocks: a barrier per 4 slots instead of 9), plus 2.5 us per launch.
 struct LatPlan {
     bool use, wide;
@@ -293,13 +293,13 @@ static LatPlan lat_plan(const tz_ctx* ctx, int NT, int epi, bool ups, bool fullk
     const long long wglat1 = (long long)a.ncb * ((a.W + ts_ - 1) / ts_) * rows_ * nbatch;          // 16 pixels per workgroup
     const long long wglat2 = (long long)a.ncb * ((a.W + 2 * ts_ - 1) / (2 * ts_)) * rows_ * nbatch;  // 32 pixels
     // 32-pixel workgroups (two accumulator chains per wave, half as many workgroups streaming the weights)
-    // pay where the matrix pipe is the limit: 178 / 92 us against 191 / 99 with 16 pixels at 512x512, B = 1
+    // pay where the matrix pipe is the limit: 167 / 87 us against 180 / 94 with 16 pixels at 512x512, B = 1
     static const long long wide_min = getenv("TEZIP_LAT_WIDE_MIN") ? atoll(getenv("TEZIP_LAT_WIDE_MIN")) : 2560;  // diagnostic
     lp.wide = wglat1 > wide_min;
     int slots = 0;
     for (int s = 0; s < a.nsrc; ++s) slots += a.src[s].cpt * (a.src[s].up ? 4 : 9);
     const double t16 = slots * 1.08 * (double)((wg16 + 255) / 256);
-    const double per_slot = lp.wide ? 0.143 * (double)((wglat2 + 255) / 256) : std::max(0.105, 0.078 * (double)((wglat1 + 255) / 256));
+    const double per_slot = lp.wide ? 0.134 * (double)((wglat2 + 255) / 256) : std::max(0.105, 0.078 * (double)((wglat1 + 255) / 256));
     const double tlat = slots * per_slot * (ts_ == 8 ? 1.1 : 1.0) + 2.5;
     lp.use = wg16 <= 768 && (ctx->lat_mode == 2 || tlat < 0.9 * t16);
     lp.blocks = (int)(lp.wide ? wglat2 : wglat1);
