@@ -293,7 +293,7 @@ static LatPlan lat_plan(const tz_ctx* ctx, int NT, int epi, bool ups, bool fullk
     const long long wglat1 = (long long)a.ncb * ((a.W + ts_ - 1) / ts_) * rows_ * nbatch;          // 16 pixels per workgroup
     const long long wglat2 = (long long)a.ncb * ((a.W + 2 * ts_ - 1) / (2 * ts_)) * rows_ * nbatch;  // 32 pixels
     // 32-pixel workgroups (two accumulator chains per wave, half as many workgroups streaming the weights)
-    // pay where the matrix pipe is the limit: 167 / 87 us against 180 / 94 with 16 pixels at 512x512, B = 1
+    // pay where the matrix pipe is the limit: 166 / 86 us against 175 / 90 with 16 pixels at 512x512, B = 1
     static const long long wide_min = getenv("TEZIP_LAT_WIDE_MIN") ? atoll(getenv("TEZIP_LAT_WIDE_MIN")) : 2560;  // diagnostic
     lp.wide = wglat1 > wide_min;
     int slots = 0;
