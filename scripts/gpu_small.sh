@@ -1,5 +1,6 @@
 #!/bin/bash
 # On the GPU box: per-shape kernel durations of the cfg1 (64x64, 2 windows) and cfg2 (128x160, 4 windows) rollouts.
+# SMALL_LAT=always|never forces / forbids k_convlat (default: the cost model).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for C in 1 2; do
 cat > /tmp/small$C.py <<PY
@@ -8,6 +9,7 @@ sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 from tezip_amd import _lib, synth
 from tezip_amd.prednet import PredNetConfig
 cfg = PredNetConfig(); ctx = _lib.Context(0); ctx.load_model(cfg, cfg.init_weights(seed=123))
+if os.environ.get("SMALL_LAT"): ctx.set_conv_impl(True, lat=os.environ["SMALL_LAT"])
 if $C == 1:
     f = synth.moving_blobs(40, 64, 64); ctx.prepare(64, 64, 2); w = 20
 else:
