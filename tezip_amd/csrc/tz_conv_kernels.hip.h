@@ -596,36 +596,51 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     const int nbe = up0 ? 0 : (UPS && a.nsrc > 1 && a.src[1].up ? nb0 : nblk);  // same-resolution blocks
 
     // ---- LDS-DMA issue.  Item i = piece * 64 + lane of a patch = quad plane i / NP, slot i % NP.
+    // The geometry of a lane's items (which pixel, inside the image or not) is the same for every block of the
+    // workgroup, so it is worked out ONCE: poff[j] = float offset of item (wv + 8j) * 64 + lane inside a source
+    // image (pixel offset x pixel stride + 4 x quad), or -1 outside.  Per block that leaves a compare, a 64-bit
+    // add and a select per item instead of ~30 integer instructions -- and VALU instructions are not free
+    // beside the K loops of the other waves: each one takes 4 cycles of the SIMD that its matrix pipe then does
+    // not get (scripts/microbench/coexec.hip: 8 v_fma beside every MFMA double the MFMA stream's time).  The
+    // same-resolution sources of a launch share one pixel stride except E_0 (k_conv16b's business).
+    constexpr int NPJ = (P16_PIECES + 7) / 8;
+    int poff[NPJ], poff_lo = -1;
+    {
+        const int ps = a.src[0].pstride;
+#pragma unroll
+        for (int j = 0; j < NPJ; ++j) {
+            const int piece = wv + 8 * j;
+            const int i = piece * 64 + lane, q = i / NP16, slot = i - q * NP16;
+            const int y = slot / PW, xs = slot - y * PW;
+            const int x = MAP == MAP_PARITY ? (xs < PW / 2 ? 2 * xs : 2 * (xs - PW / 2) + 1) : xs;
+            const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
+            const bool ok = piece < P16_PIECES && slot < PPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            poff[j] = ok ? (yy * a.W + xx) * ps + 4 * q : -1;
+        }
+        if (UPS) {
+            const ConvSrc& su = a.src[a.nsrc - 1];
+            const int i = wv * 64 + lane, q = i / NPU16, slot = i - q * NPU16;
+            const int Y = slot / LW, X = slot - Y * LW;
+            const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
+            const bool ok = wv < U16_PIECES && slot < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
+            poff_lo = ok ? (ly * (a.W >> 1) + lx) * su.pstride + 4 * q : -1;
+        }
+    }
     auto issue_patch = [&](int blk, int piece0) {
         const bool s1 = blk >= nb0;
         const ConvSrc& s = s1 ? a.src[1] : a.src[0];
         const int c0 = (s1 ? blk - nb0 : blk) * 16;
-        const float* base = s.p + (long long)n * s.nstride;
+        const float* base = s.p + (long long)n * s.nstride + c0;
         float* dst = smem + piece0 * 256;
-        // the patch geometry is recomputed per call (once per block): kept live across the K loop
-        // it costs ~12 VGPRs and spills
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
         if (UPS && blk >= nbe) {
             if (wv >= U16_PIECES) return;
-            const int i = wv * 64 + ln, q = i / NPU16, slot = i - q * NPU16;
-            const int Y = slot / LW, X = slot - Y * LW;
-            const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
-            const bool ok = slot < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
-            glds16(ok ? base + ((long long)ly * (a.W >> 1) + lx) * s.pstride + c0 + 4 * q : a.zero, dst + wv * 256);
+            glds16(poff_lo >= 0 ? base + (unsigned)poff_lo : a.zero, dst + wv * 256);
             return;
         }
 #pragma unroll
-        for (int j = 0; j < (P16_PIECES + 7) / 8; ++j) {
+        for (int j = 0; j < NPJ; ++j) {
             const int piece = wv + 8 * j;
-            if (piece < P16_PIECES) {
-                const int i = piece * 64 + ln, q = i / NP16, slot = i - q * NP16;
-                const int y = slot / PW, xs = slot - y * PW;
-                const int x = MAP == MAP_PARITY ? (xs < PW / 2 ? 2 * xs : 2 * (xs - PW / 2) + 1) : xs;
-                const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
-                const bool ok = slot < PPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-                glds16(ok ? base + ((long long)yy * a.W + xx) * s.pstride + c0 + 4 * q : a.zero, dst + piece * 256);
-            }
+            if (piece < P16_PIECES) glds16(poff[j] >= 0 ? base + (unsigned)poff[j] : a.zero, dst + piece * 256);
         }
     };
     // weights of one step into the pieces starting at piece0.  Same-resolution step: the 4 k-steps
