@@ -568,6 +568,15 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// LDS-DMA of one contiguous kilobyte: lane i's 16 bytes come from ubase + 16 i (ubase wave-uniform, voff = 16 x lane
+// kept in a register by the caller).  `global_load_lds_dwordx4 v_off, s[base]`: the address needs no VALU
+// instruction (the generic form costs a 64-bit vector add per issue, and VALU instructions take matrix-pipe time).
+// Opaque to hipcc like glds16_opaque below; k_conv16 waits with explicit vmcnt(0) in front of its barriers.
+__device__ __forceinline__ void glds16_lanes(const float* ubase, unsigned voff, const float* l) {
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)l);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(ubase), "s"(la) : "memory");
+}
+
 // waits for all of this wave's vector-memory operations (LDS-DMA included)
 __device__ __forceinline__ void wait_vm(int = 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wg_barrier() {
@@ -647,15 +656,16 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     // of (block, tap), one piece each from the waves of half `half` of the workgroup.  Upsampled
     // step: the 4 k-steps of one collapsed tap for each of the 4 parity classes, piece index
     // class * 4 + k-step; wave w fetches k-steps 2(w&1), 2(w&1)+1 of class w>>1.
+    // (scalar base + lane offset: no address arithmetic in the vector ALU, see glds16_lanes)
+    const unsigned lane16 = lane * 16;
     auto issue_w = [&](int slot, bool up, int piece0, int half) {
         if (UPS && up) {
-            const float* src = a.Wimg + (((long long)(slot + (wv >> 1)) * a.ncb + cb) * 4 + 2 * (wv & 1)) * 256 + lane * 4;
+            const float* src = a.Wimg + (((long long)(slot + (wv >> 1)) * a.ncb + cb) * 4 + 2 * (wv & 1)) * 256;
             float* dst = smem + (piece0 + 2 * wv) * 256;
-            glds16(src, dst);
-            glds16(src + 256, dst + 256);
+            glds16_lanes(src, lane16, dst);
+            glds16_lanes(src + 256, lane16, dst + 256);
         } else if ((wv >> 2) == half) {
-            glds16(a.Wimg + (((long long)slot * a.ncb + cb) * 4 + (wv & 3)) * 256 + lane * 4,
-                   smem + (piece0 + (wv & 3)) * 256);
+            glds16_lanes(a.Wimg + (((long long)slot * a.ncb + cb) * 4 + (wv & 3)) * 256, lane16, smem + (piece0 + (wv & 3)) * 256);
         }
     };
 
