@@ -81,21 +81,24 @@ enum { MAP_LINEAR = 0, MAP_POOL = 1, MAP_PARITY = 2 };
 // and POOL (PARITY keeps a 2-way conflict, see below; LDS is not the critical path).
 template <int MAP>
 __device__ __forceinline__ void row_to_patch(int m, int& py, int& px) {
+    // The two M-tiles of a wave (mt = 0, 1) sit EIGHT patch rows apart in every map: 8 x 18 pixels x 4
+    // floats = 576 = 9 x 64 dwords, so k_conv16 reaches both tiles and all four k-step planes (21 x 64 dwords
+    // apart) of a tap from ONE address register through the 64-dword-granular immediates of
+    // ds_read2st64_b32 -- no vector address arithmetic per k-step (VALU instructions take matrix-pipe time).
     int w = m >> 5, mt = (m >> 4) & 1, r16 = m & 15;
     if (MAP == MAP_POOL) {
-        // M-tile = 8 rows x 2 columns = four stacked 2x2 windows (conflict-free at stride 18)
-        int T = 2 * w + mt;
-        py = 8 * (T >> 3) + 2 * (r16 >> 2) + ((r16 & 3) >> 1);
-        px = 2 * (T & 7) + (r16 & 1);
+        // M-tile = 8 rows x 2 columns = four stacked 2x2 windows; wave w = columns 2w, 2w+1, rows 8 mt ..
+        py = 8 * mt + 2 * (r16 >> 2) + ((r16 & 3) >> 1);
+        px = 2 * w + (r16 & 1);
     } else if (MAP == MAP_PARITY) {
-        // M-tile = two rows x 8 columns of the 8x8 grid of one parity class (2-way conflicts on its
-        // A reads; the conflict-free alternative -- rows (sub, sub+4) at stride 17 -- needs 4-byte
-        // patch stores and measured 2.5 % slower)
-        int T = 2 * w + mt, pc = T >> 2, sub = T & 3;
+        // M-tile = two rows x 8 columns of the 8x8 grid of one parity class pc = w >> 1 (wave-uniform: the
+        // collapsed weights of an upsampled source depend on it); class rows 2 sub, 2 sub + 1 with
+        // sub = (w & 1) + 2 mt
+        int pc = w >> 1, sub = (w & 1) + 2 * mt;
         py = 2 * (2 * sub + (r16 >> 3)) + (pc >> 1);
         px = 2 * (r16 & 7) + (pc & 1);
     } else {
-        py = 2 * w + mt;
+        py = w + 8 * mt;
         px = r16;
     }
 }
@@ -556,12 +559,15 @@ __global__ __launch_bounds__(NTHR, NT == 1 ? 8 : 6) void k_conv3x3(const ConvArg
 // LDS = 50 pieces of 1 KB (3 workgroups per CU).  Same-resolution phase: patches P0 = [0,21),
 // P1 = [21,42), weight buffers 42 + 4*buf.  The upsampled source's steps (one collapsed tap each:
 // 4 k-steps x 4 parity classes = 16 pieces of weights, 32 MFMAs per wave and barrier) use
-// 7-piece patches [0,7), [7,14) and weight buffers 14 + 16*buf; the switch between the two
+// 8-piece patches [0,8), [8,16) and weight buffers 16 + 16*buf; the switch between the two
 // layouts happens once per workgroup behind a barrier, with an un-overlapped first load.
 static constexpr int P16_PIECES = 21;                   // 1 KB pieces of an 18x18 patch (324 px -> 20.25)
-static constexpr int U16_PIECES = 7;                    // ... of a 10x10 half-resolution patch
+static constexpr int U16_PIECES = 7;                    // ... of a 10x10 half-resolution patch (k_conv16b)
 static constexpr int NP16 = P16_PIECES * 16, NPU16 = U16_PIECES * 16;  // slots per quad plane (336 / 112)
-static constexpr int C16_LDS_PIECES = 2 * P16_PIECES + 8;   // >= 2 * U16_PIECES + 32
+// k_conv16 stores its 10x10 half-resolution patch with a row stride of 12 slots: the two M-tiles of a wave are
+// 4 half-resolution rows apart = 4 x 12 x 4 = 3 x 64 dwords (see row_to_patch); 10 x 12 = 120 -> 128 slots per plane
+static constexpr int LWS16 = 12, NPU16S = 128, U16S_PIECES = NPU16S * 4 / 64;
+static constexpr int C16_LDS_PIECES = 2 * P16_PIECES + 8;   // >= 2 * U16S_PIECES + 32
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -628,10 +634,10 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
         }
         if (UPS) {
             const ConvSrc& su = a.src[a.nsrc - 1];
-            const int i = wv * 64 + lane, q = i / NPU16, slot = i - q * NPU16;
-            const int Y = slot / LW, X = slot - Y * LW;
+            const int i = wv * 64 + lane, q = i / NPU16S, slot = i - q * NPU16S;
+            const int Y = slot / LWS16, X = slot - Y * LWS16;
             const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
-            const bool ok = wv < U16_PIECES && slot < LPIX && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
+            const bool ok = wv < U16S_PIECES && Y < LW && X < LW && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
             poff_lo = ok ? (ly * (a.W >> 1) + lx) * su.pstride + 4 * q : -1;
         }
     }
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
         const float* base = s.p + (long long)n * s.nstride + c0;
         float* dst = smem + piece0 * 256;
         if (UPS && blk >= nbe) {
-            if (wv >= U16_PIECES) return;
+            if (wv >= U16S_PIECES) return;
             glds16(poff_lo >= 0 ? base + (unsigned)poff_lo : a.zero, dst + wv * 256);
             return;
         }
@@ -714,7 +720,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
         int py, px;
         row_to_patch<MAP>(wv * 32 + mt * 16 + (lane & 15), py, px);
         abase[mt] = 4 * (py * PW + (MAP == MAP_PARITY ? (px >> 1) + (PW / 2) * (px & 1) : px)) + g;
-        abase_lo[mt] = 4 * (((py >> 1) + (py & 1)) * LW + (px >> 1) + (px & 1)) + g;
+        abase_lo[mt] = 4 * (((py >> 1) + (py & 1)) * LWS16 + (px >> 1) + (px & 1)) + g;
     }
     const int wcls = MAP == MAP_PARITY ? (wv >> 1) : 0;  // parity class (py&1, px&1) of this wave's rows
 
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
     auto run_phase = [&](auto upc, int b0, int b1) {
         constexpr bool UP = decltype(upc)::value;
         constexpr int nsteps = UP ? 4 : 9, bslots = UP ? 16 : 9, WP = UP ? 16 : 4;
-        constexpr int pA0 = 0, pA1 = UP ? U16_PIECES : P16_PIECES;   // patch buffers
+        constexpr int pA0 = 0, pA1 = UP ? U16S_PIECES : P16_PIECES;  // patch buffers
         constexpr int wA = 2 * pA1;                                  // weight buffers
         if (b0 >= b1) return;
         // first patch and first weights of the phase (nothing of the previous phase is live)
@@ -751,13 +757,13 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
                 // steps are +1.  Upsampled: the 2x2 collapsed taps of the 10-wide half-resolution patch.
                 int toff;
                 if (UP) {
-                    toff = 4 * ((st >> 1) * LW + (st & 1));
+                    toff = 4 * ((st >> 1) * LWS16 + (st & 1));
                 } else {
                     const int dy = st / 3, dx = st - 3 * dy;
                     const int xo = MAP == MAP_PARITY ? (dx == 1 ? ((wcls & 1) ? 1 - PW / 2 : PW / 2) : (dx >> 1)) : dx;
                     toff = 4 * (dy * PW + xo);
                 }
-                constexpr int KOFF = 4 * (UP ? NPU16 : NP16);  // floats between the quad planes
+                constexpr int KOFF = 4 * (UP ? NPU16S : NP16);  // floats between the quad planes
                 float fa[MT][4];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
