@@ -583,6 +583,15 @@ __device__ __forceinline__ void glds16_lanes(const float* ubase, unsigned voff, 
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(ubase), "s"(la) : "memory");
 }
 
+// ... and the gather form of the same: lane i fetches 16 bytes from ubase + voff_i if bit i of `mask` is set and
+// does nothing otherwise (its LDS slot keeps what it holds: k_conv16 zeroes the slots of out-of-image pixels once
+// per workgroup).  The wave runs with all lanes enabled around it.
+__device__ __forceinline__ void glds16_gather(const float* ubase, unsigned voff, unsigned long long mask, const float* l) {
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)l);
+    asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
+                 : : "v"(voff), "s"(ubase), "s"(la), "s"(mask) : "memory");
+}
+
 // waits for all of this wave's vector-memory operations (LDS-DMA included)
 __device__ __forceinline__ void wait_vm(int = 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wg_barrier() {
@@ -612,14 +621,17 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
 
     // ---- LDS-DMA issue.  Item i = piece * 64 + lane of a patch = quad plane i / NP, slot i % NP.
     // The geometry of a lane's items (which pixel, inside the image or not) is the same for every block of the
-    // workgroup, so it is worked out ONCE: poff[j] = float offset of item (wv + 8j) * 64 + lane inside a source
-    // image (pixel offset x pixel stride + 4 x quad), or -1 outside.  Per block that leaves a compare, a 64-bit
-    // add and a select per item instead of ~30 integer instructions -- and VALU instructions are not free
-    // beside the K loops of the other waves: each one takes 4 cycles of the SIMD that its matrix pipe then does
-    // not get (scripts/microbench/coexec.hip: 8 v_fma beside every MFMA double the MFMA stream's time).  The
-    // same-resolution sources of a launch share one pixel stride except E_0 (k_conv16b's business).
+    // workgroup, so it is worked out ONCE: poff[j] = byte offset of item (wv + 8j) * 64 + lane inside a source
+    // image (pixel offset x pixel stride + quad), pmask[j] = the lanes whose pixel exists.  Per block a patch DMA
+    // is then scalar work only (exec = mask, scalar base of the 16-channel block): VALU instructions are not
+    // free beside the K loops of the other waves -- each one takes 4 cycles of the SIMD that its matrix pipe
+    // does not get (scripts/microbench/coexec.hip: 8 v_fma beside every MFMA double the MFMA stream's time; the
+    // per-block geometry was ~30 integer instructions per item: 0.845 -> 0.861 of the MFMA peak without it).
+    // Lanes outside the image fetch nothing: their LDS slots are zeroed once per phase (below) and never
+    // written.  The same-resolution sources of a launch share one pixel stride (E_0's is k_conv16b's business).
     constexpr int NPJ = (P16_PIECES + 7) / 8;
-    int poff[NPJ], poff_lo = -1;
+    unsigned poff[NPJ], poff_lo = 0;
+    unsigned long long pmask[NPJ], pmask_lo = 0;
     {
         const int ps = a.src[0].pstride;
 #pragma unroll
@@ -630,7 +642,8 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
             const int x = MAP == MAP_PARITY ? (xs < PW / 2 ? 2 * xs : 2 * (xs - PW / 2) + 1) : xs;
             const int yy = ty0 - 1 + y, xx = tx0 - 1 + x;
             const bool ok = piece < P16_PIECES && slot < PPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-            poff[j] = ok ? (yy * a.W + xx) * ps + 4 * q : -1;
+            poff[j] = ok ? 4u * (unsigned)((yy * a.W + xx) * ps + 4 * q) : 0u;
+            pmask[j] = __ballot(ok);
         }
         if (UPS) {
             const ConvSrc& su = a.src[a.nsrc - 1];
@@ -638,9 +651,14 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
             const int Y = slot / LWS16, X = slot - Y * LWS16;
             const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
             const bool ok = wv < U16S_PIECES && Y < LW && X < LW && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
-            poff_lo = ok ? (ly * (a.W >> 1) + lx) * su.pstride + 4 * q : -1;
+            poff_lo = ok ? 4u * (unsigned)((ly * (a.W >> 1) + lx) * su.pstride + 4 * q) : 0u;
+            pmask_lo = __ballot(ok);
         }
     }
+    // zeroes the first `pieces` KB of the workgroup's LDS (the patch buffers of the coming phase)
+    auto zero_lds = [&](int pieces) {
+        for (int i = tid; i < pieces * 64; i += NTHR) *(f32x4*)(smem + i * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
     auto issue_patch = [&](int blk, int piece0) {
         const bool s1 = blk >= nb0;
         const ConvSrc& s = s1 ? a.src[1] : a.src[0];
@@ -648,14 +666,13 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
         const float* base = s.p + (long long)n * s.nstride + c0;
         float* dst = smem + piece0 * 256;
         if (UPS && blk >= nbe) {
-            if (wv >= U16S_PIECES) return;
-            glds16(poff_lo >= 0 ? base + (unsigned)poff_lo : a.zero, dst + wv * 256);
+            if (wv < U16S_PIECES) glds16_gather(base, poff_lo, pmask_lo, dst + wv * 256);
             return;
         }
 #pragma unroll
         for (int j = 0; j < NPJ; ++j) {
             const int piece = wv + 8 * j;
-            if (piece < P16_PIECES) glds16(poff[j] >= 0 ? base + (unsigned)poff[j] : a.zero, dst + piece * 256);
+            if (piece < P16_PIECES) glds16_gather(base, poff[j], pmask[j], dst + piece * 256);
         }
     };
     // weights of one step into the pieces starting at piece0.  Same-resolution step: the 4 k-steps
@@ -734,6 +751,9 @@ __global__ __launch_bounds__(NTHR, 6) void k_conv16(const ConvArgs a) {
         constexpr int pA0 = 0, pA1 = UP ? U16S_PIECES : P16_PIECES;  // patch buffers
         constexpr int wA = 2 * pA1;                                  // weight buffers
         if (b0 >= b1) return;
+        // the slots of pixels outside the image stay zero for the whole phase (glds16_gather skips their lanes)
+        zero_lds(2 * pA1);
+        wg_barrier();
         // first patch and first weights of the phase (nothing of the previous phase is live)
         issue_patch(b0, pA0);
         issue_w(slot0, UP, wA, 0);
