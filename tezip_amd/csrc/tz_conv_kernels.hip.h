@@ -942,34 +942,49 @@ __device__ __forceinline__ void convlat_body(const ConvArgs& a, int bid) {
     const bool up0 = UPS && a.src[0].up != 0;
     const int nbe = up0 ? 0 : (UPS && a.nsrc > 1 && a.src[1].up ? nb0 : nblk);  // same-resolution blocks
 
-    // ---- LDS-DMA issue: item i = piece * 64 + lane = quad plane i / NP, slot i % NP
+    // ---- LDS-DMA issue: item i = piece * 64 + lane = quad plane i / NP, slot i % NP.  As in k_conv16 the geometry
+    // of a lane's items is worked out once (byte offset inside a source image + the mask of the lanes whose
+    // pixel exists), a patch DMA per block is scalar work, and the slots of pixels outside the image are zeroed
+    // once per phase: here a wave has its SIMD to itself, so every VALU instruction is on the critical path.
+    unsigned poff[NPI], poffu[NPI];
+    unsigned long long pmask[NPI], pmasku[NPI];
+#pragma unroll
+    for (int k = 0; k < NPI; ++k) {
+        const int piece = k * 4 + wv;
+        {
+            const int i = piece * 64 + lane, q = i / NPS, slot = i - q * NPS;
+            const int Y = slot / PWL, xs = slot - Y * PWL;
+            const int X = MAP == MAP_PARITY ? (xs < PWL / 2 ? 2 * xs : 2 * (xs - PWL / 2) + 1) : xs;
+            const int yy = ty0 - 1 + Y, xx = tx0 - 1 + X;
+            const bool ok = piece < PCS && slot < PPL && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            poff[k] = ok ? 4u * (unsigned)((yy * a.W + xx) * a.src[0].pstride + 4 * q) : 0u;
+            pmask[k] = __ballot(ok);
+        }
+        poffu[k] = 0;
+        pmasku[k] = 0;
+        if (UPS) {
+            const ConvSrc& su = a.src[a.nsrc - 1];
+            const int i = piece * 64 + lane, q = i / NPU, slot = i - q * NPU;
+            const int Y = slot / LWL, X = slot - Y * LWL;
+            const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
+            const bool ok = piece < PCU && slot < LPL && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
+            poffu[k] = ok ? 4u * (unsigned)((ly * (a.W >> 1) + lx) * su.pstride + 4 * q) : 0u;
+            pmasku[k] = __ballot(ok);
+        }
+    }
     auto issue_patch = [&](int blk, int buf, bool up) {
         const bool s1 = blk >= nb0;
         const ConvSrc& s = s1 ? a.src[1] : a.src[0];
-        const int c0 = (s1 ? blk - nb0 : blk) * 16;
-        const float* base = s.p + (long long)n * s.nstride;
+        const float* base = s.p + (long long)n * s.nstride + (s1 ? blk - nb0 : blk) * 16;
 #pragma unroll
         for (int k = 0; k < NPI; ++k) {
             const int piece = k * 4 + wv;
-            const float* src = a.zero;
-            if (up) {
-                if (piece >= PCU) continue;               // wave-uniform
-                const int i = piece * 64 + lane, q = i / NPU, slot = i - q * NPU;
-                const int Y = slot / LWL, X = slot - Y * LWL;
-                const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
-                if (slot < LPL && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1))
-                    src = base + ((long long)ly * (a.W >> 1) + lx) * s.pstride + c0 + 4 * q;
-            } else {
-                if (piece >= PCS) continue;
-                const int i = piece * 64 + lane, q = i / NPS, slot = i - q * NPS;
-                const int Y = slot / PWL, xs = slot - Y * PWL;
-                const int X = MAP == MAP_PARITY ? (xs < PWL / 2 ? 2 * xs : 2 * (xs - PWL / 2) + 1) : xs;
-                const int yy = ty0 - 1 + Y, xx = tx0 - 1 + X;
-                if (slot < PPL && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
-                    src = base + ((long long)yy * a.W + xx) * s.pstride + c0 + 4 * q;
-            }
-            glds16_opaque(src, sP[buf] + piece * 256);
+            if (piece >= (up ? PCU : PCS)) continue;               // wave-uniform
+            glds16_gather(base, up ? poffu[k] : poff[k], up ? pmasku[k] : pmask[k], sP[buf] + piece * 256);
         }
+    };
+    auto zero_patches = [&]() {
+        for (int i = tid; i < 2 * PBUF / 4; i += 256) *(f32x4*)(&sP[0][0] + i * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
     };
 
     // ---- accumulators: rows 4g..4g+3 of tile m (tile m sits m * TS pixels to the right), column lane&15
@@ -1037,6 +1052,8 @@ __device__ __forceinline__ void convlat_body(const ConvArgs& a, int bid) {
         const long long wstep = (UP ? 4 : 1) * wstride;
         const float* wblk = wbase + (long long)(slot0 + (UP ? pc : 0)) * wstride;   // first slot of the current block
         __syncthreads();                                  // every wave is done with the previous phase's patches
+        zero_patches();                                   // slots of pixels outside the image: zero for the whole phase
+        __syncthreads();
         issue_patch(b0, 0, UP);
         f32x4 wr[SPB];
         if (active) {
