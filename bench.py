@@ -388,6 +388,10 @@ def main():
     SUB = ("conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general", "convlat_small_grid")  # sub-classes of conv3x3_mfma
     step_dev_ms = sum(v[0] for k, v in prof.items() if k not in SUB)
     c16_ms, c16_n = prof["conv16_lds_dma"]               # the dominant kernel on its own
+    lat_ms, lat_n = prof.get("convlat_small_grid", (0.0, 0))
+    # (with fewer than 4 windows per GPU -- `--frames 40` -- the upper levels run on k_convlat: same convolutions,
+    # same FLOPs; counted with the dominant kernel so that the fraction stays FLOPs of these launches / their time)
+    c16_ms, c16_n = c16_ms + lat_ms, c16_n + lat_n
     c16_flops = conv16_flops_per_px0(cfg) * H * W * n_pred
     c16_tflops = c16_flops / (c16_ms * 1e-3) / 1e12 if c16_ms > 0 else 0.0
     delta_ms, delta_n = prof["delta"]
