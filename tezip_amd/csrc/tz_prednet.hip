@@ -312,6 +312,10 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
     for (int s = 0; s < a.nsrc; ++s) {
         ups = ups || a.src[s].up;
         fullk = fullk && (a.src[s].C % 16) == 0;
+        // k_conv16 / k_convlat address a source image through 32-bit byte offsets from its base (patch geometry
+        // worked out once per workgroup): a level of 4 GiB or more goes through the general kernel
+        const long long hs = a.src[s].up ? a.H >> 1 : a.H, ws = a.src[s].up ? a.W >> 1 : a.W;
+        fullk = fullk && hs * ws * a.src[s].pstride * 4 < (1LL << 32);
     }
     ps.sub = TZP_CONV_GEN;
     if (epi == EPI_RELU && a.nsrc == 1 && !ups && a.src[0].C == 3 && a.Cout == 3 && ctx->conv_impl) {
