@@ -882,6 +882,13 @@ __device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b, f32x2& c, f32x2& d)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
 }
 
+template <int N>
+__device__ __forceinline__ void wait_w(f32x4& w) {   // vmcnt(N), and `w` is not read before it
+    static_assert(N == 3 || N == 8, "immediate of s_waitcnt");
+    if (N == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(w) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" : "+v"(w) : : "memory");
+}
+
 template <int MAP>
 __device__ __forceinline__ void lat_row_to_pixel(int r, int pc, int& py, int& px) {
     if (MAP == MAP_POOL) {  // rows 4g..4g+3 = the 2x2 window g of the 4x4 block
@@ -1026,17 +1033,17 @@ __device__ __forceinline__ void convlat_body(const ConvArgs& a, int bid) {
     const unsigned wlane = lane * 16;                                                  // bytes
     // scalar base + 32-bit lane offset (global_load ... v_off, s[base]): half the address registers of the
     // 64-bit form -- a kilobyte of VMEM traffic costs the SIMD's matrix pipe 20-30 cycles, less in this form
-    // (scripts/microbench/lat_occ.hip).  The offset is laundered per use: hoisted out of the block as a
-    // 64-bit pair, instruction selection no longer sees the zero-extension and falls back to v[lo:hi], off.
+    // (scripts/microbench/lat_occ.hip).  Written as asm: hipcc only selects this form when it sees the
+    // zero-extension of the offset next to the load, i.e. at the price of a v_mov per load.  It then does not
+    // count these loads either: wait_w<N> in front of a ring entry's first use (N = loads issued after its own).
     auto ldw = [&](const float* u) {
-        unsigned o = wlane;
-        asm volatile("" : "+v"(o));
-        return *(const f32x4*)((const char*)u + o);
+        f32x4 v;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(wlane), "s"(u) : "memory");
+        return v;
     };
-
     // The K loop: per slot (16 channels x one tap) the wave takes its four B k-steps from a REGISTER ring
     // (one global_load_dwordx4 per slot, issued one block = SPB slots ahead into the entry the slot just
-    // consumed; hipcc counts those loads itself) and four A values per tile from the patch, and runs 4
+    // consumed) and four A values per tile from the patch, and runs 4
     // dependent MFMAs per tile.  The patch travels by LDS-DMA, whose waits are explicit: memory operations
     // of a wave complete in order, so a patch issued at the start of a block, in front of that block's SPB
     // weight loads, has landed at vmcnt(SPB).  One barrier per 16-channel block (the patch is shared by
@@ -1101,6 +1108,7 @@ __device__ __forceinline__ void convlat_body(const ConvArgs& a, int bid) {
 #pragma unroll
             for (int st = 0; st < SPB; ++st) {
                 const bool more = st + 1 < SPB;
+                wait_w<SPB - 1>(wr[st]);   // the SPB - 1 younger ring loads (and this block's patch DMAs) may still fly
                 const f32x4 w = wr[st];
                 f32x2 fan[MTL][2];
 #pragma unroll
@@ -1142,6 +1150,16 @@ __device__ __forceinline__ void convlat_body(const ConvArgs& a, int bid) {
             const float* wnext = wblk + (last ? 0 : SPB * wstep);
             if (active) block(wnext);
             wblk = wnext;
+        }
+        // The last block reloaded its ring entries once more (unused).  hipcc does not know that these asm loads
+        // are still in flight: the registers must stay the ring's until they have landed, or the late data
+        // lands in whatever hipcc put there next.
+        if (active) {
+            if constexpr (SPB == 9)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2]), "+v"(wr[3]), "+v"(wr[4]), "+v"(wr[5]), "+v"(wr[6]),
+                             "+v"(wr[7]), "+v"(wr[8]) : : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2]), "+v"(wr[3]) : : "memory");
         }
         slot0 += (b1 - b0) * (UP ? 16 : 9);
     };
