@@ -207,3 +207,28 @@ def test_small_grid_kernel_agrees_with_k_conv16(ctx, h, w, batch, nt, seed):
     ctx.set_conv_impl(1)
     assert np.array_equal(preds["never"], preds["always"]) and np.array_equal(preds["never"], preds[None])
     assert preds["never"].std() > 0
+
+
+def test_the_hot_launches_run_on_the_kernels_the_design_names(ctx):
+    """Dispatch guard: at 512x512 with four windows every convolution of levels >= 1 is k_conv16 (95 launches
+    per 19-step rollout), the level-0 ones k_conv16b / k_conv_small, and nothing falls back to the general
+    k_conv3x3; at 64x64 the levels >= 1 run on k_convlat (split gate launches included).  A silent fallback
+    would keep every parity test green and cost 15 % of the headline."""
+    frames = synth.turbulence(80, 512, 512, seed=9)
+    ctx.prepare(512, 512, max_batch=4)
+    ctx.rollout(frames, 0, 20)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    ctx.rollout(frames, 0, 20)
+    p = ctx.prof_get()
+    assert p["conv16_lds_dma"][1] == 95 and p["conv16b_level0"][1] == 38 and p["conv_small_valu"][1] == 19
+    assert p["conv3x3_general"][1] == 0 and p["convlat_small_grid"][1] == 0
+    small = synth.moving_blobs(40, 64, 64)
+    ctx.prepare(64, 64, max_batch=2)
+    ctx.rollout(small, 0, 20)
+    ctx.prof_reset()
+    ctx.rollout(small, 0, 20)
+    p = ctx.prof_get()
+    ctx.prof_enable(False)
+    # per step: pair (A1 + gates-1 E part), pair (A2 + gates-2 E part), gates 3, gates-2 / gates-1 upsampled parts
+    assert p["convlat_small_grid"][1] == 19 * 5 and p["conv16_lds_dma"][1] == 0 and p["conv3x3_general"][1] == 0
