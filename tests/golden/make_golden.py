@@ -176,6 +176,117 @@ def _helpers(compress, decompress, data_utils, out):
     out["pad_sizes_out"] = np.array([data_utils.padding_size(int(v)) for v in out["pad_sizes_in"]])
 
 
+def _chain(rng, kind, n, e_hint):
+    """One (frame, channel) chain of `n` integer deltas whose greedy runs under a tolerance of
+    about `e_hint` have a known character (the HIP quantiser works in 64-element chunks, walks a
+    chain in 8 segments from speculative starts and stitches them: tz_codec.hip)."""
+    if kind == "walk_slow":      # random walk that stays inside a 2E band for hundreds of elements
+        d = np.round(np.cumsum(rng.normal(0, 0.25 * max(e_hint, 1.0) / 2.0, size=n)))
+    elif kind == "walk_fast":    # runs of about ten elements
+        d = np.round(np.cumsum(rng.normal(0, 1.2, size=n)))
+        d = (d + 255) % 1020
+        d = np.where(d > 510, 1020 - d, d) - 255          # reflect into [-255, 255]
+    elif kind in ("steps64", "steps64_off"):              # runs of exactly 64, chunk-aligned or not
+        off = 0 if kind == "steps64" else 17
+        lev = rng.integers(-200, 201, size=n // 64 + 2)
+        jump = int(2 * e_hint) + 3
+        lev[1:] = np.where(np.abs(np.diff(lev)) <= jump, lev[1:] + 3 * jump, lev[1:])
+        for k in range(1, len(lev)):                       # neighbours differ by more than 2E
+            if abs(int(lev[k]) - int(lev[k - 1])) <= jump:
+                lev[k] = lev[k - 1] + jump + 1 if lev[k - 1] < 0 else lev[k - 1] - jump - 1
+        d = np.repeat(lev, 64)[64 - off: 64 - off + n] if off else np.repeat(lev, 64)[:n]
+    elif kind == "flat_spikes":  # runs much longer than a segment (1/8 of the chain)
+        d = np.full(n, int(rng.integers(-20, 21)), dtype=np.int64)
+        for pos in rng.integers(0, n, size=3):
+            d[pos] += int(4 * e_hint) + 9
+    elif kind == "one_run":      # the whole chain is a single run
+        d = np.full(n, int(rng.integers(-5, 6)), dtype=np.int64)
+        d[rng.integers(0, n, size=n // 50)] += 1
+    elif kind == "noise":        # runs of one or two elements
+        d = rng.integers(-255, 256, size=n)
+    elif kind == "mixed":        # a long run, a stretch of noise, steps, a slow walk
+        q = n // 4
+        d = np.concatenate([_chain(rng, "flat_spikes", q, e_hint), _chain(rng, "noise", q, e_hint),
+                            _chain(rng, "steps64_off", q, e_hint), _chain(rng, "walk_slow", n - 3 * q, e_hint)])
+    else:
+        raise ValueError(kind)
+    return np.clip(np.asarray(d, dtype=np.int64), -255, 255)
+
+
+def _orig_slab(rng, kind, n):
+    if kind == "full":           # range 255
+        o = rng.integers(0, 256, size=n)
+        o[0], o[-1] = 0, 255
+    elif kind == "narrow":       # range 40: `rel 0.01` gives E = 0.4, only equal neighbours merge
+        o = rng.integers(100, 141, size=n)
+        o[3], o[5] = 100, 140
+    elif kind == "zeros":        # pwrel: tolerance 0 wherever the pixel is black
+        o = rng.integers(0, 256, size=n)
+        o[rng.random(n) < 0.08] = 0
+        o[n // 3: n // 3 + 700] = 0
+    elif kind == "bright":       # pwrel with large tolerances: long runs
+        o = rng.integers(180, 256, size=n)
+    else:
+        raise ValueError(kind)
+    return o.astype(np.int64)
+
+
+def _run_lengths(res):
+    f = res.reshape(-1)
+    cut = np.flatnonzero(np.diff(f) != 0) + 1
+    return np.diff(np.concatenate([[0], cut, [f.size]]))
+
+
+def _long_chains(compress, out):
+    """error_bound of the REFERENCE on chains long enough for the parallel quantiser's chunk carry
+    (64 elements), segment speculation (1/8 of a chain) and stitch to fire: 96x128 and 100x131
+    (not a multiple of 64) slabs in all four modes and one 256x256 frame per mode.  Three slabs of
+    one (mode, bound) make the three channels of an HWC frame, the form tz_error_bound takes."""
+    rng = np.random.default_rng(20261005)
+    specs = [
+        # mode, value, H, W, (delta kind, orig kind) x 3 channels
+        ("abs", [2.0], 96, 128, [("walk_slow", "full"), ("steps64", "full"), ("flat_spikes", "full")]),
+        ("abs", [0.4], 96, 128, [("walk_slow", "full"), ("one_run", "full"), ("steps64_off", "full")]),
+        ("abs", [12.0], 96, 128, [("noise", "full"), ("walk_fast", "full"), ("mixed", "full")]),
+        ("abs", [3.5], 100, 131, [("mixed", "full"), ("steps64_off", "full"), ("walk_slow", "full")]),
+        ("rel", [0.01], 96, 128, [("walk_slow", "full"), ("walk_fast", "narrow"), ("steps64_off", "full")]),
+        ("rel", [0.1], 96, 128, [("noise", "full"), ("mixed", "full"), ("walk_fast", "narrow")]),
+        ("absrel", [3.0, 0.01], 96, 128, [("mixed", "full"), ("walk_slow", "narrow"), ("steps64", "full")]),
+        ("absrel", [1.0, 0.5], 96, 128, [("flat_spikes", "full"), ("walk_fast", "full"), ("one_run", "narrow")]),
+        ("pwrel", [0.05], 96, 128, [("walk_slow", "zeros"), ("mixed", "zeros"), ("steps64_off", "bright")]),
+        ("pwrel", [0.5], 100, 131, [("noise", "zeros"), ("walk_fast", "bright"), ("flat_spikes", "zeros")]),
+        ("abs", [2.0], 256, 256, [("mixed", "full"), ("flat_spikes", "full"), ("walk_slow", "full")]),
+        ("rel", [0.02], 256, 256, [("walk_slow", "full"), ("mixed", "full"), ("steps64_off", "narrow")]),
+        ("absrel", [4.0, 0.05], 256, 256, [("flat_spikes", "full"), ("walk_fast", "full"), ("mixed", "narrow")]),
+        ("pwrel", [0.1], 256, 256, [("mixed", "zeros"), ("walk_slow", "bright"), ("one_run", "zeros")]),
+    ]
+    out["lc_n"] = np.array(len(specs))
+    for i, (mode, val, h, w, chans) in enumerate(specs):
+        n = h * w
+        e_hint = abs(val[0]) if mode in ("abs", "absrel") else 255 * val[0]
+        orig = np.empty((h, w, 3), np.uint8)
+        diff = np.empty((h, w, 3), np.int16)
+        res = np.empty((h, w, 3), np.int16)
+        stats = []
+        for c, (dk, ok) in enumerate(chans):
+            o = _orig_slab(rng, ok, n).reshape(1, h, w)
+            d = _chain(rng, dk, n, e_hint).reshape(1, h, w)
+            r = compress.error_bound(o.copy(), d.copy(), mode, val, False, np)
+            r_int = np.empty((1, h, w), dtype=np.int64)     # compress.py:319: stored into an int64 array
+            r_int[...] = r
+            assert np.abs(r_int).max() <= 255
+            orig[..., c], diff[..., c], res[..., c] = o[0], d[0], r_int[0]
+            rl = _run_lengths(r_int)
+            stats.append((int(rl.size), int(rl.max()), int((rl == 64).sum())))
+        out["lc_%d_mode" % i] = np.array(mode)
+        out["lc_%d_val" % i] = np.array(val, dtype=np.float64)
+        out["lc_%d_orig" % i] = orig
+        out["lc_%d_diff" % i] = diff
+        out["lc_%d_res" % i] = res
+        print("long chain %2d %-6s %-12s %3dx%3d  (runs, longest, runs of 64) per channel: %s" % (
+            i, mode, val, h, w, stats))
+
+
 def _make_frames(rng, nt, h, w, gray):
     yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
     frames = []
@@ -191,10 +302,26 @@ def _make_frames(rng, nt, h, w, gray):
     return np.stack(frames)
 
 
-def _runs(compress, decompress, out):
-    from PIL import Image
-    rng = np.random.default_rng(777)
-    runs = [
+def _make_frames_uneven(rng, nt, h, w, gray):
+    """Motion that speeds up, stalls and jumps, so that the window MSE of compress.py:246 reaches a
+    threshold after a different number of frames in every window (DWP windows of mixed length)."""
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    speed = np.array([0.2, 0.2, 0.3, 3.0, 0.2, 0.1, 0.1, 0.2, 0.2, 4.0, 2.5, 0.3, 0.2, 0.2, 0.2, 0.1, 5.0, 0.3,
+                      0.3, 0.2, 0.2, 0.2, 0.2, 3.5, 0.2, 0.2])
+    phase = np.concatenate([[0.0], np.cumsum(speed)])
+    frames = []
+    for t in range(nt):
+        ph = phase[t % len(phase)]
+        base = 120 + 70 * np.sin((xx + 3 * ph) / 4.0) + 45 * np.cos((yy - 2 * ph) / 3.0)
+        img = np.stack([base, base * 0.6 + 40, 250 - base * 0.5], axis=-1) + rng.normal(0, 1.5, size=(h, w, 3))
+        img = np.clip(np.round(img), 0, 255).astype(np.uint8)
+        if t == 0:
+            img[0, 0] = (0, 0, 0)
+        frames.append(img[..., 0] if gray else img)
+    return np.stack(frames)
+
+
+RUNS_1 = [
         # name, nt, H, W, gray, p, w, t, mode, bound, entropy
         ("swp_p2_w4_lossless", 14, 21, 30, False, 2, 4, None, "abs", [0.0], True),
         ("swp_p0_w5_abs4", 12, 16, 24, False, 0, 5, None, "abs", [4.0], True),
@@ -203,10 +330,24 @@ def _runs(compress, decompress, out):
         ("swp_p0_w6_absrel", 13, 8, 40, False, 0, 6, None, "absrel", [3.0, 0.01], True),
         ("swp_p0_w4_lastkey", 9, 16, 16, False, 0, 4, None, "abs", [1.0], True),
         ("dwp_p2_lossless", 12, 10, 12, False, 2, None, 0.0045, "abs", [0.0], True),
-    ]
+]
+# round 3: DWP runs whose windows have MIXED lengths (the ones above came out uniform), one of them
+# with warm-up, a lossy bound and the entropy remap all together
+RUNS_2 = [
+        ("dwp_mixed_p0_lossless", 26, 24, 40, False, 0, None, 0.0085, "abs", [0.0], True),
+        ("dwp_mixed_p2_abs3_entropy", 26, 21, 30, False, 2, None, 0.0085, "abs", [3.0], True),
+        ("dwp_mixed_p1_pwrel_gray", 24, 19, 27, True, 1, None, 0.012, "pwrel", [0.04], True),
+]
+
+
+def _runs(compress, decompress, out, runs=None, seed=777, make_frames=None):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    make_frames = make_frames or _make_frames
+    runs = RUNS_1 if runs is None else runs
     out["run_names"] = np.array([r[0] for r in runs])
     for name, nt, h, w, gray, p, win, thr, mode, bound, entropy in runs:
-        frames = _make_frames(rng, nt, h, w, gray)
+        frames = make_frames(rng, nt, h, w, gray)
         hp, wp = ((h + 7) // 8) * 8, ((w + 7) // 8) * 8
         _FakeTrainModel.hp, _FakeTrainModel.wp = hp, wp
         _FakeTestModel.calls = []
@@ -270,6 +411,10 @@ def main():
     _helpers(compress, decompress, data_utils, helpers)
     np.savez_compressed(os.path.join(HERE, "ref_helpers.npz"), **helpers)
     print("ref_helpers.npz:", len(helpers), "arrays")
+    longc = {}
+    _long_chains(compress, longc)
+    np.savez_compressed(os.path.join(HERE, "ref_long.npz"), **longc)
+    print("ref_long.npz:", len(longc), "arrays")
     if not hasattr(np.ndarray, "tostring"):
         print("numpy >= 2: skipping compress.run/decompress.run goldens (needs ndarray.tostring)")
         return
@@ -277,6 +422,10 @@ def main():
     _runs(compress, decompress, runs)
     np.savez_compressed(os.path.join(HERE, "ref_runs.npz"), **runs)
     print("ref_runs.npz:", len(runs), "arrays")
+    runs2 = {}
+    _runs(compress, decompress, runs2, RUNS_2, seed=778, make_frames=_make_frames_uneven)
+    np.savez_compressed(os.path.join(HERE, "ref_runs2.npz"), **runs2)
+    print("ref_runs2.npz:", len(runs2), "arrays")
 
 
 if __name__ == "__main__":

@@ -70,6 +70,34 @@ def test_error_bound(ctx, mode, bound):
         np.testing.assert_array_equal(got[i], ref, err_msg="frame %d" % i)
 
 
+def _long_chain_cases():
+    import os
+    from conftest import GOLDEN
+    lc = np.load(os.path.join(GOLDEN, "ref_long.npz"))
+    return lc, range(int(lc["lc_n"]))
+
+
+@pytest.mark.parametrize("i", _long_chain_cases()[1])
+def test_error_bound_against_reference_long_chains(ctx, i):
+    """tz_error_bound on chains the REFERENCE itself quantised (tests/golden/ref_long.npz, made by
+    make_golden.py::_long_chains from compress.py:23-70): 12,288 / 13,100 / 65,536 elements per
+    chain, with runs shorter than, exactly and far longer than the kernel's 64-element chunks and
+    1/8-chain segments, pwrel with black pixels (tolerance 0).  Chunk carry, segment speculation
+    and k_q_stitch all fire here, and the expected output is the reference's, not the oracle's."""
+    lc, _ = _long_chain_cases()
+    mode, val = str(lc["lc_%d_mode" % i]), lc["lc_%d_val" % i].tolist()
+    orig, diff, res = (lc["lc_%d_%s" % (i, k)] for k in ("orig", "diff", "res"))
+    got = ctx.error_bound(orig[None], diff[None].copy(), mode, val)
+    np.testing.assert_array_equal(got[0], res)
+    # several frames per launch, one of them skipped (compress.py:315-319 skips slot 0 of a group)
+    o3 = np.stack([orig, orig[::-1].copy(), orig])
+    d3 = np.stack([diff, diff[::-1].copy(), diff])
+    got3 = ctx.error_bound(o3, d3.copy(), mode, val, np.array([0, 0, 1], np.uint8))
+    np.testing.assert_array_equal(got3[0], res)
+    np.testing.assert_array_equal(got3[1], coracle.error_bound_frame(o3[1], d3[1], mode, val))
+    np.testing.assert_array_equal(got3[2], diff)
+
+
 def test_error_bound_rejects_negative_pwrel(ctx):
     from tezip_amd._lib import TezipError
     o = np.zeros((1, 8, 8, 3), np.uint8)

@@ -12,6 +12,10 @@ from oracle import oracle as O
 
 H = np.load(os.path.join(GOLDEN, "ref_helpers.npz"))
 R = np.load(os.path.join(GOLDEN, "ref_runs.npz"))
+R2 = np.load(os.path.join(GOLDEN, "ref_runs2.npz"))   # DWP runs with windows of mixed length (round 3)
+LC = np.load(os.path.join(GOLDEN, "ref_long.npz"))    # error_bound of the reference on 12k..65k-element chains
+RUNS = {str(n): R for n in R["run_names"]}
+RUNS.update({str(n): R2 for n in R2["run_names"]})
 PRED = O.FnPredictor(fake_predictor.c0_image, fake_predictor.g_next)
 
 
@@ -20,6 +24,18 @@ def test_error_bound_matches_reference(i):
     mode, val = str(H["eb_%d_mode" % i]), H["eb_%d_val" % i].tolist()
     got = O.error_bound(H["eb_%d_orig" % i], H["eb_%d_diff" % i], mode, val)
     np.testing.assert_array_equal(got, H["eb_%d_res" % i])
+
+
+@pytest.mark.parametrize("i", range(int(LC["lc_n"])))
+def test_error_bound_long_chains_match_reference(i):
+    """Chains of 12,288 / 13,100 / 65,536 elements computed by the reference itself: runs shorter
+    than, equal to and far longer than the 64-element chunks and 1/8-chain segments of the HIP
+    quantiser (tests/golden/make_golden.py::_long_chains)."""
+    mode, val = str(LC["lc_%d_mode" % i]), LC["lc_%d_val" % i].tolist()
+    orig, diff, res = (LC["lc_%d_%s" % (i, k)] for k in ("orig", "diff", "res"))
+    for c in range(3):
+        got = O.error_bound(orig[..., c], diff[..., c], mode, val)
+        np.testing.assert_array_equal(got, res[..., c], err_msg="channel %d" % c)
 
 
 def test_error_bound_doc_kat():
@@ -88,13 +104,14 @@ def test_uint8_scale_identities():
 
 
 def _frames3(name):
-    f = R["run_%s_frames" % name]
+    f = RUNS[name]["run_%s_frames" % name]
     return f if f.ndim == 4 else np.repeat(f[..., None], 3, axis=-1)
 
 
-@pytest.mark.parametrize("name", [str(n) for n in R["run_names"]])
+@pytest.mark.parametrize("name", sorted(RUNS))
 def test_full_run_matches_reference(name):
     pre = "run_%s_" % name
+    R = RUNS[name]
     p, win, gray, entropy = (int(v) for v in R[pre + "params"])
     thr = float(R[pre + "thr"])
     frames = _frames3(name)
@@ -110,6 +127,17 @@ def test_full_run_matches_reference(name):
     # reference call pattern: one (1,2,..) predict per frame after the first (+p warm-ups)
     assert len(R[pre + "enc_calls"]) == frames.shape[0] - 1
     assert (R[pre + "enc_calls"][:, 1] == 2).all()
+
+
+def test_mixed_dwp_goldens_really_have_windows_of_mixed_length():
+    for name in (str(n) for n in R2["run_names"]):
+        pre = "run_%s_" % name
+        p = int(R2[pre + "params"][0])
+        f = R2[pre + "frames"]
+        kf = R2[pre + "key_frame"].reshape((f.shape[0], f.shape[1], f.shape[2], 3))
+        keys = [i for i in range(f.shape[0]) if kf[i].any()]
+        lens = set(np.diff(keys[p:]).tolist())
+        assert len(lens) >= 3, (name, keys)
 
 
 def test_short_sequences_rejected():
