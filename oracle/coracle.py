@@ -186,3 +186,21 @@ def act_probe(x):
     hs, th = np.empty_like(x), np.empty_like(x)
     lib().tzo_act_probe(_p(x), x.size, _p(hs), _p(th))
     return hs, th
+
+
+def encode_tail(delta_i16, entropy=True):
+    """compress.py:329-373 on an int16 delta stack of any size, through the C functions: spatial delta
+    over the whole flattened stack (+ the 1600 offset), bincount, table by count descending with ties
+    in ascending symbol order (the stable reverse sort of compress.py:356-359), remap.
+    Returns (payload int16[N], table int16[T] | None)."""
+    flat = np.ascontiguousarray(delta_i16, np.int16).reshape(-1)
+    if not entropy:
+        return spatial_delta(flat, 0), None
+    y = spatial_delta(flat, 1)
+    hist = histogram(y)
+    syms = np.nonzero(hist)[0]
+    order = sorted(zip(syms.tolist(), hist[syms].tolist()), key=lambda e: e[1], reverse=True)
+    table = np.array([s for s, _ in order], dtype=np.int16)
+    lut = np.arange(65536, dtype=np.int64) - 32768
+    lut[table.astype(np.int64) + 32768] = np.arange(len(table))
+    return lut_apply(y, lut.astype(np.int16)), table

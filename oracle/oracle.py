@@ -266,14 +266,22 @@ def encode_stream(frames_u8, ro, p, mode, bound, entropy=True):
         y = (OFFSET - sd.astype(np.int64)).astype(np.int16)
         table = build_table(y)
         payload = remap_enc(y, table)
-        tail = np.concatenate([table.astype(np.int64), [len(table)]])
     else:
         table = None
         payload = sd
-        tail = np.array([-1], dtype=np.int64)
-    trailer = np.concatenate([tail, [1, nt, h, w, 3], [p]]).astype(np.int64)
-    stream = np.concatenate([payload.astype(np.int64), trailer]).astype(np.int16)
+    stream = build_stream(payload, table, nt, h, w, p)
     return dict(stream=stream, delta=dm, sd=sd, table=table)
+
+
+def build_stream(payload, table, nt, h, w, p):
+    """compress.py:375-395: payload | table | len(table)  (or payload | -1), then the shape
+    (1, nt, H, W, 3) and PREPROCESS, everything as int16."""
+    if table is not None:
+        tail = np.concatenate([np.asarray(table).astype(np.int64), [len(table)]])
+    else:
+        tail = np.array([-1], dtype=np.int64)
+    trailer = np.concatenate([tail, [1, nt, h, w, 3], [p]]).astype(np.int16)
+    return np.concatenate([np.asarray(payload, dtype=np.int16).reshape(-1), trailer])
 
 
 def key_frame_stream(frames_u8, key):

@@ -95,8 +95,15 @@ def test_batch_invariance_of_the_rollout(ctx):
 
 def test_cfg4_full_length_on_one_gpu(ctx):
     """BASELINE configs[3] at its full size (320 frames of 1024x1024, eight 40-frame windows):
-    1.0e9 elements through every kernel with device-resident buffers; round trip within the bound."""
+    1.0e9 elements through every kernel with device-resident buffers.  The integer back half is
+    compared with the C ORACLE at this size -- spatial delta, 1600 offset, histogram, table, remap
+    and trailer of the whole 1,006,632,960-element stack (64-bit offsets, multi-block histogram
+    merge), payload and table byte for byte (compress.py:329-395) -- plus the quantiser of two whole
+    frames; then the round trip within the bound."""
     import torch
+    from oracle import coracle
+    from oracle import oracle as O
+    from tezip_amd import compress
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(4)
     nt, h, w = 320, 1024, 1024
@@ -110,13 +117,31 @@ def test_cfg4_full_length_on_one_gpu(ctx):
     del base
     ctx.prepare(1024, 1024, max_batch=8)
     payload = torch.empty(nt * h * w * 3, dtype=torch.int16, device=dev)
+    delta = torch.empty(nt * h * w * 3, dtype=torch.int16, device=dev)
     # this context runs on its OWN HIP stream: order it against torch's stream explicitly
     torch.cuda.synchronize()
     key, _ = ctx.rollout(frames, 0, 40)
     assert key.nonzero()[0].tolist() == list(range(0, 320, 40))
-    _, table, _ = ctx.encode("abs", [2.0], True, payload=payload)
+    _, table, _ = ctx.encode("abs", [2.0], True, payload=payload, delta_out=delta)
     ctx.synchronize()  # device outputs are asynchronous on the context's stream
     assert 0 < len(table) <= 1021 and int(payload.max()) < len(table) and int(payload.min()) >= 0
+    # --- the whole job's integer back half vs the C oracle
+    delta_h = delta.cpu().numpy()
+    ref_payload, ref_table = coracle.encode_tail(delta_h, True)
+    np.testing.assert_array_equal(table, ref_table)
+    payload_h = payload.cpu().numpy()
+    assert np.array_equal(payload_h, ref_payload)
+    stream = compress.build_stream(payload_h, table, (1, nt, h, w, 3), 0)
+    assert stream[-7 - len(table):].tobytes() == O.build_stream(ref_payload[:0], ref_table, nt, h, w, 0).tobytes()
+    del ref_payload, payload_h, stream
+    # --- quantiser of two whole frames (3 chains of 1,048,576 elements each) vs the C oracle
+    pred = ctx.get_predictions()
+    for f in (1, 279):
+        fr = frames[f].cpu().numpy()
+        raw = coracle.delta_frame(pred[f], fr)
+        got = delta_h[f * h * w * 3:(f + 1) * h * w * 3].reshape(h, w, 3)
+        np.testing.assert_array_equal(got, coracle.error_bound_frame(fr, raw, "abs", [2.0]), err_msg="frame %d" % f)
+    del pred, delta_h, delta
     keys = torch.zeros_like(frames)
     kidx = torch.from_numpy(key).to(dev)
     keys[kidx] = frames[kidx]

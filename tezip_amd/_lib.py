@@ -377,9 +377,10 @@ class Context:
         self._ck(self.lib.tz_byte_unshuffle(self.h, _ptr(planes), n, _ptr(out)))
         return out
 
-    def encode(self, mode, bound, entropy=True, payload=None, want_delta=False, shuffle=False):
+    def encode(self, mode, bound, entropy=True, payload=None, want_delta=False, shuffle=False, delta_out=None):
         """shuffle=True (not a reference format): `payload` then holds the two byte planes of the
-        int16 payload (same buffer size), see tz_byte_shuffle."""
+        int16 payload (same buffer size), see tz_byte_shuffle.  want_delta / delta_out (a host or
+        device buffer of nt*H*W*3 int16): also return the quantised delta stack."""
         nt, h, w = self._shape
         b0 = float(bound[0])
         b1 = float(bound[1]) if len(bound) > 1 else 0.0
@@ -390,7 +391,9 @@ class Context:
             payload = _RESULTS.empty(nt * h * w * 3, np.int16)
         table = np.zeros(TZ_MAX_TABLE, np.int16)
         tlen = C.c_int(0)
-        delta = np.empty((nt, h, w, 3), np.int16) if want_delta else None
+        delta = delta_out if delta_out is not None else (np.empty((nt, h, w, 3), np.int16) if want_delta else None)
+        if delta is not None and _numel(delta) != nt * h * w * 3:
+            raise ValueError("delta buffer holds %d elements, expected %d" % (_numel(delta), nt * h * w * 3))
         self._ck(self.lib.tz_encode(self.h, MODES[mode], b0, b1, int(bool(entropy)) | (2 if shuffle else 0), _ptr(payload), table.ctypes.data,
                                     C.byref(tlen), _ptr(delta)))
         t = table[: tlen.value].copy() if tlen.value >= 0 else None
