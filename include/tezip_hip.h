@@ -133,6 +133,23 @@ int tz_payload_get(tz_ctx* ctx, size_t offset, size_t count, int16_t* out);
  * over GPUs: the spatial delta and the histogram then need a carry / a sum across shards
  * (tz_spatial_delta with has_carry, tz_build_table, tz_remap). */
 int tz_encode_delta(tz_ctx* ctx, int mode, double b0, double b1, int16_t* delta_out);
+/* tz_encode in two phases, for jobs whose frame windows are sharded over GPUs (the
+ * reference is single-process).  The spatial delta runs over the whole flattened stack
+ * (compress.py:339) and the rank table comes from the global histogram (compress.py:354-361), so a
+ * shard runs compress.py:292-355 on its own frames (begin), the ranks exchange one carry element
+ * and sum the 2111 counters, and the shard finishes compress.py:356-373 with the global table
+ * (finish).  Same kernels as tz_encode.
+ * begin: hist (host, TZ_NBINS counters, may be NULL when entropy == 0) receives this shard's counts
+ * taken WITHOUT a carry; edge[0], edge[1] (host) the first and the last element of the shard's
+ * quantised delta stack.  edge[1] is the carry of the next shard; with its own carry c a shard moves
+ * its first symbol in the histogram from 1600 - edge[0] to 1600 - (int16)(c - edge[0]).
+ * finish: has_carry/carry as in tz_spatial_delta; table_len >= 0: remap with `table` (the table of the
+ * summed histogram, tz_build_table), -1: no remap (must match begin's entropy flag); payload NULL: the
+ * payload stays in the context (tz_payload_get). */
+int tz_encode_begin(tz_ctx* ctx, int mode, double b0, double b1, int entropy, unsigned long long* hist,
+                    int16_t* edge);
+int tz_encode_finish(tz_ctx* ctx, int has_carry, int16_t carry, const int16_t* table, int table_len,
+                     int16_t* payload);
 /* ---- decoder back half (decompress.py:203-256): payload (+table) -> nt*H*W*3 uint8 frames,
  * using the prediction stack of the last tz_rollout_decode.  payload_len (elements) must be
  * nt*H*W*3 of that rollout: the reference fails at its reshape otherwise (decompress.py:240). */

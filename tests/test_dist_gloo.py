@@ -56,25 +56,28 @@ class OracleEngine:
         from oracle import coracle, oracle
         self.O, self.C, self.pred = oracle, coracle, pred
 
-    def encode_delta(self, frames, warm_up, window, mode, bound):
+    def encode_begin(self, frames, warm_up, window, mode, bound, entropy):
+        """What tz_rollout + tz_encode_begin do: symbols of the shard taken WITHOUT a carry, their
+        histogram, first / last element of the quantised delta stack."""
         ro = self.O.rollout(frames, warm_up, window, None, self.pred)
-        enc = self.O.encode_stream(frames, ro, warm_up, mode, bound, entropy=False)
-        return ro["key"], enc["delta"].reshape(-1)
+        d = self.O.encode_stream(frames, ro, warm_up, mode, bound, entropy=False)["delta"].reshape(-1)
+        self.entropy, self.first = entropy, int(d[0])
+        self.y = self.C.spatial_delta(d, 1 if entropy else 0)
+        hist = self.C.histogram(self.y).astype(np.uint64) if entropy else None
+        return ro["key"], hist, int(d[0]), int(d[-1])
 
-    def spatial_delta(self, d, carry, offset):
-        if carry is None:
-            y = self.C.spatial_delta(d, offset)
-        else:
-            y = self.C.spatial_delta(np.concatenate([[carry], d]).astype(np.int16), offset)[1:]
-        return y, (self.C.histogram(y).astype(np.uint64) if offset else None)
+    def encode_finish(self, carry, table):
+        """tz_encode_finish: the first symbol is re-made with the carry, then the remap."""
+        y = self.y.copy()
+        if carry is not None:
+            sd = np.int16(np.int64(carry) - self.first)
+            y[0] = np.int16(1600 - np.int64(sd)) if self.entropy else sd
+        return self.O.remap_enc(y, table) if table is not None else y
 
     def build_table(self, hist):
         syms = [int(s) for s in np.nonzero(hist)[0]]
         syms.sort(key=lambda s: int(hist[s]), reverse=True)
         return np.array(syms, np.int16)
-
-    def remap(self, y, table):
-        return self.O.remap_enc(y, table)
 
     def decode_prepare(self, key_frames, warm_up):
         self.key_frames = key_frames
@@ -149,34 +152,53 @@ def _worker(rank, world, port, p, window, mode, bound, entropy):
         dist.destroy_process_group()
 
 
-def _failing_worker(rank, world, port):
+def _failing_worker(rank, world, port, stage):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path[:0] = [os.path.dirname(here), os.path.join(here, "golden")]
     import torch.distributed as dist
+    from oracle import oracle as O
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
         frames, pred = _case()
         eng = OracleEngine(pred)
+
+        def boom(*a, **k):
+            raise MemoryError("injected failure on rank 1 (%s)" % stage)
+        decode = stage in ("decode_prepare", "undelta", "reconstruct")
         if rank == 1:
-            def boom(*a, **k):
-                raise MemoryError("injected failure on rank 1")
-            eng.encode_delta = boom
+            if stage == "undelta":      # the first undelta is the probe of stage 1: fail the SECOND one
+                real, calls = eng.undelta, []
+
+                def second(*a, **k):
+                    calls.append(1)
+                    return real(*a, **k) if len(calls) == 1 else boom()
+                eng.undelta = second
+            else:
+                setattr(eng, stage, boom)
         try:
-            tzdist.compress_sharded(eng, frames, 0, 4, "abs", [0.0], True)
+            if decode:
+                ref = O.compress_oracle(frames, 0, 4, None, "abs", [0.0], pred, True)
+                pl, tb, _, _ = O.parse_stream(ref["stream"])
+                tzdist.decompress_sharded(eng, ref["key_frame"].reshape(frames.shape), pl, tb, 0)
+            else:
+                tzdist.compress_sharded(eng, frames, 0, 4, "abs", [0.0], True)
         except MemoryError:
             assert rank == 1
         except RuntimeError as e:  # the healthy rank learns of it instead of hanging in a collective
-            assert rank == 0 and "rank(s) [1]" in str(e)
+            assert rank == 0 and "failed on" in str(e), str(e)
         else:
             raise AssertionError("a failed rank went unnoticed")
     finally:
         dist.destroy_process_group()
 
 
-def test_a_failing_rank_stops_every_rank():
+@pytest.mark.parametrize("stage", ["encode_begin", "build_table", "encode_finish", "decode_prepare", "undelta", "reconstruct"])
+def test_a_failing_rank_stops_every_rank(stage):
+    """A failure in ANY compute stage between two collectives (not only the first one) reaches the
+    other ranks through the next collective: nobody waits in an all-reduce or a receive."""
     import torch.multiprocessing as mp
-    mp.spawn(_failing_worker, args=(2, _free_port()), nprocs=2, join=True)
+    mp.spawn(_failing_worker, args=(2, _free_port(), stage), nprocs=2, join=True)
 
 
 def _free_port():

@@ -137,6 +137,31 @@ def test_spatial_delta_histogram_and_inverse(ctx, n, offset):
         np.testing.assert_array_equal(ctx.spatial_undelta(sd2.copy(), carry=int(x[k - 1])), x[k:])
 
 
+@pytest.mark.parametrize("kind", ["wide", "uniform", "spikes", "constant"])
+def test_histogram_of_heavy_tailed_symbols(ctx, kind):
+    """The block-private histogram keeps the 128 bins around the centre symbol in interleaved copies and
+    sends everything farther out through a rarely taken path: distributions that live out there --
+    sigma 100, uniform over the whole delta range, isolated +-255 jumps in flat data, one single symbol --
+    must count exactly (compress.py:354 bincount)."""
+    rng = np.random.default_rng(31)
+    n = 3 * 64 * 64 * 7 + 5
+    if kind == "wide":
+        x = np.clip(np.round(rng.normal(0, 100, n)), -255, 255)
+    elif kind == "uniform":
+        x = rng.integers(-255, 256, n)
+    elif kind == "spikes":
+        x = np.zeros(n)
+        x[rng.integers(0, n, 200)] = rng.choice([-255, 255, 70, -64, 64, -65, 65, 63], 200)
+    else:
+        x = np.full(n, 17)
+    x = x.astype(np.int16)
+    hist = np.zeros(2111, np.uint64)
+    y = ctx.spatial_delta(x, 1, hist=hist)
+    np.testing.assert_array_equal(y, coracle.spatial_delta(x, 1))
+    np.testing.assert_array_equal(hist, coracle.histogram(y).astype(np.uint64))
+    assert int(hist.sum()) == n
+
+
 def test_undelta_wraparound_matches_reference_loop(ctx):
     rng = np.random.default_rng(4)
     s = rng.integers(-32768, 32768, 10007).astype(np.int16)

@@ -55,6 +55,8 @@ _SIGS = {
     "tz_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "tz_host_free": (C.c_int, [C.c_void_p]),
     "tz_encode_delta": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]),
+    "tz_encode_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "tz_encode_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int16, C.c_void_p, C.c_int, C.c_void_p]),
     "tz_decode_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "tz_delta_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "tz_error_bound": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -398,6 +400,35 @@ class Context:
                                     C.byref(tlen), _ptr(delta)))
         t = table[: tlen.value].copy() if tlen.value >= 0 else None
         return payload, t, delta
+
+    def encode_begin(self, mode, bound, entropy=True):
+        """First phase of a window-sharded encode (tz_encode_begin): -> (hist uint64[2111] | None,
+        first, last) where hist counts this shard's symbols taken without a carry and first / last
+        are the edge elements of its quantised delta stack.  The symbols stay in the context."""
+        b1 = float(bound[1]) if len(bound) > 1 else 0.0
+        hist = np.zeros(TZ_NBINS, np.uint64) if entropy else None
+        edge = np.zeros(2, np.int16)
+        self._ck(self.lib.tz_encode_begin(self.h, MODES[mode], float(bound[0]), b1, int(bool(entropy)),
+                                          None if hist is None else hist.ctypes.data, edge.ctypes.data))
+        return hist, int(edge[0]), int(edge[1])
+
+    def encode_finish(self, carry, table, out=None):
+        """Second phase (tz_encode_finish): carry = last delta element of the previous shard (None for
+        the first shard), table = the table of the summed histogram (None: no remap).  out: host or
+        device buffer, "resident" keeps the payload in the context (payload_get)."""
+        nt, h, w = self._shape
+        resident = isinstance(out, str) and out == "resident"
+        if resident:
+            out = None
+        elif out is None:
+            out = _RESULTS.empty(nt * h * w * 3, np.int16)
+        tb = None if table is None else np.ascontiguousarray(table, np.int16)
+        self._ck(self.lib.tz_encode_finish(self.h, int(carry is not None), int(carry or 0), _ptr(tb),
+                                           -1 if tb is None else len(tb), _ptr(out)))
+        return out
+
+    def stream_ptr(self):
+        return self.lib.tz_ctx_stream(self.h)
 
     def encode_delta(self, mode, bound, out=None):
         nt, h, w = self._shape

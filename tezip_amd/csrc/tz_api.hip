@@ -1025,10 +1025,44 @@ static int remap_out(tz_ctx* ctx, const int16_t* d_sd, size_t N, const int16_t* 
     return TZ_OK;
 }
 
+// compress.py:292-355 on the context-resident rollout: delta, quantiser, spatial delta over the whole
+// flattened stack (no carry), 1600 offset + bincount when `entropy`.  d_sym receives the symbols (or
+// the raw spatial delta), d_hist the counters (zeroed here), d_edge[0..1] the first and the last
+// element of the quantised delta stack (what a shard boundary needs).  d_delta_tap
+// (may be NULL): the quantised delta stack is also wanted there.
+static int encode_front(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t* d_delta_tap, int16_t* d_sym,
+                        unsigned long long* d_hist, int16_t* d_edge) {
+    const int nt = ctx->nt, H = ctx->H, W = ctx->W;
+    const size_t N = (size_t)nt * H * W * 3;
+    void *d_mask = nullptr, *d_delta = d_delta_tap;
+    TZ_TRY(tz_pool_alloc(ctx, nt, &d_mask));
+    TZ_TRY(tz_upload(ctx, d_mask, ctx->group_first.data(), nt));
+    if (entropy) TZ_HIP(ctx, hipMemsetAsync(d_hist, 0, TZ_NBINS * sizeof(unsigned long long), ctx->stream));
+    // error_bound returns its input untouched in these cases (compress.py:24,35)
+    const bool lossless = b0 == 0.0 || (mode == TZ_MODE_ABSREL && b1 == 0.0);
+    bool fused = false;
+    // lossless and nobody asked for the delta stack: one fused pass (compress.py:292-355)
+    if (lossless && !d_delta_tap)
+        TZ_TRY(tzk_delta_sd_fused(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt, H, W, ctx->Hp, ctx->Wp,
+                                  entropy ? 1 : 0, d_sym, entropy ? d_hist : nullptr, d_edge, &fused));
+    if (fused) return TZ_OK;
+    if (!d_delta) TZ_TRY(tz_pool_alloc(ctx, N * 2, &d_delta));
+    // compress.py:292-314
+    TZ_TRY(tzk_delta(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt, H, W, ctx->Hp, ctx->Wp, (int16_t*)d_delta));
+    // compress.py:315-319
+    TZ_TRY(tzk_error_bound(ctx, ctx->d_frames, (int16_t*)d_delta, ctx->quant_skip.data(), nt, H, W, mode, b0, b1));
+    // compress.py:339-355
+    TZ_TRY(tzk_spatial_delta(ctx, (const int16_t*)d_delta, N, 0, 0, entropy ? 1 : 0, d_sym, entropy ? d_hist : nullptr));
+    TZ_HIP(ctx, hipMemcpyAsync(d_edge, d_delta, 2, hipMemcpyDeviceToDevice, ctx->stream));
+    TZ_HIP(ctx, hipMemcpyAsync(d_edge + 1, (const int16_t*)d_delta + (N - 1), 2, hipMemcpyDeviceToDevice, ctx->stream));
+    return TZ_OK;
+}
+
 extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t* payload, int16_t* table,
                          int* table_len, int16_t* delta_out) {
     if (!ctx || !table_len || ((entropy & 1) && !table)) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode needs a tz_rollout first");
+    ctx->enc_pending = false;
     if (!payload) {  // keep the payload in the context: it leaves through tz_payload_get
         const size_t n = (size_t)ctx->nt * ctx->H * ctx->W * 3;
         TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_payload, &ctx->cap_payload, n * 2));
@@ -1036,14 +1070,13 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
         payload = ctx->d_payload;
     }
     if (mode < 0 || mode > 3) return tz_fail(ctx, TZ_ERR_INVALID, "unknown error-bound mode %d", mode);
-    const int nt = ctx->nt, H = ctx->H, W = ctx->W;
-    const size_t N = (size_t)nt * H * W * 3;
+    const size_t N = (size_t)ctx->nt * ctx->H * ctx->W * 3;
     const bool shuffle = (entropy & 2) != 0;  // opt-in byte planes (not a reference format)
     entropy &= 1;
     if (shuffle && (N & 7)) return tz_fail(ctx, TZ_ERR_INVALID, "byte shuffle needs a multiple of 8 elements");
     std::vector<tz_out> outs;
     tz_out o_pay, o_delta, o_final;
-    void *d_delta = nullptr, *d_mask = nullptr, *d_hist = nullptr, *d_sd = nullptr;
+    void *d_hist = nullptr, *d_sd = nullptr, *d_edge = nullptr;
     int rc = tz_dev_out(ctx, payload, N * 2, &o_pay);
     if (rc == TZ_OK && shuffle) {  // the stages below write the plain payload to a scratch buffer instead
         o_final = o_pay;
@@ -1053,41 +1086,16 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
     }
     if (rc == TZ_OK && delta_out) {
         rc = tz_dev_out(ctx, delta_out, N * 2, &o_delta);
-        if (rc == TZ_OK) {
-            outs.push_back(o_delta);
-            d_delta = o_delta.dev;
-        }
-    } else if (rc == TZ_OK) {
-        rc = tz_pool_alloc(ctx, N * 2, &d_delta);
+        if (rc == TZ_OK) outs.push_back(o_delta);
     }
-    if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_mask);
-    if (rc == TZ_OK) rc = tz_upload(ctx, d_mask, ctx->group_first.data(), nt);
-    // error_bound returns its input untouched in these cases (compress.py:24,35)
-    const bool lossless = b0 == 0.0 || (mode == TZ_MODE_ABSREL && b1 == 0.0);
-    bool fused = false;
+    if (rc == TZ_OK) rc = tz_pool_alloc(ctx, 16, &d_edge);
     if (rc == TZ_OK && entropy) {
         rc = tz_pool_alloc(ctx, TZ_NBINS * sizeof(unsigned long long), &d_hist);
         if (rc == TZ_OK) rc = tz_pool_alloc(ctx, N * 2, &d_sd);
-        if (rc == TZ_OK) {
-            hipError_t e = hipMemsetAsync(d_hist, 0, TZ_NBINS * sizeof(unsigned long long), ctx->stream);
-            if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "hist memset: %s", hipGetErrorString(e));
-        }
     }
-    // lossless and nobody asked for the delta stack: one fused pass (compress.py:292-355)
-    if (rc == TZ_OK && lossless && !delta_out)
-        rc = tzk_delta_sd_fused(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt, H, W, ctx->Hp, ctx->Wp,
-                                entropy ? 1 : 0, entropy ? (int16_t*)d_sd : (int16_t*)o_pay.dev,
-                                (unsigned long long*)d_hist, &fused);
-    if (rc == TZ_OK && !fused) {
-        // compress.py:292-314
-        rc = tzk_delta(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt, H, W, ctx->Hp, ctx->Wp, (int16_t*)d_delta);
-        // compress.py:315-319
-        if (rc == TZ_OK) rc = tzk_error_bound(ctx, ctx->d_frames, (int16_t*)d_delta, ctx->quant_skip.data(), nt, H, W, mode, b0, b1);
-        // compress.py:339-355
-        if (rc == TZ_OK)
-            rc = tzk_spatial_delta(ctx, (const int16_t*)d_delta, N, 0, 0, entropy ? 1 : 0,
-                                   entropy ? (int16_t*)d_sd : (int16_t*)o_pay.dev, (unsigned long long*)d_hist);
-    }
+    if (rc == TZ_OK)
+        rc = encode_front(ctx, mode, b0, b1, entropy, delta_out ? (int16_t*)o_delta.dev : nullptr,
+                          entropy ? (int16_t*)d_sd : (int16_t*)o_pay.dev, (unsigned long long*)d_hist, (int16_t*)d_edge);
     if (rc == TZ_OK && !entropy) {
         *table_len = -1;
     } else if (rc == TZ_OK) {
@@ -1106,6 +1114,75 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
     }
     outs.push_back(o_pay);
     if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+// ---- tz_encode in two phases, for jobs whose frame windows are sharded over GPUs.
+// The spatial delta runs over the WHOLE flattened stack (compress.py:339) and the rank table comes
+// from the GLOBAL histogram (compress.py:354-361): a shard therefore runs everything up to its own
+// symbols and counters (begin), the ranks exchange one carry element and sum 2111 counters, and
+// the shard finishes with the global table (finish).  Same kernels as tz_encode; the symbols stay in
+// the context's resident payload buffer between the two calls and are remapped in place.
+extern "C" int tz_encode_begin(tz_ctx* ctx, int mode, double b0, double b1, int entropy, unsigned long long* hist,
+                               int16_t* edge) {
+    if (!ctx || !edge || (entropy && !hist)) return TZ_ERR_INVALID;
+    if (!ctx->have_rollout || ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode_begin needs a tz_rollout first");
+    if (mode < 0 || mode > 3) return tz_fail(ctx, TZ_ERR_INVALID, "unknown error-bound mode %d", mode);
+    ctx->enc_pending = false;
+    const size_t N = (size_t)ctx->nt * ctx->H * ctx->W * 3;
+    TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_payload, &ctx->cap_payload, N * 2));
+    ctx->payload_len = N;
+    void *d_hist = nullptr, *d_edge = nullptr;
+    int rc = tz_pool_alloc(ctx, 16, &d_edge);
+    if (rc == TZ_OK && entropy) rc = tz_pool_alloc(ctx, TZ_NBINS * sizeof(unsigned long long), &d_hist);
+    if (rc == TZ_OK)
+        rc = encode_front(ctx, mode, b0, b1, entropy ? 1 : 0, nullptr, ctx->d_payload, (unsigned long long*)d_hist, (int16_t*)d_edge);
+    if (rc == TZ_OK) {
+        hipError_t e = hipMemcpyAsync(edge, d_edge, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && entropy)
+            e = hipMemcpyAsync(hist, d_hist, TZ_NBINS * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "tz_encode_begin: %s", hipGetErrorString(e));
+    }
+    if (rc == TZ_OK) {
+        ctx->enc_pending = true;
+        ctx->enc_entropy = entropy != 0;
+        ctx->enc_first = edge[0];
+    }
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
+extern "C" int tz_encode_finish(tz_ctx* ctx, int has_carry, int16_t carry, const int16_t* table, int table_len,
+                                int16_t* payload) {
+    if (!ctx) return TZ_ERR_INVALID;
+    if (!ctx->enc_pending) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode_finish needs a tz_encode_begin first");
+    if (ctx->enc_entropy != (table_len >= 0) || (table_len > 0 && !table) || table_len > TZ_MAX_TABLE)
+        return tz_fail(ctx, TZ_ERR_INVALID, "tz_encode_finish: table does not match the entropy flag of tz_encode_begin");
+    const size_t N = ctx->payload_len;
+    int rc = TZ_OK;
+    if (has_carry) {
+        // the first element of the shard: sd = carry - x[0] instead of x[0] (compress.py:73-77 across the boundary)
+        const int16_t sd = (int16_t)(carry - ctx->enc_first);
+        const int16_t y = ctx->enc_entropy ? (int16_t)(TZ_OFFSET - sd) : sd;
+        rc = tz_upload(ctx, ctx->d_payload, &y, 2);
+    }
+    std::vector<tz_out> outs;
+    tz_out o;
+    if (rc == TZ_OK && payload) rc = tz_dev_out(ctx, payload, N * 2, &o);
+    if (rc == TZ_OK && ctx->enc_entropy) {
+        std::vector<int16_t> lut;
+        rc = build_enc_lut(ctx, table, table_len, &lut);
+        if (rc == TZ_OK && payload) rc = remap_out(ctx, ctx->d_payload, N, lut.data(), &o);                 // compress.py:369
+        else if (rc == TZ_OK) rc = tzk_lut(ctx, ctx->d_payload, N, lut.data(), 0, ctx->d_payload);           // in place: stays resident
+    } else if (rc == TZ_OK && payload) {
+        hipError_t e = hipMemcpyAsync(o.dev, ctx->d_payload, N * 2, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "payload copy: %s", hipGetErrorString(e));
+    }
+    if (payload) outs.push_back(o);
+    if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    if (rc == TZ_OK) ctx->enc_pending = false;
     tz_pool_release_all(ctx);
     return rc;
 }
@@ -1209,22 +1286,20 @@ extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, size_t payload_len
     std::vector<tz_out> outs;
     tz_out o;
     const void* d_pay = nullptr;
-    void *d_sd = nullptr, *d_diff = nullptr, *d_mask = nullptr;
+    void *d_diff = nullptr, *d_mask = nullptr;
     int rc = tz_dev_in(ctx, payload, N * 2, &d_pay);
     if (rc == TZ_OK) rc = tz_dev_out(ctx, frames_out, N, &o);
     if (rc == TZ_OK) outs.push_back(o);
     if (rc == TZ_OK) rc = tz_pool_alloc(ctx, N * 2, &d_diff);
     if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_mask);
     if (rc == TZ_OK) rc = tz_upload(ctx, d_mask, ctx->key_mask.data(), nt);
-    const int16_t* sd = (const int16_t*)d_pay;
-    if (rc == TZ_OK && table_len >= 0) {  // decompress.py:203-236
+    if (rc == TZ_OK && table_len >= 0) {  // decompress.py:203-236 fused into the scan of 240-245
         std::vector<int16_t> lut;
         build_dec_lut(table, table_len, 1, &lut);
-        rc = tz_pool_alloc(ctx, N * 2, &d_sd);
-        if (rc == TZ_OK) rc = tzk_lut(ctx, (const int16_t*)d_pay, N, lut.data(), 1, (int16_t*)d_sd);
-        sd = (const int16_t*)d_sd;
+        rc = tzk_unmap_undelta(ctx, (const int16_t*)d_pay, N, lut.data(), 1, (int16_t*)d_diff);
+    } else if (rc == TZ_OK) {
+        rc = tzk_undelta(ctx, (const int16_t*)d_pay, N, 0, 0, (int16_t*)d_diff);  // decompress.py:240-245
     }
-    if (rc == TZ_OK) rc = tzk_undelta(ctx, sd, N, 0, 0, (int16_t*)d_diff);  // decompress.py:240-245
     if (rc == TZ_OK)                                                        // decompress.py:252-256,269
         rc = tzk_reconstruct(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, (const int16_t*)d_diff, nt, H, W,
                              ctx->Hp, ctx->Wp, (uint8_t*)o.dev);

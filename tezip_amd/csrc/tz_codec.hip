@@ -2,6 +2,8 @@
 // HBM-bound integer/byte work: wide coalesced accesses (16 B per lane where the layout
 // allows), LDS-privatised histogram, grid-stride launches of ~8 blocks per CU.
 // Reference semantics are cited per kernel (paths into /root/reference/src).
+#include <algorithm>
+
 #include "tz_internal.h"
 
 static constexpr int kBlocksPerCU = 8;
@@ -651,47 +653,143 @@ int tzk_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8
     return TZ_OK;
 }
 
+// ------------------------------------------------------------- block-private symbol histogram
+// compress.py:354 (bincount of the symbols 1600 - sd).  The symbols of a prediction residual pile up
+// on a handful of values around the centre c (1600, or 0 without the offset), so a plain LDS
+// histogram spends its time serialising atomics on the same few words (rounds 1-2: one copy per wave,
+// 4.7 M bank-conflict cycles per 7.9 M LDS operations, the spatial-delta kernel ran at 41 % of HBM
+// against 74 % without the histogram).  Now:
+//   * the centre symbol never touches the bins: a wave counts it with a ballot into a scalar register;
+//   * the 128 bins around c have 8 copies per wave, interleaved as [bin][copy] with copy = lane & 7, so
+//     that a wave's 64 lanes spread over all 32 banks (bank = (bin % 4) * 8 + copy) and only the ~2 lanes
+//     that share copy AND bin % 4 meet in a bank;
+//   * everything else (rare) goes to one full-range copy per block.
+// flush() folds the copies into the full-range one and adds its non-zero bins to the global counters.
+static constexpr int HC_HALF = 64, HC_BINS = 2 * HC_HALF, HC_COPIES = 8;
+static constexpr int HC_WAVE = (HC_BINS + 1) * HC_COPIES;   // + one junk bin per copy (see hist_add8)
+// Blocks of the histogram kernels are 1024 threads, two per CU: what a block's flush costs is global --
+// every block adds each of its non-zero bins to the same ~450 counters, and same-address atomics from
+// different workgroups are served one after the other (about 12 ns each): with 2048 blocks of 256
+// threads that was 25 us of a 76 us kernel, whatever the LDS part did.
+static constexpr int HB_THREADS = 1024, HB_WAVES = HB_THREADS / 64, HB_GRID = 2 * kCUs;
+static constexpr int HL_CENTRAL = 0, HL_FULL = HB_WAVES * HC_WAVE, HL_SINK = HL_FULL + TZ_NBINS + 1, HL_WORDS = HL_SINK + 64;
+struct HistLds {
+    // [waves][bin][copy] | full range | one sink word per lane
+    unsigned w[HL_WORDS];
+};
+
+struct HistAcc {
+    unsigned n0 = 0;   // wave-uniform count of the centre symbol
+};
+
+__device__ __forceinline__ void hist_clear(HistLds& h) {
+    for (int k = threadIdx.x; k < HL_WORDS; k += blockDim.x) h.w[k] = 0;
+    __syncthreads();
+}
+
+// Eight symbols of one lane, packed two per dword.  The update is ONE unconditional LDS atomic per
+// element in straight-line code (a branch per element cost more than the atomics it saved: the
+// spatial-delta kernel is as much VALU-issue as HBM bound): the centre symbol goes to the lane's own
+// sink word (it is counted by the ballot), symbols within +-64 of the centre to [bin][copy], anything
+// farther to the junk bin of the copy -- and, in a branch the wave takes only when one of its 512
+// symbols is that far out, to the full-range bins.
+__device__ __forceinline__ void hist_add8(HistLds& h, HistAcc& acc, const unsigned* Y, int c) {
+    const int lane = threadIdx.x & 63;
+    const int base = HL_CENTRAL + (int)(threadIdx.x >> 6) * HC_WAVE + (lane & 7), sink = HL_SINK + lane;
+    unsigned far = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int y = (k & 1) ? ((int)Y[k >> 1] >> 16) : (int)(short)(Y[k >> 1] & 0xFFFFu);
+        const bool hot = y == c;
+        acc.n0 += (unsigned)__popcll(__ballot(hot));
+        const unsigned rel = (unsigned)(y - (c - HC_HALF));
+        const unsigned idx = min(rel, (unsigned)HC_BINS);
+        far |= idx >> 7;   // HC_BINS == 128
+        atomicAdd(&h.w[hot ? sink : base + (int)idx * HC_COPIES], 1u);
+    }
+    if (__any(far != 0)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int y = (k & 1) ? ((int)Y[k >> 1] >> 16) : (int)(short)(Y[k >> 1] & 0xFFFFu);
+            if ((unsigned)(y - (c - HC_HALF)) >= (unsigned)HC_BINS && (unsigned)y < (unsigned)TZ_NBINS) atomicAdd(&h.w[HL_FULL + y], 1u);
+        }
+    }
+}
+static_assert(HC_BINS == 128, "hist_add8 takes the far flag from bit 7 of the clamped index");
+static_assert(HL_WORDS * 4 <= 80 * 1024, "two histogram blocks per CU must fit the 160 KB of LDS");
+
+// every thread of the block calls this (after its last add)
+__device__ __forceinline__ void hist_flush(HistLds& h, const HistAcc& a, int c, unsigned long long* __restrict__ hist) {
+    if ((threadIdx.x & 63) == 0 && a.n0 && c >= 0 && c < TZ_NBINS) atomicAdd(&h.w[HL_FULL + c], a.n0);
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    for (int b = threadIdx.x; b < HC_BINS; b += blockDim.x) {
+        const int y = c - HC_HALF + b;
+        unsigned t = 0;
+        for (int w = 0; w < nw; ++w)
+#pragma unroll
+            for (int k = 0; k < HC_COPIES; ++k) t += h.w[HL_CENTRAL + w * HC_WAVE + b * HC_COPIES + k];
+        if (t && y >= 0 && y < TZ_NBINS) atomicAdd(&h.w[HL_FULL + y], t);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < TZ_NBINS; k += blockDim.x) {
+        const unsigned v = h.w[HL_FULL + k];
+        if (v) atomicAdd(&hist[k], (unsigned long long)v);
+    }
+}
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b) {   // two int16 lanes, wrap-around
+    const short2v r = __builtin_bit_cast(short2v, a) - __builtin_bit_cast(short2v, b);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+// spatial delta of 8 consecutive int16 (V, two per dword) given the element in front of them:
+// sd[k] = x[k-1] - x[k]; symbols y = 1600 - sd when `offs` = (1600, 1600), y = sd when offs is 0 and `negate`
+// is false ... both forms are y = offs - (P - V) resp. P - V; P is V shifted up by one element.
+__device__ __forceinline__ void sdelta8(const uint4 V, unsigned prev16, bool apply_offset, unsigned* Y) {
+    const unsigned P0 = __builtin_amdgcn_alignbit(V.x, prev16 << 16, 16);
+    const unsigned P1 = __builtin_amdgcn_alignbit(V.y, V.x, 16);
+    const unsigned P2 = __builtin_amdgcn_alignbit(V.z, V.y, 16);
+    const unsigned P3 = __builtin_amdgcn_alignbit(V.w, V.z, 16);
+    const unsigned C = ((unsigned)TZ_OFFSET << 16) | (unsigned)TZ_OFFSET;
+    Y[0] = pk_sub(P0, V.x);
+    Y[1] = pk_sub(P1, V.y);
+    Y[2] = pk_sub(P2, V.z);
+    Y[3] = pk_sub(P3, V.w);
+    if (apply_offset) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Y[j] = pk_sub(C, Y[j]);
+    }
+}
+
 // ------------------------------------------------------- spatial delta (+offset, histogram)
 // compress.py:73-77: out[0]=in[0], out[i]=in[i-1]-in[i] over the whole flat array (int16
 // wrap); compress.py:348: y = 1600 - sd; compress.py:354: bincount(y).
 // 8 elements (16 B) per lane; the element before a lane's first comes from one extra 2-byte
-// load (same cache line).  Histogram: per-block LDS bins, the dominant symbol (sd == 0) is
-// counted in registers and added once per wave, the rest with LDS atomics; blocks flush
-// non-zero bins to the global uint64 histogram.
-__global__ __launch_bounds__(256) void k_sdelta(const int16_t* __restrict__ in, size_t n, int has_carry, int16_t carry,
+// load (same cache line).  Histogram: HistLds / HistAcc above.
+template <bool HIST>
+__global__ __launch_bounds__(HIST ? HB_THREADS : 256) void k_sdelta(const int16_t* __restrict__ in, size_t n, int has_carry, int16_t carry,
                                                 int apply_offset, int16_t* __restrict__ out,
                                                 unsigned long long* __restrict__ hist) {
-    __shared__ unsigned lhs[4][TZ_NBINS + 1];  // one sub-histogram per wave: 4x less atomic contention
-    unsigned* lh = lhs[threadIdx.x >> 6];
-    const bool do_hist = hist != nullptr;
-    if (do_hist) {
-        for (int k = threadIdx.x; k < 4 * (TZ_NBINS + 1); k += 256) (&lhs[0][0])[k] = 0;
-        __syncthreads();
-    }
-    const int dominant = apply_offset ? TZ_OFFSET : 0;
-    unsigned ndom = 0;
+    __shared__ unsigned hraw[HIST ? HL_WORDS : 1];
+    HistLds& hl = *(HistLds*)hraw;
+    if (HIST) hist_clear(hl);
+    const int centre = apply_offset ? TZ_OFFSET : 0;
+    HistAcc acc;
     size_t n8 = n / 8;
     size_t stride = (size_t)gridDim.x * blockDim.x;
-    const short8* in8 = (const short8*)in;
-    short8* out8 = (short8*)out;
+    const uint4* in8 = (const uint4*)in;
+    uint4* out8 = (uint4*)out;
+    const unsigned short* inu = (const unsigned short*)in;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
-        short8 v = in8[i];
-        short prev = i ? in[8 * i - 1] : (has_carry ? carry : (short)0);
-        short8 r;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            short cur = v[k];
-            short sd = (short)(prev - cur);
-            if (i == 0 && k == 0 && !has_carry) sd = cur;
-            short y = apply_offset ? (short)(TZ_OFFSET - sd) : sd;
-            r[k] = y;
-            prev = cur;
-            if (do_hist) {
-                if (y == dominant) ++ndom;
-                else if (y >= 0 && y < TZ_NBINS) atomicAdd(&lh[y], 1u);
-            }
-        }
-        out8[i] = r;
+        const uint4 v = in8[i];
+        // the element in front; without one (start of the stream, no carry) sd[0] = x[0], i.e. "prev" = 2 x[0]
+        unsigned prev = i ? (unsigned)inu[8 * i - 1] : (has_carry ? (unsigned)(unsigned short)carry : ((v.x << 1) & 0xFFFFu));
+        unsigned Y[4];
+        sdelta8(v, prev, apply_offset != 0, Y);
+        out8[i] = make_uint4(Y[0], Y[1], Y[2], Y[3]);
+        if (HIST) hist_add8(hl, acc, Y, centre);
     }
     // tail (n % 8 elements) by the first lanes of block 0
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
@@ -700,36 +798,27 @@ __global__ __launch_bounds__(256) void k_sdelta(const int16_t* __restrict__ in, 
         short sd = i ? (short)(in[i - 1] - cur) : (has_carry ? (short)(carry - cur) : cur);
         short y = apply_offset ? (short)(TZ_OFFSET - sd) : sd;
         out[i] = y;
-        if (do_hist && y >= 0 && y < TZ_NBINS) atomicAdd(&lh[y], 1u);
+        if (HIST && y >= 0 && y < TZ_NBINS) atomicAdd(&hl.w[HL_FULL + y], 1u);
     }
-    if (do_hist) {
-        for (int s = 32; s >= 1; s >>= 1) ndom += __shfl_down(ndom, s);
-        if ((threadIdx.x & 63) == 0 && ndom && dominant >= 0 && dominant < TZ_NBINS) atomicAdd(&lh[dominant], ndom);
-        __syncthreads();
-        for (int k = threadIdx.x; k < TZ_NBINS; k += 256) {
-            unsigned c = lhs[0][k] + lhs[1][k] + lhs[2][k] + lhs[3][k];
-            if (c) atomicAdd(&hist[k], (unsigned long long)c);
-        }
-    }
+    if (HIST) hist_flush(hl, acc, centre, hist);
 }
 
 // Lossless fast path (error_bound is the identity, compress.py:24): delta, spatial delta,
 // 1600 offset and histogram in ONE pass over pred/orig -- 7 B/element instead of 7 + 4.
 // Same arithmetic as k_delta_flat followed by k_sdelta; the element before a lane's first is
 // recomputed from pred/orig (one extra float + byte, same cache lines).
-__global__ __launch_bounds__(256) void k_delta_sd_fused(const float4* __restrict__ pred, const uint2* __restrict__ orig,
+template <bool HIST>
+__global__ __launch_bounds__(HIST ? HB_THREADS : 256) void k_delta_sd_fused(const float4* __restrict__ pred, const uint2* __restrict__ orig,
                                                         const uint8_t* __restrict__ zero_mask, size_t n8,
                                                         unsigned frame_elems8, int apply_offset,
-                                                        short8* __restrict__ out, unsigned long long* __restrict__ hist) {
-    __shared__ unsigned lhs[4][TZ_NBINS + 1];  // one sub-histogram per wave: 4x less atomic contention
-    unsigned* lh = lhs[threadIdx.x >> 6];
-    const bool do_hist = hist != nullptr;
-    if (do_hist) {
-        for (int k = threadIdx.x; k < 4 * (TZ_NBINS + 1); k += 256) (&lhs[0][0])[k] = 0;
-        __syncthreads();
-    }
-    const int dominant = apply_offset ? TZ_OFFSET : 0;
-    unsigned ndom = 0;
+                                                        short8* __restrict__ out, unsigned long long* __restrict__ hist,
+                                                        int16_t* __restrict__ edge) {
+    __shared__ unsigned hraw[HIST ? HL_WORDS : 1];
+    HistLds& hl = *(HistLds*)hraw;
+    constexpr bool do_hist = HIST;
+    if (do_hist) hist_clear(hl);
+    const int centre = apply_offset ? TZ_OFFSET : 0;
+    HistAcc acc;
     const float* predf = (const float*)pred;
     const uint8_t* origb = (const uint8_t*)orig;
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -751,43 +840,43 @@ __global__ __launch_bounds__(256) void k_delta_sd_fused(const float4* __restrict
             size_t e = 8 * i - 1;
             if (!zero_mask[(i * 8 - 1) / ((size_t)frame_elems8 * 8)]) prev = (short)((int)(predf[e] * 255.0f) - (int)origb[e]);
         }
-        short8 r;
+        // pack the (masked) deltas two per dword and take the spatial delta in packed int16 arithmetic
+        uint4 V;
+        {
+            unsigned q[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            short cur = zero ? (short)0 : d[k];
-            short sd = (short)(prev - cur);
-            if (i == 0 && k == 0) sd = cur;
-            short y = apply_offset ? (short)(TZ_OFFSET - sd) : sd;
-            r[k] = y;
-            prev = cur;
-            if (do_hist) {
-                if (y == dominant) ++ndom;
-                else if (y >= 0 && y < TZ_NBINS) atomicAdd(&lh[y], 1u);
-            }
+            for (int j = 0; j < 4; ++j)
+                q[j] = zero ? 0u : (((unsigned)(unsigned short)d[2 * j]) | ((unsigned)(unsigned short)d[2 * j + 1] << 16));
+            V = make_uint4(q[0], q[1], q[2], q[3]);
         }
-        out[i] = r;
+        const unsigned pv = i ? (unsigned)(unsigned short)prev : ((V.x << 1) & 0xFFFFu);   // stream start: sd[0] = x[0]
+        unsigned Y[4];
+        sdelta8(V, pv, apply_offset != 0, Y);
+        ((uint4*)out)[i] = make_uint4(Y[0], Y[1], Y[2], Y[3]);
+        if (do_hist) hist_add8(hl, acc, Y, centre);
+        // first / last element of the delta stack (shard boundaries, tz_encode_begin)
+        if (i == 0) edge[0] = zero ? (short)0 : d[0];
+        if (i == n8 - 1) edge[1] = zero ? (short)0 : d[7];
     }
-    if (do_hist) {
-        for (int s = 32; s >= 1; s >>= 1) ndom += __shfl_down(ndom, s);
-        if ((threadIdx.x & 63) == 0 && ndom && dominant >= 0 && dominant < TZ_NBINS) atomicAdd(&lh[dominant], ndom);
-        __syncthreads();
-        for (int k = threadIdx.x; k < TZ_NBINS; k += 256) {
-            unsigned c = lhs[0][k] + lhs[1][k] + lhs[2][k] + lhs[3][k];
-            if (c) atomicAdd(&hist[k], (unsigned long long)c);
-        }
-    }
+    if (do_hist) hist_flush(hl, acc, centre, hist);
 }
 
 // returns TZ_OK and sets *done when the fused path applies (unpadded frames, whole 8-element groups)
 int tzk_delta_sd_fused(tz_ctx* ctx, const float* pred, const uint8_t* orig, const uint8_t* d_zero_mask, int nframes, int H,
-                       int W, int Hp, int Wp, int apply_offset, int16_t* out, unsigned long long* d_hist, bool* done) {
+                       int W, int Hp, int Wp, int apply_offset, int16_t* out, unsigned long long* d_hist, int16_t* d_edge,
+                       bool* done) {
     *done = false;
     size_t fe = (size_t)H * W * 3;
     if (H != Hp || W != Wp || fe % 8 || nframes <= 0) return TZ_OK;
     size_t n8 = fe * nframes / 8;
     tz_prof_scope ps(ctx, TZP_DELTA);
-    hipLaunchKernelGGL(k_delta_sd_fused, dim3(grid_for(n8, 256)), dim3(256), 0, ctx->stream, (const float4*)pred,
-                       (const uint2*)orig, d_zero_mask, n8, (unsigned)(fe / 8), apply_offset, (short8*)out, d_hist);
+    if (d_hist)
+        hipLaunchKernelGGL(k_delta_sd_fused<true>, dim3(std::min(HB_GRID, grid_for(n8, HB_THREADS))), dim3(HB_THREADS), 0, ctx->stream,
+                           (const float4*)pred, (const uint2*)orig, d_zero_mask, n8, (unsigned)(fe / 8), apply_offset, (short8*)out,
+                           d_hist, d_edge);
+    else
+        hipLaunchKernelGGL(k_delta_sd_fused<false>, dim3(grid_for(n8, 256)), dim3(256), 0, ctx->stream, (const float4*)pred,
+                           (const uint2*)orig, d_zero_mask, n8, (unsigned)(fe / 8), apply_offset, (short8*)out, d_hist, d_edge);
     TZ_HIP(ctx, hipGetLastError());
     *done = true;
     return TZ_OK;
@@ -799,8 +888,12 @@ int tzk_spatial_delta(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, i
     if (((uintptr_t)in & 15) || ((uintptr_t)out & 15))
         return tz_fail(ctx, TZ_ERR_INVALID, "spatial_delta buffers must be 16-byte aligned");
     tz_prof_scope ps(ctx, TZP_SDELTA);
-    hipLaunchKernelGGL(k_sdelta, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, ctx->stream, in, n, has_carry, carry,
-                       apply_offset, out, d_hist);
+    if (d_hist)
+        hipLaunchKernelGGL(k_sdelta<true>, dim3(std::min(HB_GRID, grid_for(n / 8 + 1, HB_THREADS))), dim3(HB_THREADS), 0, ctx->stream,
+                           in, n, has_carry, carry, apply_offset, out, d_hist);
+    else
+        hipLaunchKernelGGL(k_sdelta<false>, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, ctx->stream, in, n, has_carry, carry,
+                           apply_offset, out, d_hist);
     TZ_HIP(ctx, hipGetLastError());
     return TZ_OK;
 }
@@ -915,9 +1008,26 @@ int tzk_shuffle(tz_ctx* ctx, const int16_t* in, size_t n, uint8_t* out, int inve
 // decompress.py:22-29 is a serial loop x[i] = x[i-1] - s[i] (pure Python, forced onto the
 // CPU by the reference, docs/index.rst:1392-1396).  It is the wrap-around prefix scan
 //   x[i] = c0 - sum_{j<=i} s'[j]   (mod 2^16),  s'[0] = -s[0] and c0 = 0 without a carry.
-// Three passes: block sums -> scan of block sums -> block-local scan + offset.
+// ONE launch of SCAN_G resident blocks (round 3; rounds 1-2: three launches, 85 us per 62.9 M elements):
+// block g owns a contiguous chunk of tiles; it (1) sums its chunk, (2) publishes the sum and reads
+// the sums of the chunks in front of it -- they all run at the same time and do the same work, so they
+// are there within one round trip --, (3) walks its chunk again, scanning tile by tile.  6 B/element
+// move for 4 algorithmic, as before, but without the launch gaps and the scan-of-sums kernel in
+// between: 60 us = 4.2 TB/s algorithmic, which is what 6 B/element at the chip's copy rate
+// (6.3 TB/s) allows.  A single pass with decoupled look-back (4 B/element) was built and measured and
+// is NOT faster here: a look-back hop between workgroups on different XCDs takes several microseconds
+// under streaming load (and a ticket counter serialises at 12 ns per block): 170-220 us in every
+// variant (scripts/microbench/scan_lookback.hip, profiles/r03/scan_lookback.txt).
+// With LUT the decoder's inverse rank remap (decompress.py:31-36,236: rank -> 1600 - symbol) is
+// applied to the elements as they are loaded (both times), which removes the separate k_lut pass
+// over the payload (4 B/element) from tz_decode.
+// The blocks of phase 2 wait for lower-numbered blocks only; SCAN_G is far below what the chip holds
+// (4 of 8 possible workgroups per CU) and workgroups are dispatched in index order, so every block a
+// waiter waits for is running.
 static constexpr int SCAN_EPT = 16;                 // elements per thread
-static constexpr int SCAN_BLK = 256 * SCAN_EPT;     // elements per block
+static constexpr int SCAN_BLK = 256 * SCAN_EPT;     // elements per tile
+static constexpr int SCAN_G = 1024;                 // resident blocks
+static constexpr unsigned SCAN_VALID = 1u << 16;
 
 __device__ __forceinline__ unsigned block_scan_excl(unsigned v, unsigned* total) {
     __shared__ unsigned wsum[4];
@@ -939,9 +1049,12 @@ __device__ __forceinline__ unsigned block_scan_excl(unsigned v, unsigned* total)
     return pre + inc - v;
 }
 
-// 16 consecutive int16 per thread = two 16-byte accesses (scalar fallback at the ragged tail
-// and for unaligned buffers)
-__device__ __forceinline__ void scan_load16(const int16_t* __restrict__ in, size_t base, size_t n, bool vec, int* v) {
+// 16 consecutive elements of a tile for this thread: two 16-byte accesses (scalar at the ragged tail and
+// for unaligned buffers), through the decoder LUT when there is one, the first element of the stream
+// negated (s'[0] = -s[0]); elements past the end count as 0
+template <bool LUT>
+__device__ __forceinline__ void scan_load16(const int16_t* __restrict__ in, size_t base, size_t n, bool vec, bool first_neg,
+                                            const int16_t* sl, int post_offset, int* v) {
     if (vec && base + SCAN_EPT <= n) {
         short8 a = *(const short8*)(in + base), b = *(const short8*)(in + base + 8);
 #pragma unroll
@@ -953,85 +1066,127 @@ __device__ __forceinline__ void scan_load16(const int16_t* __restrict__ in, size
 #pragma unroll
         for (int k = 0; k < SCAN_EPT; ++k) v[k] = base + k < n ? (int)in[base + k] : 0;
     }
+    if (LUT) {
+#pragma unroll
+        for (int k = 0; k < SCAN_EPT; ++k) {
+            const int x = v[k];
+            const int y = (x >= 0 && x <= TZ_NBINS) ? (int)sl[x] : (int)(short)(post_offset ? TZ_OFFSET - x : x);
+            v[k] = base + k < n ? y : 0;
+        }
+    }
+    if (base == 0 && first_neg) v[0] = -v[0];
 }
 
-__global__ __launch_bounds__(256) void k_scan_sums(const int16_t* __restrict__ in, size_t n, int has_carry, int vec,
-                                                   unsigned* __restrict__ bsum) {
-    size_t base = (size_t)blockIdx.x * SCAN_BLK + (size_t)threadIdx.x * SCAN_EPT;
-    int v[SCAN_EPT];
-    scan_load16(in, base, n, vec != 0, v);
-    if (base == 0 && !has_carry) v[0] = -v[0];
+__device__ __forceinline__ unsigned st_load(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_store(unsigned* p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// status[g] = SCAN_VALID | (sum of chunk g mod 2^16); all zero at launch
+template <bool LUT>
+__global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, size_t n, int tiles_per_block, int has_carry,
+                                                int16_t carry, int vec, const int16_t* __restrict__ lut, int post_offset,
+                                                unsigned* __restrict__ status, int16_t* __restrict__ out) {
+    __shared__ int16_t sl[LUT ? TZ_NBINS + 1 : 1];
+    if (LUT) {
+        for (int k = threadIdx.x; k < TZ_NBINS + 1; k += 256) sl[k] = lut[k];
+        __syncthreads();
+    }
+    const int g = blockIdx.x;
+    const size_t chunk0 = (size_t)g * tiles_per_block * SCAN_BLK;
+    // (1) the chunk's sum
     unsigned s = 0;
+    for (int t = 0; t < tiles_per_block; ++t) {
+        const size_t base = chunk0 + (size_t)t * SCAN_BLK + (size_t)threadIdx.x * SCAN_EPT;
+        if (base >= n) break;
+        int v[SCAN_EPT];
+        scan_load16<LUT>(in, base, n, vec != 0, !has_carry, sl, post_offset, v);
 #pragma unroll
-    for (int k = 0; k < SCAN_EPT; ++k) s += (unsigned)v[k];
+        for (int k = 0; k < SCAN_EPT; ++k) s += (unsigned)v[k];
+    }
     unsigned tot;
     block_scan_excl(s, &tot);
-    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
-}
-
-// exclusive scan of the block sums: every thread scans a contiguous run of them
-__global__ __launch_bounds__(256) void k_scan_blocks(unsigned* __restrict__ bsum, int nb) {
-    const int per = (nb + 255) / 256;
-    const int b0 = threadIdx.x * per, b1 = min(nb, b0 + per);
-    unsigned s = 0;
-    for (int b = b0; b < b1; ++b) s += bsum[b];
-    unsigned tot;
-    unsigned run = block_scan_excl(s, &tot);
-    for (int b = b0; b < b1; ++b) {
-        unsigned v = bsum[b];
-        bsum[b] = run;
-        run += v;
+    if (threadIdx.x == 0) st_store(&status[g], SCAN_VALID | (tot & 0xFFFFu));
+    // (2) the sums of the chunks in front: thread t takes chunks t, t + 256, ...
+    unsigned mine = 0;
+    for (int b = threadIdx.x; b < g; b += 256) {
+        unsigned w = st_load(&status[b]);
+        while ((w >> 16) == 0) w = st_load(&status[b]);
+        mine += w & 0xFFFFu;
     }
-}
-
-__global__ __launch_bounds__(256) void k_scan_apply(const int16_t* __restrict__ in, size_t n, int has_carry,
-                                                    int16_t carry, int vec, const unsigned* __restrict__ bsum,
-                                                    int16_t* __restrict__ out) {
-    size_t base = (size_t)blockIdx.x * SCAN_BLK + (size_t)threadIdx.x * SCAN_EPT;
-    int v[SCAN_EPT];
-    scan_load16(in, base, n, vec != 0, v);
-    if (base == 0 && !has_carry) v[0] = -v[0];
-    unsigned s = 0;
+    unsigned run;
+    block_scan_excl(mine, &run);
+    // (3) scan the chunk tile by tile
+    const unsigned c0 = has_carry ? (unsigned)(int)carry : 0u;
+    for (int t = 0; t < tiles_per_block; ++t) {
+        const size_t base = chunk0 + (size_t)t * SCAN_BLK + (size_t)threadIdx.x * SCAN_EPT;
+        if (chunk0 + (size_t)t * SCAN_BLK >= n) break;   // uniform for the block: the barriers below stay matched
+        int v[SCAN_EPT];
+        scan_load16<LUT>(in, base, n, vec != 0, !has_carry, sl, post_offset, v);
+        unsigned q = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_EPT; ++k) s += (unsigned)v[k];
-    unsigned tot;
-    unsigned pre = block_scan_excl(s, &tot) + bsum[blockIdx.x];
-    unsigned c0 = has_carry ? (unsigned)(int)carry : 0u;
-    short r[SCAN_EPT];
+        for (int k = 0; k < SCAN_EPT; ++k) q += (unsigned)v[k];
+        unsigned ttot;
+        unsigned pre = block_scan_excl(q, &ttot) + run;
+        run += ttot;
+        short r[SCAN_EPT];
 #pragma unroll
-    for (int k = 0; k < SCAN_EPT; ++k) {
-        pre += (unsigned)v[k];
-        r[k] = (short)(uint16_t)(c0 - pre);
-    }
-    if (vec && base + SCAN_EPT <= n) {
-        short8 a, b;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            a[k] = r[k];
-            b[k] = r[8 + k];
+        for (int k = 0; k < SCAN_EPT; ++k) {
+            pre += (unsigned)v[k];
+            r[k] = (short)(uint16_t)(c0 - pre);
         }
-        *(short8*)(out + base) = a;
-        *(short8*)(out + base + 8) = b;
-    } else {
+        if (vec && base + SCAN_EPT <= n) {
+            short8 a, b;
 #pragma unroll
-        for (int k = 0; k < SCAN_EPT; ++k)
-            if (base + k < n) out[base + k] = r[k];
+            for (int k = 0; k < 8; ++k) {
+                a[k] = r[k];
+                b[k] = r[8 + k];
+            }
+            *(short8*)(out + base) = a;
+            *(short8*)(out + base + 8) = b;
+        } else {
+#pragma unroll
+            for (int k = 0; k < SCAN_EPT; ++k)
+                if (base + k < n) out[base + k] = r[k];
+        }
     }
+}
+
+static int scan_launch(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, int16_t carry, const int16_t* h_lut2112,
+                       int post_offset, int16_t* out) {
+    if (n == 0) return TZ_OK;
+    const size_t tiles = (n + SCAN_BLK - 1) / SCAN_BLK;
+    const int G = (int)std::min<size_t>(SCAN_G, tiles);
+    const size_t tpb = (tiles + G - 1) / G;
+    if (tpb > 0x7FFFFFFFull) return tz_fail(ctx, TZ_ERR_INVALID, "inverse scan: too many elements");
+    void *d_status, *d_lut = nullptr;
+    TZ_TRY(tz_pool_alloc(ctx, sizeof(unsigned) * (size_t)G, &d_status));
+    if (h_lut2112) {
+        TZ_TRY(tz_pool_alloc(ctx, (TZ_NBINS + 1) * 2, &d_lut));
+        TZ_TRY(tz_upload(ctx, d_lut, h_lut2112, (TZ_NBINS + 1) * 2));
+    }
+    tz_prof_scope ps(ctx, TZP_SCAN);
+    TZ_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(unsigned) * (size_t)G, ctx->stream));
+    const int vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    if (h_lut2112)
+        hipLaunchKernelGGL(k_scan2p<true>, dim3(G), dim3(256), 0, ctx->stream, in, n, (int)tpb, has_carry, carry, vec,
+                           (const int16_t*)d_lut, post_offset, (unsigned*)d_status, out);
+    else
+        hipLaunchKernelGGL(k_scan2p<false>, dim3(G), dim3(256), 0, ctx->stream, in, n, (int)tpb, has_carry, carry, vec,
+                           (const int16_t*)nullptr, 0, (unsigned*)d_status, out);
+    TZ_HIP(ctx, hipGetLastError());
+    return TZ_OK;
 }
 
 int tzk_undelta(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, int16_t carry, int16_t* out) {
-    if (n == 0) return TZ_OK;
-    int nb = (int)((n + SCAN_BLK - 1) / SCAN_BLK);
-    void* d_bsum;
-    TZ_TRY(tz_pool_alloc(ctx, sizeof(unsigned) * nb, &d_bsum));
-    tz_prof_scope ps(ctx, TZP_SCAN);
-    const int vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
-    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, ctx->stream, in, n, has_carry, vec, (unsigned*)d_bsum);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, (unsigned*)d_bsum, nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, ctx->stream, in, n, has_carry, carry, vec,
-                       (const unsigned*)d_bsum, out);
-    TZ_HIP(ctx, hipGetLastError());
-    return TZ_OK;
+    return scan_launch(ctx, in, n, has_carry, carry, nullptr, 0, out);
+}
+
+// decoder: inverse rank remap (+ 1600 - x) and inverse spatial delta in one pass over the payload
+int tzk_unmap_undelta(tz_ctx* ctx, const int16_t* in, size_t n, const int16_t* h_lut2112, int post_offset, int16_t* out) {
+    return scan_launch(ctx, in, n, 0, 0, h_lut2112, post_offset, out);
 }
 
 // ----------------------------------------------------------------------------- reconstruct

@@ -86,6 +86,8 @@ struct tz_ctx {
     uint8_t* d_out = nullptr;               // resident decoded frames of a tz_decode(frames_out = NULL)
     size_t cap_out = 0;
     bool have_decoded = false;
+    bool enc_pending = false, enc_entropy = false;  // tz_encode_begin done, symbols resident in d_payload
+    int16_t enc_first = 0;                          // first element of the shard's quantised delta stack
     const uint8_t* pending_src = nullptr;  // host frame stack whose non-key frames are still to be sent
     std::vector<uint8_t> pending_sent;     // nt: 1 = already on its way
     std::vector<hipEvent_t> chunk_ev;  // payload chunk hand-over events (compute -> copy stream)
@@ -155,7 +157,8 @@ struct tz_prof_scope {
 int tzk_delta(tz_ctx*, const float* pred, const uint8_t* orig, const uint8_t* d_zero_mask, int nframes,
               int H, int W, int Hp, int Wp, int16_t* out);
 int tzk_delta_sd_fused(tz_ctx*, const float* pred, const uint8_t* orig, const uint8_t* d_zero_mask, int nframes, int H,
-                       int W, int Hp, int Wp, int apply_offset, int16_t* out, unsigned long long* d_hist, bool* done);
+                       int W, int Hp, int Wp, int apply_offset, int16_t* out, unsigned long long* d_hist, int16_t* d_edge,
+                       bool* done);
 int tzk_error_bound(tz_ctx*, const uint8_t* orig, int16_t* diff, const uint8_t* h_skip, int nframes, int H,
                     int W, int mode, double b0, double b1);
 int tzk_spatial_delta(tz_ctx*, const int16_t* in, size_t n, int has_carry, int16_t carry, int apply_offset,
@@ -164,6 +167,7 @@ int tzk_lut(tz_ctx*, const int16_t* in, size_t n, const int16_t* h_lut2112, int 
 // forward: int16[n] -> low-byte plane | high-byte plane (2n bytes); inverse: planes (passed as `in`) -> int16[n] at `out`
 int tzk_shuffle(tz_ctx*, const int16_t* in, size_t n, uint8_t* out, int inverse);
 int tzk_undelta(tz_ctx*, const int16_t* in, size_t n, int has_carry, int16_t carry, int16_t* out);
+int tzk_unmap_undelta(tz_ctx*, const int16_t* in, size_t n, const int16_t* h_lut2112, int post_offset, int16_t* out);
 int tzk_reconstruct(tz_ctx*, const float* pred, const uint8_t* key, const uint8_t* d_key_mask, const int16_t* diff,
                     int nframes, int H, int W, int Hp, int Wp, uint8_t* out);
 int tzk_sse(tz_ctx*, const uint8_t* orig, const float* pred, int nframes, int H, int W, int Hp, int Wp,

@@ -4,20 +4,26 @@ Windows (a key frame + its predicted frames) are independent through prediction,
 quantisation (compress.py:218-220,256-263): each rank runs them on a contiguous range of
 windows with NO data-path collective.  Only three things cross shard boundaries
 (SURVEY.md §8e), exchanged through torch.distributed (RCCL on GPUs, gloo in CPU tests):
-  1. the spatial delta runs over the whole flattened stack (compress.py:339): a shard needs the
-     last delta element of the previous shard (one int16 `carry`; it travels in one small
-     all_gather together with the shard's key mask and an error flag);
+  1. the spatial delta runs over the whole flattened stack (compress.py:339): the FIRST element of a
+     shard needs the last delta element of the previous shard (one int16 `carry`; it travels in one
+     small all_gather together with the shard's key mask and an error flag);
   2. the rank table is built from the global histogram (compress.py:354-361): all-reduce of
-     2111 counters, the table is then rebuilt identically on every rank;
+     2111 counters (+ one failure counter), the table is then rebuilt identically on every rank;
   3. rank 0 receives the payload shards point to point, straight into their place in the
      full payload buffer (peers `send`, rank 0 `irecv`s into slices: nothing lands on a rank
      that does not use it).
+A rank runs the SAME fused kernels as a single GPU does (round 3): tz_rollout, then tz_encode_begin
+(delta, quantiser, spatial delta without a carry, histogram -- the symbols stay in its HBM), the two
+small collectives, then tz_encode_finish (patches the shard's first symbol for the carry, remaps
+with the global table).  Until round 2 a rank went through the unfused stand-alone operators with a
+host round trip for the carry.
 The decoder shards the same way; its inverse scan needs the prefix of per-shard sums.
 
-Everything between the frames and the payload stays in the rank's HBM: the per-rank `engine`
-hands out engine-native buffers (HipEngine: torch CUDA tensors whose pointers go through the C
-ABI; the oracle engine of the CPU tests: numpy arrays) and only turns them into communication
-tensors (`comm_tensor`) for step 3.
+Failure handling: every compute stage that sits in front of a collective reports its outcome THROUGH
+that collective (flag in the all_gather, failure counter in the all-reduce, one more one-element
+all-reduce in front of the point-to-point gather), so a rank that fails -- out of memory, a TezipError
+-- raises its own error while every other rank raises a RuntimeError naming it; nobody is left
+waiting in a collective until the watchdog fires.
 
 DWP (-t) discovers window boundaries sequentially and does not shard: replicas only.
 """
@@ -40,41 +46,34 @@ class HipEngine:
         return self.torch.empty(int(n), dtype=dtype, device=self.dev)
 
     def _sync(self):
-        # the context launches on its own stream: torch / RCCL consume the buffers afterwards
-        self.ctx.synchronize()
+        # a context with its OWN stream: torch / RCCL consume the buffers afterwards, so wait.  A
+        # context created on torch's current stream (bench.py) is already ordered with them.
+        if self.ctx.stream_ptr() != self.torch.cuda.current_stream(self.dev).cuda_stream:
+            self.ctx.synchronize()
 
     def _buf(self, x):
         """numpy (host) and torch tensors are both accepted by the C ABI."""
         return np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x.contiguous()
 
-    # encoder
-    def encode_delta(self, frames, warm_up, window, mode, bound):
+    # encoder: the two phases of tz_encode around the exchange of carry + histogram
+    def encode_begin(self, frames, warm_up, window, mode, bound, entropy):
         frames = self._buf(frames)
-        nt, h, w = frames.shape[:3]
         key, _ = self.ctx.rollout(frames, warm_up, window)
-        d = self._new(nt * h * w * 3, self.torch.int16)
-        self.ctx.encode_delta(mode, bound, out=d)
-        self._sync()
-        return key, d
+        hist, first, last = self.ctx.encode_begin(mode, bound, entropy)
+        return key, hist, first, last
 
-    def last(self, buf):
-        return int(buf[-1].item())
-
-    def spatial_delta(self, d, carry, offset):
-        hist = np.zeros(NBINS, np.uint64) if offset else None
-        y = self._new(d.numel(), self.torch.int16)
-        self.ctx.spatial_delta(d, offset, carry=carry, hist=hist, out=y)
+    def encode_finish(self, carry, table):
+        nt, h, w = self.ctx._shape
+        y = self._new(nt * h * w * 3, self.torch.int16)
+        self.ctx.encode_finish(carry, table, out=y)
         self._sync()
-        return y, hist
+        return y
 
     def build_table(self, hist):
         return self.ctx.build_table(hist)
 
-    def remap(self, y, table):
-        out = self._new(y.numel(), self.torch.int16)
-        self.ctx.remap(y, table, out=out)
-        self._sync()
-        return out
+    def last(self, buf):
+        return int(buf[-1].item())
 
     # decoder
     def decode_prepare(self, key_frames, warm_up):
@@ -270,6 +269,20 @@ class PendingCompress:
         return _typed(full, np.int16, self.to_host), self.table, self.keys
 
 
+def _i16(v):
+    v &= 0xFFFF
+    return v - 65536 if v >= 32768 else v
+
+
+def _all_ok(ok, dist, what):
+    """One-element all-reduce of a failure count: every rank learns whether all of them got here."""
+    import torch
+    t = torch.tensor([0 if ok else 1], dtype=torch.int64, device=_device(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if int(t.item()):
+        raise RuntimeError("%s failed on %d rank(s) (see their logs)" % (what, int(t.item())))
+
+
 def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True, nt=None, to_host=True, wait=True):
     """Every rank passes the same arguments.  `frames` is the full (nt,H,W,3) stack (anything whose
     [f0:f1] slice yields frames) or, with `nt` given, a callable (f0, f1) -> this rank's frames
@@ -289,15 +302,15 @@ def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True,
     shards = plan_shards(nt, warm_up, window, world)
     f0, f1 = shards[rank]
     klen = max(b - a for a, b in shards)
-    ok, err, key, d, fe = 1, None, np.zeros(0, bool), None, 0
+    ok, err, key, hist, first, last, fe = 1, None, np.zeros(0, bool), None, 0, 0, 0
     try:
         if f1 > f0:
             mine = fetch(f0, f1)
             fe = int(np.prod(mine.shape[1:]))
-            key, d = engine.encode_delta(mine, warm_up if rank == 0 else 0, window, mode, bound)
+            key, hist, first, last = engine.encode_begin(mine, warm_up if rank == 0 else 0, window, mode, bound, entropy)
     except Exception as e:  # the other ranks are about to enter a collective: tell them
         ok, err = 0, e
-    head = [ok, int(f1 > f0 and ok), engine_last(engine, d) if (f1 > f0 and ok) else 0, fe]
+    head = [ok, int(f1 > f0 and ok), int(last), fe]
     kpad = np.zeros(klen, np.int64)
     kpad[: len(key)] = np.asarray(key, np.int64)
     infos = _all_gather_i64(head + kpad.tolist(), dist)
@@ -310,17 +323,43 @@ def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True,
         if infos[r][1]:
             carry = int(infos[r][2])
             break
-    hist = np.zeros(NBINS, np.uint64) if entropy else None
-    y = None
-    if f1 > f0:
-        y, hist = engine.spatial_delta(d, carry, 1 if entropy else 0)
-    table = None
-    if entropy:
-        h = torch.from_numpy(np.asarray(hist).astype(np.int64)).to(_device(dist))
-        dist.all_reduce(h, op=dist.ReduceOp.SUM)
-        table = engine.build_table(h.cpu().numpy().astype(np.uint64))
+    # stage 2: the global table.  The failure counter rides in the same all-reduce as the histogram.
+    table, y = None, None
+    try:
+        h = np.zeros(NBINS + 1, np.int64)
+        if entropy and f1 > f0:
+            h[:NBINS] = np.asarray(hist).astype(np.int64)
+            if carry is not None:  # the shard's first symbol moves: sd = carry - x[0] instead of x[0] (compress.py:73-77)
+                old, new = 1600 - _i16(first), _i16(1600 - _i16(carry - first))
+                if 0 <= old < NBINS:
+                    h[old] -= 1
+                if 0 <= new < NBINS:
+                    h[new] += 1
+    except Exception as e:
+        err = e
+        h = np.zeros(NBINS + 1, np.int64)
+    h[NBINS] = 0 if err is None else 1
+    ht = torch.from_numpy(h).to(_device(dist))
+    dist.all_reduce(ht, op=dist.ReduceOp.SUM)
+    h = ht.cpu().numpy()
+    if err is not None:
+        raise err
+    if int(h[NBINS]):
+        raise RuntimeError("window-sharded encode (histogram stage) failed on %d rank(s) (see their logs)" % int(h[NBINS]))
+    # stage 3: remap with the global table; its outcome is agreed on before anyone posts a send / receive
+    try:
+        if entropy:
+            table = engine.build_table(h[:NBINS].astype(np.uint64))
         if f1 > f0:
-            y = engine.remap(y, table)
+            y = engine.encode_finish(carry, table)
+    except Exception as e:
+        err = e
+    try:
+        _all_ok(err is None, dist, "window-sharded encode (remap stage)")
+    except RuntimeError:
+        if err is not None:
+            raise err
+        raise
     gather = _gather_shards_begin(engine, y, [(b - a) * fe * 2 for a, b in shards], dist)
     keys = np.concatenate([np.asarray(i[4: 4 + (b - a)]) for i, (a, b) in zip(infos, shards)]).astype(bool)
     pending = PendingCompress(gather, rank, table, keys, to_host)
@@ -384,17 +423,26 @@ def decompress_sharded(engine, key_frames, payload, table, warm_up, to_host=True
         raise err
     _raise_if_any_failed([int(i[0]) for i in infos], "window-sharded decode")
     frames = None
-    if f1 > f0:
-        if rank > 0:
-            x_end = int(infos[0][2])
-            for r in range(1, rank):
-                if infos[r][1]:
-                    x_end = (x_end - int(infos[r][3])) & 0xFFFF
-            carry = x_end - 65536 if x_end >= 32768 else x_end
-            delta = engine.undelta(sd, carry)
-        if isinstance(delta, np.ndarray):
-            delta = delta.reshape(f1 - f0, H, W, C)
-        frames = engine.reconstruct(delta)
+    try:
+        if f1 > f0:
+            if rank > 0:
+                x_end = int(infos[0][2])
+                for r in range(1, rank):
+                    if infos[r][1]:
+                        x_end = (x_end - int(infos[r][3])) & 0xFFFF
+                carry = x_end - 65536 if x_end >= 32768 else x_end
+                delta = engine.undelta(sd, carry)
+            if isinstance(delta, np.ndarray):
+                delta = delta.reshape(f1 - f0, H, W, C)
+            frames = engine.reconstruct(delta)
+    except Exception as e:
+        err = e
+    try:  # agreed on before anyone posts a send / receive
+        _all_ok(err is None, dist, "window-sharded decode (reconstruct stage)")
+    except RuntimeError:
+        if err is not None:
+            raise err
+        raise
     full = _gather_shards(engine, frames, [(b - a) * fe for a, b in shards], dist)
     if rank != 0:
         return None
