@@ -448,10 +448,13 @@ def main():
             ctx.prof_enable(True)
             ctx.prof_reset()
             own_step("abs", [2.0])
-            q = ctx.prof_get()["quant"]
+            pq = ctx.prof_get()
+            q = pq["quant"]
             ctx.prof_enable(False)
             extras["lossy_abs2"] = {"frames_per_s": frames.shape[0] * max(3, min(args.steps, 10)) / el,
-                                    "quantiser_ms_per_step": q[0], "table_symbols": len(own_state["table"])}
+                                    "quantiser_ms_per_step": q[0], "table_symbols": len(own_state["table"]),
+                                    "encode_tail_ms_per_step": {k: pq[k][0] for k in ("delta", "quant", "spatial_delta_hist", "lut_remap")},
+                                    "encode_tail_ms_total": sum(pq[k][0] for k in ("delta", "quant", "spatial_delta_hist", "lut_remap"))}
             own_step()
 
         # ------------------------------------------------------------ compression ratio (untimed; libzstd level 9 as the reference)

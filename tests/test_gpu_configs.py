@@ -110,6 +110,12 @@ def test_cfg3_512_nt80_w20_workload(ctx):
         stream = compress.build_stream(payload, table, (1, 80, 512, 512, 3), 0)
         assert stream.tobytes() == O.build_stream(ref_payload, ref_table, 80, 512, 512, 0).tobytes()
         results[mode] = (np.array(payload), table, delta)
+        # the same job WITHOUT the delta tap takes the fused kernels (quantiser on pred / orig, run values
+        # straight into spatial delta + histogram: no delta stack in memory): same bytes
+        fused_payload, fused_table, _ = ctx.encode(mode, bound, True)
+        np.testing.assert_array_equal(fused_table, table, err_msg=mode)
+        np.testing.assert_array_equal(fused_payload, results[mode][0], err_msg=mode)
+        del fused_payload
     # one complete window: predictor recursion to depth 19, then delta + quantiser of every frame
     net = coracle.CPredNet(WTS, CFG.stack_sizes, CFG.R_stack_sizes, 512, 512)
     np.testing.assert_array_equal(enc_pred[0], net.c0())

@@ -134,6 +134,12 @@ def test_cfg4_full_length_on_one_gpu(ctx):
     stream = compress.build_stream(payload_h, table, (1, nt, h, w, 3), 0)
     assert stream[-7 - len(table):].tobytes() == O.build_stream(ref_payload[:0], ref_table, nt, h, w, 0).tobytes()
     del ref_payload, payload_h, stream
+    # without the delta tap the encode takes the fused lossy kernels: same payload, same table
+    payload2 = torch.empty_like(payload)
+    _, table2, _ = ctx.encode("abs", [2.0], True, payload=payload2)
+    ctx.synchronize()
+    assert np.array_equal(table2, table) and bool(torch.equal(payload2, payload))
+    del payload2
     # --- quantiser of two whole frames (3 chains of 1,048,576 elements each) vs the C oracle
     pred = ctx.get_predictions()
     for f in (1, 279):

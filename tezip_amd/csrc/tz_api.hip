@@ -1045,6 +1045,11 @@ static int encode_front(tz_ctx* ctx, int mode, double b0, double b1, int entropy
     if (lossless && !d_delta_tap)
         TZ_TRY(tzk_delta_sd_fused(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt, H, W, ctx->Hp, ctx->Wp,
                                   entropy ? 1 : 0, d_sym, entropy ? d_hist : nullptr, d_edge, &fused));
+    // lossy and nobody asked for the delta stack: quantiser on pred / orig, fill fused with the spatial delta
+    if (!lossless && !d_delta_tap)
+        TZ_TRY(tzk_quant_sd_fused(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, ctx->quant_skip.data(), nt, H, W,
+                                  ctx->Hp, ctx->Wp, mode, b0, b1, entropy ? 1 : 0, d_sym, entropy ? d_hist : nullptr, d_edge,
+                                  &fused));
     if (fused) return TZ_OK;
     if (!d_delta) TZ_TRY(tz_pool_alloc(ctx, N * 2, &d_delta));
     // compress.py:292-314

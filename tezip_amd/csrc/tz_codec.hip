@@ -78,19 +78,148 @@ int tzk_delta(tz_ctx* ctx, const float* pred, const uint8_t* orig, const uint8_t
     return TZ_OK;
 }
 
+// ------------------------------------------------------------- block-private symbol histogram
+// compress.py:354 (bincount of the symbols 1600 - sd).  The symbols of a prediction residual pile up
+// on a handful of values around the centre c (1600, or 0 without the offset), so a plain LDS
+// histogram spends its time serialising atomics on the same few words (rounds 1-2: one copy per wave,
+// 4.7 M bank-conflict cycles per 7.9 M LDS operations, the spatial-delta kernel ran at 41 % of HBM
+// against 74 % without the histogram).  Now:
+//   * the centre symbol never touches the bins: a wave counts it with a ballot into a scalar register;
+//   * the 128 bins around c have 8 copies per wave, interleaved as [bin][copy] with copy = lane & 7, so
+//     that a wave's 64 lanes spread over all 32 banks (bank = (bin % 4) * 8 + copy) and only the ~2 lanes
+//     that share copy AND bin % 4 meet in a bank;
+//   * everything else (rare) goes to one full-range copy per block.
+// flush() folds the copies into the full-range one and adds its non-zero bins to the global counters.
+static constexpr int HC_HALF = 64, HC_BINS = 2 * HC_HALF, HC_COPIES = 8;
+// Blocks of the histogram kernels are 1024 threads, two per CU: what a block's flush costs is global --
+// every block adds each of its non-zero bins to the same ~450 counters, and same-address atomics from
+// different workgroups are served one after the other (about 12 ns each): with 2048 blocks of 256
+// threads that was 25 us of a 76 us kernel, whatever the LDS part did.  (The copies are per BLOCK, not per
+// wave: only the lanes of one instruction can conflict, instructions of different waves pass through the
+// LDS one after the other anyway.)
+static constexpr int HB_THREADS = 1024, HB_GRID = 2 * kCUs;
+static constexpr int HL_CENTRAL = 0, HL_FULL = (HC_BINS + 1) * HC_COPIES /* + one junk bin per copy */,
+                     HL_SINK = HL_FULL + TZ_NBINS + 1, HL_WORDS = HL_SINK + 64;
+struct HistLds {
+    // [bin][copy] | full range | one sink word per lane
+    unsigned w[HL_WORDS];
+};
+
+struct HistAcc {
+    unsigned n0 = 0;   // wave-uniform count of the centre symbol
+};
+
+__device__ __forceinline__ void hist_clear(HistLds& h) {
+    for (int k = threadIdx.x; k < HL_WORDS; k += blockDim.x) h.w[k] = 0;
+    __syncthreads();
+}
+
+// Eight symbols of one lane, packed two per dword.  The update is ONE unconditional LDS atomic per
+// element in straight-line code (a branch per element cost more than the atomics it saved: the
+// spatial-delta kernel is as much VALU-issue as HBM bound): the centre symbol goes to the lane's own
+// sink word (it is counted by the ballot), symbols within +-64 of the centre to [bin][copy], anything
+// farther to the junk bin of the copy -- and, in a branch the wave takes only when one of its 512
+// symbols is that far out, to the full-range bins.
+__device__ __forceinline__ void hist_add8(HistLds& h, HistAcc& acc, const unsigned* Y, int c) {
+    const int lane = threadIdx.x & 63;
+    const int base = HL_CENTRAL + (lane & 7), sink = HL_SINK + lane;
+    unsigned far = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int y = (k & 1) ? ((int)Y[k >> 1] >> 16) : (int)(short)(Y[k >> 1] & 0xFFFFu);
+        const bool hot = y == c;
+        acc.n0 += (unsigned)__popcll(__ballot(hot));
+        const unsigned rel = (unsigned)(y - (c - HC_HALF));
+        const unsigned idx = min(rel, (unsigned)HC_BINS);
+        far |= idx >> 7;   // HC_BINS == 128
+        atomicAdd(&h.w[hot ? sink : base + (int)idx * HC_COPIES], 1u);
+    }
+    if (__any(far != 0)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int y = (k & 1) ? ((int)Y[k >> 1] >> 16) : (int)(short)(Y[k >> 1] & 0xFFFFu);
+            if ((unsigned)(y - (c - HC_HALF)) >= (unsigned)HC_BINS && (unsigned)y < (unsigned)TZ_NBINS) atomicAdd(&h.w[HL_FULL + y], 1u);
+        }
+    }
+}
+static_assert(HC_BINS == 128, "hist_add8 takes the far flag from bit 7 of the clamped index");
+
+// every thread of the block calls this (after its last add)
+__device__ __forceinline__ void hist_flush(HistLds& h, const HistAcc& a, int c, unsigned long long* __restrict__ hist) {
+    if ((threadIdx.x & 63) == 0 && a.n0 && c >= 0 && c < TZ_NBINS) atomicAdd(&h.w[HL_FULL + c], a.n0);
+    __syncthreads();
+    for (int b = threadIdx.x; b < HC_BINS; b += blockDim.x) {
+        const int y = c - HC_HALF + b;
+        unsigned t = 0;
+#pragma unroll
+        for (int k = 0; k < HC_COPIES; ++k) t += h.w[HL_CENTRAL + b * HC_COPIES + k];
+        if (t && y >= 0 && y < TZ_NBINS) atomicAdd(&h.w[HL_FULL + y], t);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < TZ_NBINS; k += blockDim.x) {
+        const unsigned v = h.w[HL_FULL + k];
+        if (v) atomicAdd(&hist[k], (unsigned long long)v);
+    }
+}
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b) {   // two int16 lanes, wrap-around
+    const short2v r = __builtin_bit_cast(short2v, a) - __builtin_bit_cast(short2v, b);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+// spatial delta of 8 consecutive int16 (V, two per dword) given the element in front of them:
+// sd[k] = x[k-1] - x[k]; symbols y = 1600 - sd when `offs` = (1600, 1600), y = sd when offs is 0 and `negate`
+// is false ... both forms are y = offs - (P - V) resp. P - V; P is V shifted up by one element.
+__device__ __forceinline__ void sdelta8(const uint4 V, unsigned prev16, bool apply_offset, unsigned* Y) {
+    const unsigned P0 = __builtin_amdgcn_alignbit(V.x, prev16 << 16, 16);
+    const unsigned P1 = __builtin_amdgcn_alignbit(V.y, V.x, 16);
+    const unsigned P2 = __builtin_amdgcn_alignbit(V.z, V.y, 16);
+    const unsigned P3 = __builtin_amdgcn_alignbit(V.w, V.z, 16);
+    const unsigned C = ((unsigned)TZ_OFFSET << 16) | (unsigned)TZ_OFFSET;
+    Y[0] = pk_sub(P0, V.x);
+    Y[1] = pk_sub(P1, V.y);
+    Y[2] = pk_sub(P2, V.z);
+    Y[3] = pk_sub(P3, V.w);
+    if (apply_offset) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Y[j] = pk_sub(C, Y[j]);
+    }
+}
+
 // --------------------------------------------------------------------------- quantiser
 // compress.py:23-70, one chain per (frame, channel) over H*W elements, row-major.
 // Stage 1 (k_q_minmax, k_q_bound): per-chain tolerance E for rel / absrel from max-min of the
 //                      ORIGINAL slab (compress.py:31-33,36-43).
-// Stage 2 (k_q_heads): exact wave-parallel form of the greedy interval-intersection
-//                      segmentation (see the kernel); stores the truncated median of every
-//                      run at its HEAD position of `tmp` (pre-filled with a sentinel).
-// Stage 3 (k_q_last / k_q_carry / k_q_fill): forward-fill the run values (a scan with
-//                      op(a,b) = b unless b is the sentinel) and write them back in place.
+// Stage 2 (k_q_heads, k_q_stitch): exact wave-parallel form of the greedy interval-intersection
+//                      segmentation (see the kernels).  Result: one bit per element (`spec`, a 64-bit
+//                      mask per 64-element chunk and chain) that says where a run starts, and the
+//                      truncated median of every run at its HEAD position of `tmp` (positions that are
+//                      not heads hold garbage: the masks are authoritative, nothing initialises tmp).
+// Stage 3 (k_q_last / k_q_carry / k_q_fill): forward-fill the run values.  k_q_fill either writes them
+//                      back as the quantised delta stack (stand-alone tz_error_bound, delta tap) or --
+//                      fused encode -- goes straight on to the spatial delta, the 1600 offset and the
+//                      histogram (compress.py:339-355) and writes symbols: the quantised deltas never
+//                      exist in memory.
+// The deltas a chain is made of come from a materialised int16 stack or, fused encode, straight from
+// prediction and original (compress.py:292-314 evaluated where it is needed): QSrc.
+// Round 3 traffic at cfg3, `abs 2`: heads 315 MB + fill 270 MB + remap 252 MB against 1.75 GB through
+// k_delta, k_q_init, k_q_last over tmp, k_q_fill, k_sdelta in round 2.
 struct QParams {
     int mode;
     double b0, b1;
 };
+
+struct QSrc {
+    const int16_t* diff;   // nframes * HW * 3, or nullptr: then
+    const float* pred;     // ... trunc(pred * 255) - orig of unpadded frames (H == Hp, W == Wp)
+};
+
+template <bool FP>
+__device__ __forceinline__ int q_delta(const QSrc& s, const uint8_t* __restrict__ orig, size_t e) {
+    if (FP) return (int)(s.pred[e] * 255.0f) - (int)orig[e];
+    return (int)s.diff[e];
+}
 
 // min/max of the original slab per (frame, channel): 12 bytes (4 interleaved RGB pixels) per
 // lane and iteration, QBB blocks per frame combined with integer atomics (mm[f][c] = {min, max}).
@@ -159,14 +288,6 @@ __global__ void k_q_bound(const int* __restrict__ mm, const uint8_t* __restrict_
     E[i] = e;
 }
 
-__global__ __launch_bounds__(256) void k_q_init(int16_t* __restrict__ tmp, const uint8_t* __restrict__ skip,
-                                                size_t frame_elems, int nframes) {
-    size_t n = frame_elems * nframes;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        if (!skip[i / frame_elems]) tmp[i] = TZ_SENTINEL;
-}
-
 // Wave-parallel exact greedy segmentation.  The chain of a (frame, channel) is walked in chunks of
 // 64 elements (lane i <-> element).  A run started at s breaks at the first i with
 // min(Du[s..i]) < max(Dl[s..i]) (compress.py:60 -- a-b<0 <=> a<b in IEEE), which is monotone in i, so
@@ -190,8 +311,8 @@ __global__ __launch_bounds__(256) void k_q_init(int16_t* __restrict__ tmp, const
 // k_q_stitch repairs it exactly: two greedy chains over the same data never cross and coincide from
 // their first common head on, so the true chain is followed from the segment start only until it
 // hits a head of the speculative chain (typically within the first chunk); the speculative heads
-// before that point are erased, the true ones written, everything behind it is already right.
-// Nothing depends on run lengths; elements past the chain end are (+inf, -inf) and can neither
+// before that point are dropped from the masks, the true ones entered, everything behind it is already
+// right.  Nothing depends on run lengths; elements past the chain end are (+inf, -inf) and can neither
 // break nor tighten a run.
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
@@ -215,7 +336,7 @@ struct QState {  // the run that is open at a segment boundary
     int head, pad;
 };
 
-// steps 1-3 and 2b for chunk `ch` of channel c (every lane returns its element's entries).
+// steps 1-3 for chunk `ch` of channel c (every lane returns its element's entries).
 //
 // The cross-lane traffic of these steps is what the quantiser costs: a 64-bit shuffle is two
 // ds_bpermute_b32, and with (min Du, max Dl) as two doubles a chunk took 86 of them -- 1.1 ms of LDS
@@ -231,8 +352,9 @@ __device__ __forceinline__ int q_pack(int mn, int mx) { return (mn & 0xFFFF) | (
 __device__ __forceinline__ int q_lo(int p) { return (int)(short)(p & 0xFFFF); }
 __device__ __forceinline__ int q_hi(int p) { return p >> 16; }
 
-template <bool PW>
-__device__ __forceinline__ QChunk q_chunk(const uint8_t* __restrict__ o, const int16_t* __restrict__ d, int c, int ch, int HW,
+// fe0 = element index of the frame's first sample in the whole stack (f * HW * 3)
+template <bool PW, bool FP>
+__device__ __forceinline__ QChunk q_chunk(const QSrc& src, const uint8_t* __restrict__ orig, size_t fe0, int c, int ch, int HW,
                                           const QParams& qp, double E, int lane) {
     const int idx = ch * 64 + lane;
     unsigned long long M = 1ull << lane;
@@ -241,7 +363,7 @@ __device__ __forceinline__ QChunk q_chunk(const uint8_t* __restrict__ o, const i
     if (!PW) {
         // past the chain end: (min, max) = (+32767, -32768) can neither break nor tighten a run
         int mn = 32767, mx = -32768;
-        if (idx < HW) mn = mx = (int)d[(size_t)idx * 3 + c];
+        if (idx < HW) mn = mx = q_delta<FP>(src, orig, fe0 + (size_t)idx * 3 + c);
         int tb[6];
         tb[0] = q_pack(mn, mx);
 #pragma unroll
@@ -259,8 +381,8 @@ __device__ __forceinline__ QChunk q_chunk(const uint8_t* __restrict__ o, const i
 #pragma unroll
         for (int k = 5; k >= 0; --k) {
             const int step = 1 << k;
-            const int src = pos < 63 ? pos : 63;
-            const int q = __shfl(tb[k], src, 64);
+            const int srcl = pos < 63 ? pos : 63;
+            const int q = __shfl(tb[k], srcl, 64);
             const int nmn = min(cmn, q_lo(q)), nmx = max(cmx, q_hi(q));
             const double nu = (double)nmn + E, nl = (double)nmx - E;
             const bool ok = (pos + step <= 64) && !(nu - nl < 0.0);
@@ -278,10 +400,11 @@ __device__ __forceinline__ QChunk q_chunk(const uint8_t* __restrict__ o, const i
         const double inf = __builtin_huge_val();
         double du = inf, dl = -inf;
         if (idx < HW) {
-            const double e = (double)o[(size_t)idx * 3 + c] * qp.b0;
-            const double df = (double)d[(size_t)idx * 3 + c];
-            du = df + e;
-            dl = df - e;
+            const size_t e = fe0 + (size_t)idx * 3 + c;
+            const double tol = (double)orig[e] * qp.b0;
+            const double df = (double)q_delta<FP>(src, orig, e);
+            du = df + tol;
+            dl = df - tol;
         }
         double tu[6], tl[6];
         tu[0] = du;
@@ -305,8 +428,8 @@ __device__ __forceinline__ QChunk q_chunk(const uint8_t* __restrict__ o, const i
 #pragma unroll
         for (int k = 5; k >= 0; --k) {
             const int step = 1 << k;
-            int src = pos < 63 ? pos : 63;
-            double xu = shfl_d(tu[k], src), xl = shfl_d(tl[k], src);
+            int srcl = pos < 63 ? pos : 63;
+            double xu = shfl_d(tu[k], srcl), xl = shfl_d(tl[k], srcl);
             double nu = cu < xu ? cu : xu, nl = cl > xl ? cl : xl;
             bool ok = (pos + step <= 64) && !(nu - nl < 0.0);
             if (ok) {
@@ -320,13 +443,17 @@ __device__ __forceinline__ QChunk q_chunk(const uint8_t* __restrict__ o, const i
         out.pu = pu;
         out.pl = pl;
     }
-    // 2b. pointer doubling: the set of run heads reached from a start at this lane
+    // 2b. pointer doubling: the set of run heads reached from a start at this lane.  (Following the chain
+    // of ONE start with scalar instructions in the resolver instead -- v_readlane of nxt, one hop per run --
+    // was tried in round 3: 17 instead of 35 shuffles per chunk, but the hops sit on the serial path and
+    // noise-like data has up to 64 runs per chunk: `rel 1e-3` went from 0.9 to 1.8 ms per step, `abs 2`
+    // gained nothing.)
     int J = pos;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        int src = J < 64 ? J : lane;
-        unsigned long long Mj = __shfl(M, src, 64);
-        int Jj = __shfl(J, src, 64);
+        int srcl = J < 64 ? J : lane;
+        unsigned long long Mj = __shfl(M, srcl, 64);
+        int Jj = __shfl(J, srcl, 64);
         if (J < 64) {
             M |= Mj;
             J = Jj;
@@ -343,6 +470,7 @@ __device__ __forceinline__ double q_rl_d(double v, int src) {  // src is wave-un
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+
 __device__ __forceinline__ unsigned long long q_rl_u64(unsigned long long v, int src) {
     return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src) << 32) |
            (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
@@ -351,7 +479,8 @@ __device__ __forceinline__ unsigned long long q_rl_u64(unsigned long long v, int
 // Speculative walk of segment `seg` of every chain (blockIdx.x = (frame * 3 + channel) * QSEG + seg):
 // fresh start at the segment's first element.  spec[chain][chunk] receives the heads the walk put into
 // each chunk, seg_out[chain][seg] the run left open at the segment end.
-__global__ __launch_bounds__(64 * (QW + 1)) void k_q_heads(const uint8_t* __restrict__ orig, const int16_t* __restrict__ diff,
+template <bool FP>
+__global__ __launch_bounds__(64 * (QW + 1)) void k_q_heads(QSrc src, const uint8_t* __restrict__ orig,
                                                          const uint8_t* __restrict__ skip, int HW, QParams qp,
                                                          const double* __restrict__ Echain, int16_t* __restrict__ tmp,
                                                          unsigned long long* __restrict__ spec, QState* __restrict__ seg_out) {
@@ -359,9 +488,8 @@ __global__ __launch_bounds__(64 * (QW + 1)) void k_q_heads(const uint8_t* __rest
     const int f = chain / 3, c = chain % 3;
     if (skip[f]) return;
     __shared__ QSlot slots[2][QW];
-    const int16_t* d = diff + (size_t)f * HW * 3;
-    const uint8_t* o = orig + (size_t)f * HW * 3;
-    int16_t* t = tmp + (size_t)f * HW * 3;
+    const size_t fe0 = (size_t)f * HW * 3;
+    int16_t* t = tmp + fe0;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double E = 0.0;
     if (qp.mode == TZ_MODE_ABS) E = fabs(qp.b0);
@@ -382,8 +510,8 @@ __global__ __launch_bounds__(64 * (QW + 1)) void k_q_heads(const uint8_t* __rest
         if (wv > 0 && r < nrounds) {
             const int ch = c0 + r * QW + (wv - 1);
             if (ch < c1) {
-                const QChunk q = qp.mode == TZ_MODE_PWREL ? q_chunk<true>(o, d, c, ch, HW, qp, E, lane)
-                                                          : q_chunk<false>(o, d, c, ch, HW, qp, E, lane);
+                const QChunk q = qp.mode == TZ_MODE_PWREL ? q_chunk<true, FP>(src, orig, fe0, c, ch, HW, qp, E, lane)
+                                                          : q_chunk<false, FP>(src, orig, fe0, c, ch, HW, qp, E, lane);
                 QSlot& sl = slots[r & 1][wv - 1];
                 sl.cu[lane] = q.cu;
                 sl.cl[lane] = q.cl;
@@ -451,25 +579,26 @@ __global__ __launch_bounds__(64 * (QW + 1)) void k_q_heads(const uint8_t* __rest
 // Exact repair of the segment guesses, one wave per chain, segments in order.  `st` is the TRUE open run
 // entering segment k.  It is walked through the segment's chunks (tables recomputed by this wave) until
 // the true chain shares a head with the guessed one (mask spec[chunk]): guessed heads before that point
-// are erased (sentinel), true ones written; from the common head on the guess is right, so the true
-// state leaving the segment is the guessed one.  A segment without any common head is walked to
-// its end (worst case: the serial walk of round 1).  Finally the run open at the chain end is closed.
-__global__ __launch_bounds__(64) void k_q_stitch(const uint8_t* __restrict__ orig, const int16_t* __restrict__ diff,
+// leave the mask, true ones enter it (with their values in tmp); from the common head on the guess is
+// right, so the true state leaving the segment is the guessed one.  A segment without any common head is
+// walked to its end (worst case: the serial walk of round 1).  Finally the run open at the chain end is
+// closed.
+template <bool FP>
+__global__ __launch_bounds__(64) void k_q_stitch(QSrc src, const uint8_t* __restrict__ orig,
                                                const uint8_t* __restrict__ skip, int HW, QParams qp,
                                                const double* __restrict__ Echain, int16_t* __restrict__ tmp,
-                                               const unsigned long long* __restrict__ spec, const QState* __restrict__ seg_out) {
+                                               unsigned long long* __restrict__ spec, const QState* __restrict__ seg_out) {
     const int chain = blockIdx.x, f = chain / 3, c = chain % 3;
     if (skip[f] || HW <= 0) return;
-    const int16_t* d = diff + (size_t)f * HW * 3;
-    const uint8_t* o = orig + (size_t)f * HW * 3;
-    int16_t* t = tmp + (size_t)f * HW * 3;
+    const size_t fe0 = (size_t)f * HW * 3;
+    int16_t* t = tmp + fe0;
     const int lane = threadIdx.x;
     double E = 0.0;
     if (qp.mode == TZ_MODE_ABS) E = fabs(qp.b0);
     else if (qp.mode != TZ_MODE_PWREL) E = Echain[chain];
     const int nch = (HW + 63) >> 6;
     const int cps = (nch + QSEG - 1) / QSEG;
-    const unsigned long long* sp = spec + (size_t)chain * nch;
+    unsigned long long* sp = spec + (size_t)chain * nch;
     QState st = seg_out[chain * QSEG];          // segment 0 starts where the chain starts: its guess is the truth
     double u = st.u, l = st.l;
     int chead = st.head;
@@ -478,13 +607,13 @@ __global__ __launch_bounds__(64) void k_q_stitch(const uint8_t* __restrict__ ori
         if (c0 >= c1) break;
         bool merged = false;
         for (int ch = c0; ch < c1 && !merged; ++ch) {
-            const QChunk q = qp.mode == TZ_MODE_PWREL ? q_chunk<true>(o, d, c, ch, HW, qp, E, lane)
-                                                      : q_chunk<false>(o, d, c, ch, HW, qp, E, lane);
+            const QChunk q = qp.mode == TZ_MODE_PWREL ? q_chunk<true, FP>(src, orig, fe0, c, ch, HW, qp, E, lane)
+                                                      : q_chunk<false, FP>(src, orig, fe0, c, ch, HW, qp, E, lane);
             const unsigned long long S = sp[ch];
             const double eu = u < q.pu ? u : q.pu, el = l > q.pl ? l : q.pl;
             const unsigned long long brk = __ballot(eu - el < 0.0);
             if (brk == 0ull) {                  // the true run swallows the chunk: every guessed head in it is wrong
-                if ((S >> lane) & 1ull) t[(size_t)(ch * 64 + lane) * 3 + c] = TZ_SENTINEL;
+                if (lane == 0) sp[ch] = 0ull;
                 u = q_rl_d(eu, 63);
                 l = q_rl_d(el, 63);
                 continue;
@@ -500,12 +629,13 @@ __global__ __launch_bounds__(64) void k_q_stitch(const uint8_t* __restrict__ ori
             const int m = common ? __ffsll((long long)common) - 1 : 64;  // first common head
             const unsigned long long below = m >= 64 ? ~0ull : ((1ull << m) - 1ull);
             const bool mine = (below >> lane) & 1ull;
-            if (mine && ((S >> lane) & 1ull) && !((T >> lane) & 1ull)) t[(size_t)(ch * 64 + lane) * 3 + c] = TZ_SENTINEL;
             if (mine && ((T >> lane) & 1ull) && q.nxt < 64)
                 t[(size_t)(ch * 64 + lane) * 3 + c] = (int16_t)(long long)((q.cu + q.cl) / 2);
-            // the carried run closes at j0 (written after the erasures: its head may be a guessed head of this chunk)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
+            if (lane == 0) {
+                sp[ch] = (S & ~below) | (T & below);
+                // the carried run closes at j0: its head keeps its mask bit and gets its value
+                t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
+            }
             if (common) {
                 merged = true;
             } else {
@@ -525,84 +655,292 @@ __global__ __launch_bounds__(64) void k_q_stitch(const uint8_t* __restrict__ ori
     if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((u + l) / 2);
 }
 
-static constexpr int QFB = 2048;  // pixels per fill block
+static constexpr int QFB = 2048;  // pixels per fill item (32 chunks of 64: a lane per mask word when a wave looks back)
 
-__global__ __launch_bounds__(256) void k_q_last(const int16_t* __restrict__ tmp, const uint8_t* __restrict__ skip,
-                                                int HW, int nblk, int16_t* __restrict__ carry) {
-    int f = blockIdx.y, b = blockIdx.x;
+// value of the last run head in each fill item (from the masks: one thread per (frame, item, channel))
+__global__ __launch_bounds__(256) void k_q_last(const int16_t* __restrict__ tmp, const unsigned long long* __restrict__ spec,
+                                                const uint8_t* __restrict__ skip, int HW, int nch, int nblk, int nframes,
+                                                int16_t* __restrict__ carry) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nframes * nblk * 3) return;
+    const int c = id % 3, b = (id / 3) % nblk, f = id / (3 * nblk);
     if (skip[f]) return;
-    __shared__ int best[3];
-    if (threadIdx.x < 3) best[threadIdx.x] = -1;
-    __syncthreads();
-    const int16_t* t = tmp + (size_t)f * HW * 3;
-    int p0 = b * QFB, p1 = min(HW, p0 + QFB);
-    int loc[3] = {-1, -1, -1};
-    for (int p = p0 + threadIdx.x; p < p1; p += 256)
-        for (int c = 0; c < 3; ++c)
-            if (t[(size_t)p * 3 + c] != TZ_SENTINEL) loc[c] = p;
-    for (int c = 0; c < 3; ++c)
-        if (loc[c] >= 0) atomicMax(&best[c], loc[c]);
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        int c = threadIdx.x;
-        carry[((size_t)f * nblk + b) * 3 + c] = best[c] >= 0 ? t[(size_t)best[c] * 3 + c] : TZ_SENTINEL;
-    }
-}
-
-__global__ void k_q_carry(int16_t* __restrict__ carry, const uint8_t* __restrict__ skip, int nblk, int nframes) {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= nframes * 3) return;
-    int f = id / 3, c = id % 3;
-    if (skip[f]) return;
-    int16_t run = TZ_SENTINEL;
-    for (int b = 0; b < nblk; ++b) {
-        size_t k = ((size_t)f * nblk + b) * 3 + c;
-        int16_t v = carry[k];
-        carry[k] = run;  // exclusive: last head value strictly before this block
-        if (v != TZ_SENTINEL) run = v;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_q_fill(const int16_t* __restrict__ tmp, const uint8_t* __restrict__ skip,
-                                                int HW, int nblk, const int16_t* __restrict__ carry,
-                                                int16_t* __restrict__ diff) {
-    int f = blockIdx.y, b = blockIdx.x;
-    if (skip[f]) return;
-    __shared__ int16_t wave_last[4][3];
-    __shared__ int16_t running[3];
-    const int16_t* t = tmp + (size_t)f * HW * 3;
-    int16_t* d = diff + (size_t)f * HW * 3;
-    if (threadIdx.x < 3) running[threadIdx.x] = carry[((size_t)f * nblk + b) * 3 + threadIdx.x];
-    __syncthreads();
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int p0 = b * QFB, p1 = min(HW, p0 + QFB);
-    for (int base = p0; base < p1; base += 256) {
-        int p = base + threadIdx.x;
-        int v[3];
-        for (int c = 0; c < 3; ++c) v[c] = p < p1 ? (int)t[(size_t)p * 3 + c] : (int)TZ_SENTINEL;
-        // inclusive forward-fill scan inside the wave
-        for (int s = 1; s < 64; s <<= 1)
-            for (int c = 0; c < 3; ++c) {
-                int up = __shfl_up(v[c], s);
-                if (lane >= s && v[c] == (int)TZ_SENTINEL) v[c] = up;
-            }
-        if (lane == 63)
-            for (int c = 0; c < 3; ++c) wave_last[wv][c] = (int16_t)v[c];
-        __syncthreads();
-        int16_t res[3];
-        for (int c = 0; c < 3; ++c) {
-            int pre = running[c];
-            for (int w = 0; w < wv; ++w)
-                if (wave_last[w][c] != TZ_SENTINEL) pre = wave_last[w][c];
-            res[c] = (int16_t)(v[c] != (int)TZ_SENTINEL ? v[c] : pre);
+    const unsigned long long* sp = spec + (size_t)(f * 3 + c) * nch;
+    const int w0 = b * (QFB / 64), w1 = min(nch, w0 + QFB / 64);
+    int16_t v = TZ_SENTINEL;
+    for (int w = w1 - 1; w >= w0; --w) {
+        const unsigned long long m = sp[w];
+        if (m) {
+            const int pos = w * 64 + 63 - __clzll((long long)m);
+            v = tmp[((size_t)f * HW + pos) * 3 + c];
+            break;
         }
-        if (p < p1)
-            for (int c = 0; c < 3; ++c) d[(size_t)p * 3 + c] = res[c];
-        __syncthreads();
-        if (threadIdx.x == 255)
-            for (int c = 0; c < 3; ++c) running[c] = res[c];
-        __syncthreads();
     }
+    carry[((size_t)f * nblk + b) * 3 + c] = v;
+}
+
+// exclusive forward fill over the items of a chain, one wave per chain (64 items per pass; the last value seen
+// carries from pass to pass); ftail = value of the chain's last run (its last element)
+__global__ __launch_bounds__(64) void k_q_carry(int16_t* __restrict__ carry, const uint8_t* __restrict__ skip, int nblk, int nframes,
+                                                int16_t* __restrict__ ftail) {
+    const int id = blockIdx.x, lane = threadIdx.x;
+    if (id >= nframes * 3) return;
+    const int f = id / 3, c = id % 3;
+    if (skip[f]) return;
+    int run = (int)TZ_SENTINEL;
+    for (int b0 = 0; b0 < nblk; b0 += 64) {
+        const int b = b0 + lane;
+        const size_t k = ((size_t)f * nblk + b) * 3 + c;
+        const int v = b < nblk ? (int)carry[k] : (int)TZ_SENTINEL;
+        const unsigned long long has = __ballot(v != (int)TZ_SENTINEL);
+        const unsigned long long below = has & ((1ull << lane) - 1ull);       // items in front of mine that hold a head
+        const int src = below ? 63 - __clzll((long long)below) : lane;
+        const int got = __shfl(v, src, 64);
+        if (b < nblk) carry[k] = (int16_t)(below ? got : run);                 // exclusive: last head value strictly before this item
+        if (has) run = __shfl(v, 63 - __clzll((long long)has), 64);
+    }
+    if (lane == 0) ftail[id] = (int16_t)run;
+}
+
+// Forward fill of the run values, one wave per 64-element chunk, no communication between waves: the masks
+// say where the run heads are, so a lane finds the head of ITS run with bit operations (highest mask bit at or
+// below its lane; else the highest bit of the nearest non-empty mask word in front of the chunk within its
+// item of 2048 pixels; else the item's carry value from k_q_last / k_q_carry) and fetches the value there --
+// rounds 1-2 propagated the values themselves with 18 shuffles and two barriers per 256 pixels.
+//  SYM == false: the filled values go back into the delta stack (frames flagged in `skip` are not touched).
+//  SYM == true : fused encode.  Every frame is processed: a skipped frame's deltas are trunc(pred*255) - orig
+//                (0 where zero_mask says so: compress.py:314); the values go on through the spatial delta over
+//                the whole flattened stack (compress.py:73-77: the element in front of a pixel's first channel
+//                is the previous pixel's last channel, across chunk, item and frame boundaries), the 1600 offset
+//                and the histogram (compress.py:346-355), and leave as symbols in 16-byte stores (a wave's 192
+//                symbols pass through 384 bytes of its own LDS).
+struct QFill {
+    const int16_t* tmp;
+    const unsigned long long* spec;
+    const uint8_t *skip, *zero;
+    const int16_t *carry, *ftail;
+    const float* pred;
+    const uint8_t* orig;
+    int16_t* out;           // delta stack (in place) or symbols
+    unsigned long long* hist;
+    int16_t* edge;
+    int HW, nch, nblk, nframes, apply_offset;
+};
+
+static constexpr int QF_THREADS = 512, QF_WAVES = QF_THREADS / 64;
+
+// what a wave needs of one chunk before it can fetch run values: loaded one chunk AHEAD of its use, so that the
+// mask / carry round trip of chunk k+1 overlaps the value gather and the stores of chunk k
+struct QFillPre {
+    unsigned long long mw[3], m[3];
+    int cv[3];
+};
+
+__device__ __forceinline__ QFillPre q_fill_pre(const QFill& a, long long wk, int lane) {
+    QFillPre r;
+    const int nch = a.nch;
+    const int f = (int)(wk / nch), ch = (int)(wk % nch);
+    const int b = (ch * 64) / QFB, w0 = b * (QFB / 64);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned long long* sp = a.spec + (size_t)(f * 3 + c) * nch;
+        const int wi = w0 + lane;
+        r.mw[c] = (lane < QFB / 64 && wi < ch) ? sp[wi] : 0ull;   // the item's mask words in front of the chunk, one per lane
+        r.m[c] = sp[ch];
+        r.cv[c] = (int)a.carry[((size_t)f * a.nblk + b) * 3 + c];  // value of the last head in front of the item
+    }
+    return r;
+}
+
+template <bool SYM, bool HIST>
+__global__ __launch_bounds__(QF_THREADS) void k_q_fill(const QFill a) {
+    __shared__ unsigned hraw[HIST ? HL_WORDS : 1];
+    __shared__ uint4 stage[SYM ? QF_WAVES * 24 : 1];   // 64 pixels x 3 symbols x 2 bytes per wave
+    HistLds& hl = *(HistLds*)hraw;
+    HistAcc acc;
+    const int centre = a.apply_offset ? TZ_OFFSET : 0;
+    if (HIST) hist_clear(hl);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int HW = a.HW, nch = a.nch;
+    const long long nwork = (long long)a.nframes * nch;           // chunks of pixels (all three channels of them)
+    const long long wstride = (long long)gridDim.x * QF_WAVES;
+    long long wk = (long long)blockIdx.x * QF_WAVES + wv;
+    QFillPre nxt{};
+    if (wk < nwork && !a.skip[wk / nch]) nxt = q_fill_pre(a, wk, lane);
+    for (; wk < nwork; wk += wstride) {
+        const QFillPre cur = nxt;
+        if (wk + wstride < nwork && !a.skip[(wk + wstride) / nch]) nxt = q_fill_pre(a, wk + wstride, lane);
+        const int f = (int)(wk / nch), ch = (int)(wk % nch);
+        const bool skipped = a.skip[f] != 0;
+        if (!SYM && skipped) continue;
+        const size_t fe0 = (size_t)f * HW * 3;
+        const int16_t* t = a.tmp + fe0;
+        const int p = ch * 64 + lane;
+        const bool live = p < HW;
+        const int w0 = ((ch * 64) / QFB) * (QFB / 64);  // first mask word of the item this chunk belongs to
+        int res[3];
+        int prev2 = 0;                                  // SYM: channel 2 of the pixel in front of the chunk
+        bool have_prev = true;
+        if (SYM && skipped) {
+            const bool zero = a.zero[f] != 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) res[c] = (live && !zero) ? (int)(a.pred[fe0 + (size_t)p * 3 + c] * 255.0f) - (int)a.orig[fe0 + (size_t)p * 3 + c] : 0;
+            if (ch > 0) prev2 = zero ? 0 : (int)(a.pred[fe0 + (size_t)ch * 192 - 1] * 255.0f) - (int)a.orig[fe0 + (size_t)ch * 192 - 1];
+        } else {
+            int hp[3], before2 = -1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned long long mw = cur.mw[c];
+                const unsigned long long nz = __ballot(mw != 0ull);
+                // position of the last head in front of the chunk (within the item), or -1
+                int before = -1;
+                if (nz) {
+                    const int wl = 63 - __clzll((long long)nz);
+                    const unsigned long long mm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mw >> 32), wl) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mw, wl);
+                    before = (w0 + wl) * 64 + 63 - __clzll((long long)mm);
+                }
+                const unsigned long long mine = cur.m[c] & ((2ull << lane) - 1ull);
+                hp[c] = mine ? ch * 64 + 63 - __clzll((long long)mine) : before;
+                if (c == 2) before2 = before;
+            }
+            // the gathers of the three channels (and of the pixel in front) go out together
+            int16_t tv[3], tp = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tv[c] = hp[c] >= 0 ? t[(size_t)hp[c] * 3 + c] : (int16_t)0;
+            if (SYM && before2 >= 0) tp = t[(size_t)before2 * 3 + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) res[c] = hp[c] >= 0 ? (int)tv[c] : cur.cv[c];
+            prev2 = before2 >= 0 ? (int)tp : cur.cv[2];
+        }
+        if (!SYM) {
+            if (live)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a.out[fe0 + (size_t)p * 3 + c] = (int16_t)res[c];
+            continue;
+        }
+        // the element in front of the chunk's first sample when the chunk starts a frame
+        if (ch == 0) {
+            if (f == 0) have_prev = false;              // start of the stream: sd[0] = x[0]
+            else if (a.skip[f - 1]) prev2 = a.zero[f - 1] ? 0 : (int)(a.pred[fe0 - 1] * 255.0f) - (int)a.orig[fe0 - 1];
+            else prev2 = (int)a.ftail[(f - 1) * 3 + 2];
+        }
+        int prev = __shfl_up(res[2], 1);
+        if (lane == 0) prev = prev2;
+        int sd0 = prev - res[0];
+        if (!have_prev && lane == 0) sd0 = res[0];
+        const int sd1 = res[0] - res[1], sd2 = res[1] - res[2];
+        const short y0 = a.apply_offset ? (short)(TZ_OFFSET - sd0) : (short)sd0;
+        const short y1 = a.apply_offset ? (short)(TZ_OFFSET - sd1) : (short)sd1;
+        const short y2 = a.apply_offset ? (short)(TZ_OFFSET - sd2) : (short)sd2;
+        if (f == 0 && p == 0) a.edge[0] = (int16_t)res[0];
+        if (f == a.nframes - 1 && p == HW - 1) a.edge[1] = (int16_t)res[2];
+        short* so = (short*)(stage + wv * 24);
+        so[lane * 3 + 0] = y0;
+        so[lane * 3 + 1] = y1;
+        so[lane * 3 + 2] = y2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int npix = min(64, HW - ch * 64);           // HW % 8 == 0: whole 16-byte vectors
+        if (lane < npix * 3 / 8) {
+            const uint4 y = stage[wv * 24 + lane];
+            ((uint4*)(a.out + fe0 + (size_t)ch * 192))[lane] = y;
+            if (HIST) {
+                const unsigned Y[4] = {y.x, y.y, y.z, y.w};
+                hist_add8(hl, acc, Y, centre);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (HIST) hist_flush(hl, acc, centre, a.hist);
+}
+
+struct QFused {   // fused encode: symbols + histogram + edge elements instead of a delta stack
+    const float* pred;
+    const uint8_t* d_zero;
+    int apply_offset;
+    int16_t* sym;
+    unsigned long long* d_hist;
+    int16_t* d_edge;
+};
+
+static int quant_run(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const QFused* fu, const uint8_t* h_skip, int nframes,
+                     int H, int W, int mode, double b0, double b1) {
+    int HW = H * W;
+    size_t fe = (size_t)HW * 3;
+    int nblk = (HW + QFB - 1) / QFB;
+    void *d_skip, *d_E, *d_tmp, *d_carry, *d_mm, *d_spec, *d_seg, *d_ftail;
+    TZ_TRY(tz_pool_alloc(ctx, nframes, &d_skip));
+    TZ_TRY(tz_pool_alloc(ctx, sizeof(double) * 3 * nframes, &d_E));
+    TZ_TRY(tz_pool_alloc(ctx, sizeof(int) * 6 * nframes, &d_mm));
+    TZ_TRY(tz_pool_alloc(ctx, fe * nframes * 2, &d_tmp));
+    TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * nblk * 3 * 2, &d_carry));
+    TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * 3 * 2, &d_ftail));
+    const int nch = (HW + 63) / 64;
+    TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * 3 * nch * sizeof(unsigned long long), &d_spec));
+    TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * 3 * QSEG * sizeof(QState), &d_seg));
+    TZ_TRY(tz_upload(ctx, d_skip, h_skip, nframes));
+    QParams qp{mode, b0, b1};
+    QSrc src{diff, fu ? fu->pred : nullptr};
+    {
+        tz_prof_scope ps(ctx, TZP_QUANT);
+        if (mode == TZ_MODE_REL || mode == TZ_MODE_ABSREL) {
+            hipLaunchKernelGGL(k_q_mm_init, dim3((6 * nframes + 255) / 256), dim3(256), 0, ctx->stream, (int*)d_mm, 6 * nframes);
+            hipLaunchKernelGGL(k_q_minmax, dim3(QBB, nframes), dim3(256), 0, ctx->stream, orig, (const uint8_t*)d_skip, HW,
+                               (int*)d_mm);
+            hipLaunchKernelGGL(k_q_bound, dim3((3 * nframes + 63) / 64), dim3(64), 0, ctx->stream, (const int*)d_mm,
+                               (const uint8_t*)d_skip, qp, nframes, (double*)d_E);
+        }
+        if (fu) {
+            hipLaunchKernelGGL(k_q_heads<true>, dim3(nframes * 3 * QSEG), dim3(64 * (QW + 1)), 0, ctx->stream, src, orig,
+                               (const uint8_t*)d_skip, HW, qp, (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec,
+                               (QState*)d_seg);
+            hipLaunchKernelGGL(k_q_stitch<true>, dim3(nframes * 3), dim3(64), 0, ctx->stream, src, orig, (const uint8_t*)d_skip, HW,
+                               qp, (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec, (const QState*)d_seg);
+        } else {
+            hipLaunchKernelGGL(k_q_heads<false>, dim3(nframes * 3 * QSEG), dim3(64 * (QW + 1)), 0, ctx->stream, src, orig,
+                               (const uint8_t*)d_skip, HW, qp, (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec,
+                               (QState*)d_seg);
+            hipLaunchKernelGGL(k_q_stitch<false>, dim3(nframes * 3), dim3(64), 0, ctx->stream, src, orig, (const uint8_t*)d_skip, HW,
+                               qp, (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec, (const QState*)d_seg);
+        }
+        hipLaunchKernelGGL(k_q_last, dim3((nframes * nblk * 3 + 255) / 256), dim3(256), 0, ctx->stream, (const int16_t*)d_tmp,
+                           (const unsigned long long*)d_spec, (const uint8_t*)d_skip, HW, nch, nblk, nframes, (int16_t*)d_carry);
+        hipLaunchKernelGGL(k_q_carry, dim3(nframes * 3), dim3(64), 0, ctx->stream, (int16_t*)d_carry,
+                           (const uint8_t*)d_skip, nblk, nframes, (int16_t*)d_ftail);
+    }
+    QFill a{};
+    a.tmp = (const int16_t*)d_tmp;
+    a.spec = (const unsigned long long*)d_spec;
+    a.skip = (const uint8_t*)d_skip;
+    a.carry = (const int16_t*)d_carry;
+    a.ftail = (const int16_t*)d_ftail;
+    a.HW = HW;
+    a.nch = nch;
+    a.nblk = nblk;
+    a.nframes = nframes;
+    const long long nwork = (long long)nframes * nch;
+    const int grid = (int)std::min<long long>(4 * kCUs, (nwork + QF_WAVES - 1) / QF_WAVES);
+    if (!fu) {
+        tz_prof_scope ps(ctx, TZP_QUANT);
+        a.out = diff;
+        hipLaunchKernelGGL((k_q_fill<false, false>), dim3(grid), dim3(QF_THREADS), 0, ctx->stream, a);
+    } else {
+        tz_prof_scope ps(ctx, TZP_SDELTA);
+        a.zero = fu->d_zero;
+        a.pred = fu->pred;
+        a.orig = orig;
+        a.out = fu->sym;
+        a.hist = fu->d_hist;
+        a.edge = fu->d_edge;
+        a.apply_offset = fu->apply_offset;
+        if (fu->d_hist) hipLaunchKernelGGL((k_q_fill<true, true>), dim3(grid), dim3(QF_THREADS), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_q_fill<true, false>), dim3(grid), dim3(QF_THREADS), 0, ctx->stream, a);
+    }
+    TZ_HIP(ctx, hipGetLastError());
+    return TZ_OK;
 }
 
 int tzk_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8_t* h_skip, int nframes, int H,
@@ -613,154 +951,23 @@ int tzk_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8
     if (mode == TZ_MODE_PWREL && b0 < 0.0)
         return tz_fail(ctx, TZ_ERR_INVALID, "pwrel bound must be >= 0 (the reference raises on a negative one)");
     if (nframes <= 0 || H <= 0 || W <= 0) return TZ_OK;
-    int HW = H * W;
-    size_t fe = (size_t)HW * 3;
-    int nblk = (HW + QFB - 1) / QFB;
-    void *d_skip, *d_E, *d_tmp, *d_carry, *d_mm, *d_spec, *d_seg;
-    TZ_TRY(tz_pool_alloc(ctx, nframes, &d_skip));
-    TZ_TRY(tz_pool_alloc(ctx, sizeof(double) * 3 * nframes, &d_E));
-    TZ_TRY(tz_pool_alloc(ctx, sizeof(int) * 6 * nframes, &d_mm));
-    TZ_TRY(tz_pool_alloc(ctx, fe * nframes * 2, &d_tmp));
-    TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * nblk * 3 * 2, &d_carry));
-    const int nch = (HW + 63) / 64;
-    TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * 3 * nch * sizeof(unsigned long long), &d_spec));
-    TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * 3 * QSEG * sizeof(QState), &d_seg));
-    TZ_TRY(tz_upload(ctx, d_skip, h_skip, nframes));
-    QParams qp{mode, b0, b1};
-    tz_prof_scope ps(ctx, TZP_QUANT);
-    if (mode == TZ_MODE_REL || mode == TZ_MODE_ABSREL) {
-        hipLaunchKernelGGL(k_q_mm_init, dim3((6 * nframes + 255) / 256), dim3(256), 0, ctx->stream, (int*)d_mm, 6 * nframes);
-        hipLaunchKernelGGL(k_q_minmax, dim3(QBB, nframes), dim3(256), 0, ctx->stream, orig, (const uint8_t*)d_skip, HW,
-                           (int*)d_mm);
-        hipLaunchKernelGGL(k_q_bound, dim3((3 * nframes + 63) / 64), dim3(64), 0, ctx->stream, (const int*)d_mm,
-                           (const uint8_t*)d_skip, qp, nframes, (double*)d_E);
-    }
-    hipLaunchKernelGGL(k_q_init, dim3(grid_for(fe * nframes, 256)), dim3(256), 0, ctx->stream, (int16_t*)d_tmp,
-                       (const uint8_t*)d_skip, fe, nframes);
-    hipLaunchKernelGGL(k_q_heads, dim3(nframes * 3 * QSEG), dim3(64 * (QW + 1)), 0, ctx->stream, orig, (const int16_t*)diff,
-                       (const uint8_t*)d_skip, HW, qp, (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec,
-                       (QState*)d_seg);
-    hipLaunchKernelGGL(k_q_stitch, dim3(nframes * 3), dim3(64), 0, ctx->stream, orig, (const int16_t*)diff,
-                       (const uint8_t*)d_skip, HW, qp, (const double*)d_E, (int16_t*)d_tmp, (const unsigned long long*)d_spec,
-                       (const QState*)d_seg);
-    hipLaunchKernelGGL(k_q_last, dim3(nblk, nframes), dim3(256), 0, ctx->stream, (const int16_t*)d_tmp,
-                       (const uint8_t*)d_skip, HW, nblk, (int16_t*)d_carry);
-    hipLaunchKernelGGL(k_q_carry, dim3((nframes * 3 + 63) / 64), dim3(64), 0, ctx->stream, (int16_t*)d_carry,
-                       (const uint8_t*)d_skip, nblk, nframes);
-    hipLaunchKernelGGL(k_q_fill, dim3(nblk, nframes), dim3(256), 0, ctx->stream, (const int16_t*)d_tmp,
-                       (const uint8_t*)d_skip, HW, nblk, (const int16_t*)d_carry, diff);
-    TZ_HIP(ctx, hipGetLastError());
+    return quant_run(ctx, orig, diff, nullptr, h_skip, nframes, H, W, mode, b0, b1);
+}
+
+// Lossy fused encode (compress.py:292-355 without a delta stack in memory): applies to unpadded frames with
+// whole 16-byte groups per frame; *done says whether it ran (else the caller takes the unfused kernels).
+int tzk_quant_sd_fused(tz_ctx* ctx, const float* pred, const uint8_t* orig, const uint8_t* d_zero_mask, const uint8_t* h_skip,
+                       int nframes, int H, int W, int Hp, int Wp, int mode, double b0, double b1, int apply_offset,
+                       int16_t* sym, unsigned long long* d_hist, int16_t* d_edge, bool* done) {
+    *done = false;
+    if (mode < 0 || mode > 3) return tz_fail(ctx, TZ_ERR_INVALID, "unknown error-bound mode %d", mode);
+    if (mode == TZ_MODE_PWREL && b0 < 0.0)
+        return tz_fail(ctx, TZ_ERR_INVALID, "pwrel bound must be >= 0 (the reference raises on a negative one)");
+    if (H != Hp || W != Wp || ((size_t)H * W) % 8 || nframes <= 0 || (((uintptr_t)sym) & 15)) return TZ_OK;
+    QFused fu{pred, d_zero_mask, apply_offset, sym, d_hist, d_edge};
+    TZ_TRY(quant_run(ctx, orig, nullptr, &fu, h_skip, nframes, H, W, mode, b0, b1));
+    *done = true;
     return TZ_OK;
-}
-
-// ------------------------------------------------------------- block-private symbol histogram
-// compress.py:354 (bincount of the symbols 1600 - sd).  The symbols of a prediction residual pile up
-// on a handful of values around the centre c (1600, or 0 without the offset), so a plain LDS
-// histogram spends its time serialising atomics on the same few words (rounds 1-2: one copy per wave,
-// 4.7 M bank-conflict cycles per 7.9 M LDS operations, the spatial-delta kernel ran at 41 % of HBM
-// against 74 % without the histogram).  Now:
-//   * the centre symbol never touches the bins: a wave counts it with a ballot into a scalar register;
-//   * the 128 bins around c have 8 copies per wave, interleaved as [bin][copy] with copy = lane & 7, so
-//     that a wave's 64 lanes spread over all 32 banks (bank = (bin % 4) * 8 + copy) and only the ~2 lanes
-//     that share copy AND bin % 4 meet in a bank;
-//   * everything else (rare) goes to one full-range copy per block.
-// flush() folds the copies into the full-range one and adds its non-zero bins to the global counters.
-static constexpr int HC_HALF = 64, HC_BINS = 2 * HC_HALF, HC_COPIES = 8;
-static constexpr int HC_WAVE = (HC_BINS + 1) * HC_COPIES;   // + one junk bin per copy (see hist_add8)
-// Blocks of the histogram kernels are 1024 threads, two per CU: what a block's flush costs is global --
-// every block adds each of its non-zero bins to the same ~450 counters, and same-address atomics from
-// different workgroups are served one after the other (about 12 ns each): with 2048 blocks of 256
-// threads that was 25 us of a 76 us kernel, whatever the LDS part did.
-static constexpr int HB_THREADS = 1024, HB_WAVES = HB_THREADS / 64, HB_GRID = 2 * kCUs;
-static constexpr int HL_CENTRAL = 0, HL_FULL = HB_WAVES * HC_WAVE, HL_SINK = HL_FULL + TZ_NBINS + 1, HL_WORDS = HL_SINK + 64;
-struct HistLds {
-    // [waves][bin][copy] | full range | one sink word per lane
-    unsigned w[HL_WORDS];
-};
-
-struct HistAcc {
-    unsigned n0 = 0;   // wave-uniform count of the centre symbol
-};
-
-__device__ __forceinline__ void hist_clear(HistLds& h) {
-    for (int k = threadIdx.x; k < HL_WORDS; k += blockDim.x) h.w[k] = 0;
-    __syncthreads();
-}
-
-// Eight symbols of one lane, packed two per dword.  The update is ONE unconditional LDS atomic per
-// element in straight-line code (a branch per element cost more than the atomics it saved: the
-// spatial-delta kernel is as much VALU-issue as HBM bound): the centre symbol goes to the lane's own
-// sink word (it is counted by the ballot), symbols within +-64 of the centre to [bin][copy], anything
-// farther to the junk bin of the copy -- and, in a branch the wave takes only when one of its 512
-// symbols is that far out, to the full-range bins.
-__device__ __forceinline__ void hist_add8(HistLds& h, HistAcc& acc, const unsigned* Y, int c) {
-    const int lane = threadIdx.x & 63;
-    const int base = HL_CENTRAL + (int)(threadIdx.x >> 6) * HC_WAVE + (lane & 7), sink = HL_SINK + lane;
-    unsigned far = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int y = (k & 1) ? ((int)Y[k >> 1] >> 16) : (int)(short)(Y[k >> 1] & 0xFFFFu);
-        const bool hot = y == c;
-        acc.n0 += (unsigned)__popcll(__ballot(hot));
-        const unsigned rel = (unsigned)(y - (c - HC_HALF));
-        const unsigned idx = min(rel, (unsigned)HC_BINS);
-        far |= idx >> 7;   // HC_BINS == 128
-        atomicAdd(&h.w[hot ? sink : base + (int)idx * HC_COPIES], 1u);
-    }
-    if (__any(far != 0)) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int y = (k & 1) ? ((int)Y[k >> 1] >> 16) : (int)(short)(Y[k >> 1] & 0xFFFFu);
-            if ((unsigned)(y - (c - HC_HALF)) >= (unsigned)HC_BINS && (unsigned)y < (unsigned)TZ_NBINS) atomicAdd(&h.w[HL_FULL + y], 1u);
-        }
-    }
-}
-static_assert(HC_BINS == 128, "hist_add8 takes the far flag from bit 7 of the clamped index");
-static_assert(HL_WORDS * 4 <= 80 * 1024, "two histogram blocks per CU must fit the 160 KB of LDS");
-
-// every thread of the block calls this (after its last add)
-__device__ __forceinline__ void hist_flush(HistLds& h, const HistAcc& a, int c, unsigned long long* __restrict__ hist) {
-    if ((threadIdx.x & 63) == 0 && a.n0 && c >= 0 && c < TZ_NBINS) atomicAdd(&h.w[HL_FULL + c], a.n0);
-    __syncthreads();
-    const int nw = blockDim.x >> 6;
-    for (int b = threadIdx.x; b < HC_BINS; b += blockDim.x) {
-        const int y = c - HC_HALF + b;
-        unsigned t = 0;
-        for (int w = 0; w < nw; ++w)
-#pragma unroll
-            for (int k = 0; k < HC_COPIES; ++k) t += h.w[HL_CENTRAL + w * HC_WAVE + b * HC_COPIES + k];
-        if (t && y >= 0 && y < TZ_NBINS) atomicAdd(&h.w[HL_FULL + y], t);
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < TZ_NBINS; k += blockDim.x) {
-        const unsigned v = h.w[HL_FULL + k];
-        if (v) atomicAdd(&hist[k], (unsigned long long)v);
-    }
-}
-
-typedef short short2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b) {   // two int16 lanes, wrap-around
-    const short2v r = __builtin_bit_cast(short2v, a) - __builtin_bit_cast(short2v, b);
-    return __builtin_bit_cast(unsigned, r);
-}
-
-// spatial delta of 8 consecutive int16 (V, two per dword) given the element in front of them:
-// sd[k] = x[k-1] - x[k]; symbols y = 1600 - sd when `offs` = (1600, 1600), y = sd when offs is 0 and `negate`
-// is false ... both forms are y = offs - (P - V) resp. P - V; P is V shifted up by one element.
-__device__ __forceinline__ void sdelta8(const uint4 V, unsigned prev16, bool apply_offset, unsigned* Y) {
-    const unsigned P0 = __builtin_amdgcn_alignbit(V.x, prev16 << 16, 16);
-    const unsigned P1 = __builtin_amdgcn_alignbit(V.y, V.x, 16);
-    const unsigned P2 = __builtin_amdgcn_alignbit(V.z, V.y, 16);
-    const unsigned P3 = __builtin_amdgcn_alignbit(V.w, V.z, 16);
-    const unsigned C = ((unsigned)TZ_OFFSET << 16) | (unsigned)TZ_OFFSET;
-    Y[0] = pk_sub(P0, V.x);
-    Y[1] = pk_sub(P1, V.y);
-    Y[2] = pk_sub(P2, V.z);
-    Y[3] = pk_sub(P3, V.w);
-    if (apply_offset) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Y[j] = pk_sub(C, Y[j]);
-    }
 }
 
 // ------------------------------------------------------- spatial delta (+offset, histogram)

@@ -161,6 +161,9 @@ int tzk_delta_sd_fused(tz_ctx*, const float* pred, const uint8_t* orig, const ui
                        bool* done);
 int tzk_error_bound(tz_ctx*, const uint8_t* orig, int16_t* diff, const uint8_t* h_skip, int nframes, int H,
                     int W, int mode, double b0, double b1);
+int tzk_quant_sd_fused(tz_ctx*, const float* pred, const uint8_t* orig, const uint8_t* d_zero_mask, const uint8_t* h_skip,
+                       int nframes, int H, int W, int Hp, int Wp, int mode, double b0, double b1, int apply_offset,
+                       int16_t* sym, unsigned long long* d_hist, int16_t* d_edge, bool* done);
 int tzk_spatial_delta(tz_ctx*, const int16_t* in, size_t n, int has_carry, int16_t carry, int apply_offset,
                       int16_t* out, unsigned long long* d_hist);
 int tzk_lut(tz_ctx*, const int16_t* in, size_t n, const int16_t* h_lut2112, int post_offset, int16_t* out);
