@@ -734,15 +734,16 @@ static constexpr int QF_THREADS = 512, QF_WAVES = QF_THREADS / 64;
 struct QFillPre {
     unsigned long long mw[3], m[3];
     int cv[3];
+    int skipped;
 };
 
-__device__ __forceinline__ QFillPre q_fill_pre(const QFill& a, long long wk, int lane) {
+__device__ __forceinline__ QFillPre q_fill_pre(const QFill& a, int f, int ch, int lane) {
     QFillPre r;
     const int nch = a.nch;
-    const int f = (int)(wk / nch), ch = (int)(wk % nch);
     const int b = (ch * 64) / QFB, w0 = b * (QFB / 64);
+    r.skipped = a.skip[f];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 3; ++c) {   // (a skipped frame's entries are never written: loaded all the same, not used)
         const unsigned long long* sp = a.spec + (size_t)(f * 3 + c) * nch;
         const int wi = w0 + lane;
         r.mw[c] = (lane < QFB / 64 && wi < ch) ? sp[wi] : 0ull;   // the item's mask words in front of the chunk, one per lane
@@ -752,6 +753,119 @@ __device__ __forceinline__ QFillPre q_fill_pre(const QFill& a, long long wk, int
     return r;
 }
 
+// first half of a work item: where the run values are, and the loads that fetch them (issued, not yet used)
+struct QFillMid {
+    int hp[3], before2;
+    int16_t tv[3], tp;
+    int res[3], prev2;   // a skipped frame's raw deltas (fused encode)
+    bool skipped, valid;
+};
+
+template <bool SYM>
+__device__ __forceinline__ QFillMid q_fill_a(const QFill& a, const QFillPre& cur, int f, int ch, int lane, bool valid) {
+    QFillMid m{};
+    m.valid = valid;
+    m.skipped = cur.skipped != 0;
+    if (!valid || (!SYM && m.skipped)) return m;
+    const int HW = a.HW;
+    const size_t fe0 = (size_t)f * HW * 3;
+    const int16_t* t = a.tmp + fe0;
+    const int p = ch * 64 + lane;
+    const int w0 = ((ch * 64) / QFB) * (QFB / 64);  // first mask word of the item this chunk belongs to
+    if (SYM && m.skipped) {
+        const bool zero = a.zero[f] != 0, live = p < HW;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m.res[c] = (live && !zero) ? (int)(a.pred[fe0 + (size_t)p * 3 + c] * 255.0f) - (int)a.orig[fe0 + (size_t)p * 3 + c] : 0;
+        if (ch > 0) m.prev2 = zero ? 0 : (int)(a.pred[fe0 + (size_t)ch * 192 - 1] * 255.0f) - (int)a.orig[fe0 + (size_t)ch * 192 - 1];
+        return m;
+    }
+    m.before2 = -1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned long long mw = cur.mw[c];
+        const unsigned long long nz = __ballot(mw != 0ull);
+        // position of the last head in front of the chunk (within the item), or -1
+        int before = -1;
+        if (nz) {
+            const int wl = 63 - __clzll((long long)nz);
+            const unsigned long long mm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mw >> 32), wl) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mw, wl);
+            before = (w0 + wl) * 64 + 63 - __clzll((long long)mm);
+        }
+        const unsigned long long mine = cur.m[c] & ((2ull << lane) - 1ull);
+        m.hp[c] = mine ? ch * 64 + 63 - __clzll((long long)mine) : before;
+        if (c == 2) m.before2 = before;
+    }
+    // the gathers of the three channels (and of the pixel in front) go out together
+#pragma unroll
+    for (int c = 0; c < 3; ++c) m.tv[c] = m.hp[c] >= 0 ? t[(size_t)m.hp[c] * 3 + c] : (int16_t)0;
+    m.tp = (SYM && m.before2 >= 0) ? t[(size_t)m.before2 * 3 + 2] : (int16_t)0;
+    return m;
+}
+
+template <bool SYM, bool HIST>
+__device__ __forceinline__ void q_fill_b(const QFill& a, const QFillPre& cur, const QFillMid& m, int f, int ch, int lane, int wv,
+                                         uint4* stage, HistLds& hl, HistAcc& acc, int centre) {
+    if (!m.valid || (!SYM && m.skipped)) return;
+    const int HW = a.HW;
+    const size_t fe0 = (size_t)f * HW * 3;
+    const int p = ch * 64 + lane;
+    int res[3], prev2;
+    if (SYM && m.skipped) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) res[c] = m.res[c];
+        prev2 = m.prev2;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) res[c] = m.hp[c] >= 0 ? (int)m.tv[c] : cur.cv[c];
+        prev2 = m.before2 >= 0 ? (int)m.tp : cur.cv[2];
+    }
+    if (!SYM) {
+        if (p < HW)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.out[fe0 + (size_t)p * 3 + c] = (int16_t)res[c];
+        return;
+    }
+    // the element in front of the chunk's first sample when the chunk starts a frame
+    bool have_prev = true;
+    if (ch == 0) {
+        if (f == 0) have_prev = false;              // start of the stream: sd[0] = x[0]
+        else if (a.skip[f - 1]) prev2 = a.zero[f - 1] ? 0 : (int)(a.pred[fe0 - 1] * 255.0f) - (int)a.orig[fe0 - 1];
+        else prev2 = (int)a.ftail[(f - 1) * 3 + 2];
+    }
+    int prev = __shfl_up(res[2], 1);
+    if (lane == 0) prev = prev2;
+    int sd0 = prev - res[0];
+    if (!have_prev && lane == 0) sd0 = res[0];
+    const int sd1 = res[0] - res[1], sd2 = res[1] - res[2];
+    const short y0 = a.apply_offset ? (short)(TZ_OFFSET - sd0) : (short)sd0;
+    const short y1 = a.apply_offset ? (short)(TZ_OFFSET - sd1) : (short)sd1;
+    const short y2 = a.apply_offset ? (short)(TZ_OFFSET - sd2) : (short)sd2;
+    if (f == 0 && p == 0) a.edge[0] = (int16_t)res[0];
+    if (f == a.nframes - 1 && p == HW - 1) a.edge[1] = (int16_t)res[2];
+    short* so = (short*)(stage + wv * 24);
+    so[lane * 3 + 0] = y0;
+    so[lane * 3 + 1] = y1;
+    so[lane * 3 + 2] = y2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int npix = min(64, HW - ch * 64);           // HW % 8 == 0: whole 16-byte vectors
+    if (lane < npix * 3 / 8) {
+        const uint4 y = stage[wv * 24 + lane];
+        ((uint4*)(a.out + fe0 + (size_t)ch * 192))[lane] = y;
+        if (HIST) {
+            const unsigned Y[4] = {y.x, y.y, y.z, y.w};
+            hist_add8(hl, acc, Y, centre);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The mask / carry words of a wave's NEXT work item are loaded one iteration ahead.  (The kernel is bound by the
+// vector instructions a 64-pixel item costs, about 300 for its 192 symbols, not by memory: two items in flight per
+// wave made it slower, 172 -> 211 us at cfg3.)
 template <bool SYM, bool HIST>
 __global__ __launch_bounds__(QF_THREADS) void k_q_fill(const QFill a) {
     __shared__ unsigned hraw[HIST ? HL_WORDS : 1];
@@ -761,98 +875,26 @@ __global__ __launch_bounds__(QF_THREADS) void k_q_fill(const QFill a) {
     const int centre = a.apply_offset ? TZ_OFFSET : 0;
     if (HIST) hist_clear(hl);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int HW = a.HW, nch = a.nch;
-    const long long nwork = (long long)a.nframes * nch;           // chunks of pixels (all three channels of them)
-    const long long wstride = (long long)gridDim.x * QF_WAVES;
-    long long wk = (long long)blockIdx.x * QF_WAVES + wv;
+    const int nch = a.nch;
+    // work item = (frame, chunk of 64 pixels, all three channels); a wave takes every (gridDim * waves)-th of them,
+    // (f, ch) advanced without divisions
+    const int wstride = (int)gridDim.x * QF_WAVES, df = wstride / nch, dch = wstride % nch;
+    const int w_first = (int)blockIdx.x * QF_WAVES + wv;
+    int f = w_first / nch, ch = w_first % nch;
     QFillPre nxt{};
-    if (wk < nwork && !a.skip[wk / nch]) nxt = q_fill_pre(a, wk, lane);
-    for (; wk < nwork; wk += wstride) {
+    if (f < a.nframes) nxt = q_fill_pre(a, f, ch, lane);
+    while (f < a.nframes) {
         const QFillPre cur = nxt;
-        if (wk + wstride < nwork && !a.skip[(wk + wstride) / nch]) nxt = q_fill_pre(a, wk + wstride, lane);
-        const int f = (int)(wk / nch), ch = (int)(wk % nch);
-        const bool skipped = a.skip[f] != 0;
-        if (!SYM && skipped) continue;
-        const size_t fe0 = (size_t)f * HW * 3;
-        const int16_t* t = a.tmp + fe0;
-        const int p = ch * 64 + lane;
-        const bool live = p < HW;
-        const int w0 = ((ch * 64) / QFB) * (QFB / 64);  // first mask word of the item this chunk belongs to
-        int res[3];
-        int prev2 = 0;                                  // SYM: channel 2 of the pixel in front of the chunk
-        bool have_prev = true;
-        if (SYM && skipped) {
-            const bool zero = a.zero[f] != 0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) res[c] = (live && !zero) ? (int)(a.pred[fe0 + (size_t)p * 3 + c] * 255.0f) - (int)a.orig[fe0 + (size_t)p * 3 + c] : 0;
-            if (ch > 0) prev2 = zero ? 0 : (int)(a.pred[fe0 + (size_t)ch * 192 - 1] * 255.0f) - (int)a.orig[fe0 + (size_t)ch * 192 - 1];
-        } else {
-            int hp[3], before2 = -1;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const unsigned long long mw = cur.mw[c];
-                const unsigned long long nz = __ballot(mw != 0ull);
-                // position of the last head in front of the chunk (within the item), or -1
-                int before = -1;
-                if (nz) {
-                    const int wl = 63 - __clzll((long long)nz);
-                    const unsigned long long mm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mw >> 32), wl) << 32) |
-                                                  (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mw, wl);
-                    before = (w0 + wl) * 64 + 63 - __clzll((long long)mm);
-                }
-                const unsigned long long mine = cur.m[c] & ((2ull << lane) - 1ull);
-                hp[c] = mine ? ch * 64 + 63 - __clzll((long long)mine) : before;
-                if (c == 2) before2 = before;
-            }
-            // the gathers of the three channels (and of the pixel in front) go out together
-            int16_t tv[3], tp = 0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) tv[c] = hp[c] >= 0 ? t[(size_t)hp[c] * 3 + c] : (int16_t)0;
-            if (SYM && before2 >= 0) tp = t[(size_t)before2 * 3 + 2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) res[c] = hp[c] >= 0 ? (int)tv[c] : cur.cv[c];
-            prev2 = before2 >= 0 ? (int)tp : cur.cv[2];
+        const int fc = f, chc = ch;
+        f += df;
+        ch += dch;
+        if (ch >= nch) {
+            ch -= nch;
+            ++f;
         }
-        if (!SYM) {
-            if (live)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) a.out[fe0 + (size_t)p * 3 + c] = (int16_t)res[c];
-            continue;
-        }
-        // the element in front of the chunk's first sample when the chunk starts a frame
-        if (ch == 0) {
-            if (f == 0) have_prev = false;              // start of the stream: sd[0] = x[0]
-            else if (a.skip[f - 1]) prev2 = a.zero[f - 1] ? 0 : (int)(a.pred[fe0 - 1] * 255.0f) - (int)a.orig[fe0 - 1];
-            else prev2 = (int)a.ftail[(f - 1) * 3 + 2];
-        }
-        int prev = __shfl_up(res[2], 1);
-        if (lane == 0) prev = prev2;
-        int sd0 = prev - res[0];
-        if (!have_prev && lane == 0) sd0 = res[0];
-        const int sd1 = res[0] - res[1], sd2 = res[1] - res[2];
-        const short y0 = a.apply_offset ? (short)(TZ_OFFSET - sd0) : (short)sd0;
-        const short y1 = a.apply_offset ? (short)(TZ_OFFSET - sd1) : (short)sd1;
-        const short y2 = a.apply_offset ? (short)(TZ_OFFSET - sd2) : (short)sd2;
-        if (f == 0 && p == 0) a.edge[0] = (int16_t)res[0];
-        if (f == a.nframes - 1 && p == HW - 1) a.edge[1] = (int16_t)res[2];
-        short* so = (short*)(stage + wv * 24);
-        so[lane * 3 + 0] = y0;
-        so[lane * 3 + 1] = y1;
-        so[lane * 3 + 2] = y2;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int npix = min(64, HW - ch * 64);           // HW % 8 == 0: whole 16-byte vectors
-        if (lane < npix * 3 / 8) {
-            const uint4 y = stage[wv * 24 + lane];
-            ((uint4*)(a.out + fe0 + (size_t)ch * 192))[lane] = y;
-            if (HIST) {
-                const unsigned Y[4] = {y.x, y.y, y.z, y.w};
-                hist_add8(hl, acc, Y, centre);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if (f < a.nframes) nxt = q_fill_pre(a, f, ch, lane);
+        const QFillMid m = q_fill_a<SYM>(a, cur, fc, chc, lane, true);
+        q_fill_b<SYM, HIST>(a, cur, m, fc, chc, lane, wv, stage, hl, acc, centre);
     }
     if (HIST) hist_flush(hl, acc, centre, a.hist);
 }
