@@ -185,6 +185,7 @@ class FrameSource:
 
 
 PAYLOAD_CHUNK = 8 << 20  # int16 elements fetched and fed to zstd at a time
+KEY_PREFETCH_BYTES = 256 << 20  # key frames held on the host at once (more than that: streamed one by one)
 
 
 class _Stages:
@@ -207,17 +208,34 @@ def _stream_outputs(ctx, out_dir, nt, H, W, key, table, warm_up, shuffled, pool)
     and payload, piece by piece: nothing of size nt*H*W lives on the host."""
     n = nt * H * W * 3
     key_idx = [int(i) for i in np.nonzero(key)[0]]
-    key_frames = {i: ctx.frames_get(i, 1)[0] for i in key_idx}   # few frames; fetched before the worker starts
+    zero = np.zeros((H, W, 3), np.uint8)
+    if len(key_idx) * H * W * 3 <= KEY_PREFETCH_BYTES:
+        # the usual case, a few key frames: fetched up front, key_frame.dat is compressed by a worker while the
+        # payload is fetched and compressed here (the context is not thread-safe: the worker never touches it)
+        key_frames = {i: ctx.frames_get(i, 1)[0] for i in key_idx}
 
-    def key_file():
-        zero = np.zeros((H, W, 3), np.uint8)
+        def key_file():
+            with open(os.path.join(out_dir, "key_frame.dat"), mode='wb') as f:
+                sc = zstd.StreamCompressor(f, n, 9, max(1, zstd.default_threads() // 4))
+                for i in range(nt):
+                    sc.write(key_frames.get(i, zero))
+                return sc.close()
+
+        kf = pool.submit(key_file)
+    else:
+        # many key frames (-w 1, DWP with a tiny threshold: up to the whole stack): one at a time through
+        # frames_get, written before entropy.dat -- host memory stays independent of the number of frames
+        is_key = set(key_idx)
         with open(os.path.join(out_dir, "key_frame.dat"), mode='wb') as f:
-            sc = zstd.StreamCompressor(f, n, 9, max(1, zstd.default_threads() // 4))
+            sc = zstd.StreamCompressor(f, n, 9, zstd.default_threads())
             for i in range(nt):
-                sc.write(key_frames.get(i, zero))
-            return sc.close()
+                sc.write(ctx.frames_get(i, 1)[0] if i in is_key else zero)
+            ksize = sc.close()
 
-    kf = pool.submit(key_file)   # compresses while the payload is fetched and compressed here
+        class _Done:
+            def result(self):
+                return ksize
+        kf = _Done()
     if table is not None:
         tail = np.concatenate([table.astype(np.int64), [len(table)]])
     else:
@@ -254,15 +272,11 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
         os.mkdir(OUTPUT_DIR)
     stages = _Stages()
     src = FrameSource(DATA_DIR)
-    with open(os.path.join(OUTPUT_DIR, 'filename.txt'), 'w', encoding='UTF-8') as f:
-        f.write(f"{int(src.is_rgb)}\n")
-        for file_name in src.files:
-            f.write("%s\n" % file_name)
     nt, H, W = src.nt, src.H, src.W
     per_chunk = max(1, min(WINDOW_SIZE or 16, 64))
     with ThreadPoolExecutor(max_workers=io_threads() + 1) as pool:
         chunks = src.chunks(per_chunk, pool)   # decoding starts with the first next(); model + HIP start-up overlap it
-        stages.mark("list + probe + filename.txt")
+        stages.mark("list + probe")
         head = next(chunks)
         stages.mark("first window decoded")
         cfg, wts, model_shape = open_model(WEIGHTS_DIR)
@@ -276,6 +290,15 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
         if nt < PREPROCESS + 2:
             print("ERROR: need at least warm_up+2 images (%d given, warm_up %d)." % (nt, PREPROCESS))
             exit()
+        if SHUFFLE and (nt * H * W * 3) % 8:
+            print("ERROR: --shuffle needs nt*H*W*3 to be a multiple of 8 (%d x %d x %d x 3 is not)." % (nt, H, W))
+            exit()
+        # the job is accepted: only now does the output directory receive its first file (compress.py:133-136
+        # writes it after the images are loaded; a rejected job must not leave a partial directory behind)
+        with open(os.path.join(OUTPUT_DIR, 'filename.txt'), 'w', encoding='UTF-8') as f:
+            f.write(f"{int(src.is_rgb)}\n")
+            for file_name in src.files:
+                f.write("%s\n" % file_name)
         nwin = 1 if WINDOW_SIZE is None else max(1, (nt - PREPROCESS + WINDOW_SIZE - 1) // WINDOW_SIZE)
         ctx = make_context(cfg, wts, hp, wp, min(nwin, 64), device)
         stages.mark("context + model prepare")
@@ -303,6 +326,9 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
                 print("error_bound:{0}".format(prof["quant"][0] / 1e3) + "[sec]")
                 print("finding_difference:{0}".format(prof["spatial_delta_hist"][0] / 1e3) + "[sec]")
                 if ENTROPY_RUN:
+                    # compress.py:351-365 times 1600 - x, bincount and the table sort; the first two are fused into
+                    # the spatial-delta kernel here (timed above), what is left is the host-side sort
+                    print("table_create:{0}".format(prof["table_create"][0] / 1e3) + "[sec]")
                     print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
             _stream_outputs(ctx, OUTPUT_DIR, nt, H, W, key, table if ENTROPY_RUN else None, PREPROCESS, SHUFFLE, pool)
             stages.mark("key_frame.dat + entropy.dat")
@@ -316,11 +342,6 @@ def _run_sharded(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THR
     if rank0 and not os.path.exists(OUTPUT_DIR):
         os.mkdir(OUTPUT_DIR)
     origine_img, files, isRGB = load_images(DATA_DIR)
-    if rank0:
-        with open(os.path.join(OUTPUT_DIR, 'filename.txt'), 'w', encoding='UTF-8') as f:
-            f.write(f"{int(isRGB)}\n")
-            for file_name in files:
-                f.write("%s\n" % file_name)
     nt, H, W = origine_img.shape[:3]
     cfg, wts, model_shape = open_model(WEIGHTS_DIR)
     hp, wp = padding_shape(H, W)
@@ -332,6 +353,14 @@ def _run_sharded(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THR
     if nt < PREPROCESS + 2:
         print("ERROR: need at least warm_up+2 images (%d given, warm_up %d)." % (nt, PREPROCESS))
         exit()
+    if SHUFFLE and (nt * H * W * 3) % 8:
+        print("ERROR: --shuffle needs nt*H*W*3 to be a multiple of 8 (%d x %d x %d x 3 is not)." % (nt, H, W))
+        exit()
+    if rank0:
+        with open(os.path.join(OUTPUT_DIR, 'filename.txt'), 'w', encoding='UTF-8') as f:
+            f.write(f"{int(isRGB)}\n")
+            for file_name in files:
+                f.write("%s\n" % file_name)
     job = tzdist.active()
     if WINDOW_SIZE is None:
         if job[0] == 0:

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 
 #include <algorithm>
+#include <chrono>
 #include <thread>
 
 #include "tz_internal.h"
@@ -70,6 +71,16 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
         tz_ctx_destroy(ctx);
         return TZ_ERR_HIP;
     }
+    {
+        const char* e = getenv("TEZIP_SPLIT");
+        if (e) ctx->split_rollout = atoi(e);
+        if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+            tz_ctx_destroy(ctx);
+            return TZ_ERR_HIP;
+        }
+    }
     ctx->ring_size = 1 << 20;
     if (hipHostMalloc((void**)&ctx->ring, ctx->ring_size, hipHostMallocDefault) != hipSuccess) {
         ctx->ring = nullptr;
@@ -106,6 +117,12 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
     }
     for (auto e : ctx->chunk_ev) (void)hipEventDestroy(e);
+    if (ctx->stream2) {
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamDestroy(ctx->stream2);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_keys) (void)hipEventDestroy(ctx->ev_keys);
     if (ctx->ev_frames) (void)hipEventDestroy(ctx->ev_frames);
     if (ctx->ev_compute) (void)hipEventDestroy(ctx->ev_compute);
@@ -159,10 +176,17 @@ extern "C" int tz_host_free(void* p) {
 static int stage_acquire(tz_ctx* ctx, int* idx) {
     const int i = ctx->stage_next;
     ctx->stage_next = (i + 1) % tz_ctx::kStages;
-    if (!ctx->stage[i]) {
-        hipError_t e = hipHostMalloc((void**)&ctx->stage[i], tz_ctx::kStageBytes, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming);
-        if (e != hipSuccess) return tz_fail(ctx, TZ_ERR_NOMEM, "pinned staging buffer: %s", hipGetErrorString(e));
+    if (!ctx->stage[i] || !ctx->stage_ev[i]) {
+        hipError_t e = hipSuccess;
+        if (!ctx->stage[i]) e = hipHostMalloc((void**)&ctx->stage[i], tz_ctx::kStageBytes, hipHostMallocDefault);
+        if (e == hipSuccess && !ctx->stage_ev[i]) e = hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) {   // a buffer without its event is no use: the next call starts over
+            if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
+            ctx->stage[i] = nullptr;
+            ctx->stage_ev[i] = nullptr;
+            (void)hipGetLastError();
+            return tz_fail(ctx, TZ_ERR_NOMEM, "pinned staging buffer: %s", hipGetErrorString(e));
+        }
     }
     if (ctx->stage_busy[i]) {
         TZ_HIP(ctx, hipEventSynchronize(ctx->stage_ev[i]));
@@ -360,7 +384,7 @@ tz_prof_scope::~tz_prof_scope() {
 static const char* kProfNames[TZP_COUNT] = {"conv3x3_mfma", "err0", "delta", "quant", "spatial_delta_hist",
                                             "lut_remap", "undelta_scan", "reconstruct", "sse",
                                             "conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general",
-                                            "convlat_small_grid"};
+                                            "convlat_small_grid", "table_create"};
 
 extern "C" int tz_prof_enable(tz_ctx* ctx, int on) {
     if (!ctx) return TZ_ERR_INVALID;
@@ -623,29 +647,84 @@ static int run_schedule(tz_ctx* ctx, std::vector<PredItem>& items) {
     TZ_TRY(tz_model_dims(ctx, &Hp, &Wp, &maxB));
     if (items.empty()) return TZ_OK;
     std::stable_sort(items.begin(), items.end(), [](const PredItem& a, const PredItem& b) { return a.depth < b.depth; });
-    std::vector<int> table;   // per batch: [is_key | in | out], maxB ints each
-    std::vector<int> counts;
-    size_t i = 0;
-    while (i < items.size()) {
-        size_t j = i;
-        while (j < items.size() && items[j].depth == items[i].depth && (int)(j - i) < maxB) ++j;
-        size_t base = table.size();
-        table.resize(base + 3 * (size_t)maxB, 0);
-        for (size_t k = i; k < j; ++k) {
-            table[base + (k - i)] = items[k].from_key;
-            table[base + maxB + (k - i)] = items[k].in;
-            table[base + 2 * maxB + (k - i)] = items[k].out;
+    // A window is a chain of items (each reads what the one before it wrote); chains never touch each other.
+    // TEZIP_SPLIT=1 deals them to two GROUPS that advance on two streams with their own activation slots: the
+    // launches of a predictor step depend on each other, so on one stream every launch ramps up and drains alone
+    // (0.895 of the MFMA peak at 4 windows against 0.917 at 32), and with two independent launch
+    // chains one group's launch could fill the CUs the other's draining launch leaves idle.  Measured in round 3
+    // (bit-identical, all GPU tests green with it on): 62.5 -> 65.4 ms per cfg3 step -- two half-sized launches
+    // lose more to their own ramps than the overlap returns -- so it is OFF by default and kept as a switch.
+    // Per-launch event timing needs launches that run alone: profiling keeps one stream in any case.
+    const bool split = ctx->split_rollout && ctx->stream2 && maxB >= 2 && !ctx->prof_on;
+    const int capA = split ? (maxB + 1) / 2 : maxB, capB = maxB - capA;
+    std::vector<int> group(items.size(), 0);
+    if (split) {
+        std::vector<int> chain_of(ctx->nt, -1);   // frame slot -> group of the chain that wrote it
+        int nchains = 0;
+        for (size_t i = 0; i < items.size(); ++i) {
+            int g;
+            if (items[i].from_key || chain_of[items[i].in] < 0) g = (nchains++) & 1;
+            else g = chain_of[items[i].in];
+            group[i] = g;
+            chain_of[items[i].out] = g;
         }
-        counts.push_back((int)(j - i));
-        i = j;
+    }
+    // per group: batches of one depth, [is_key | in | out] x maxB ints each
+    std::vector<int> table;
+    std::vector<int> counts[2];
+    std::vector<size_t> offs[2];
+    for (int g = 0; g < (split ? 2 : 1); ++g) {
+        const int cap = g == 0 ? capA : capB;
+        size_t i = 0;
+        while (i < items.size()) {
+            const int depth = items[i].depth;
+            size_t j = i;
+            while (j < items.size() && items[j].depth == depth) ++j;
+            std::vector<size_t> mine;
+            for (size_t k = i; k < j; ++k)
+                if (group[k] == g) mine.push_back(k);
+            for (size_t q = 0; q < mine.size(); q += cap) {
+                const size_t nb = std::min<size_t>(cap, mine.size() - q), base = table.size();
+                table.resize(base + 3 * (size_t)maxB, 0);
+                for (size_t k = 0; k < nb; ++k) {
+                    const PredItem& it = items[mine[q + k]];
+                    table[base + k] = it.from_key;
+                    table[base + maxB + k] = it.in;
+                    table[base + 2 * maxB + k] = it.out;
+                }
+                counts[g].push_back((int)nb);
+                offs[g].push_back(base);
+            }
+            i = j;
+        }
     }
     TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_sched, &ctx->cap_sched, table.size() * sizeof(int)));
     TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // an earlier rollout may still read the old table
     TZ_HIP(ctx, hipMemcpy(ctx->d_sched, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
-    for (size_t b = 0; b < counts.size(); ++b)
-        TZ_TRY(tz_model_predict_batch_dev(ctx, counts[b], ctx->d_sched + b * 3 * (size_t)maxB, maxB, ctx->d_frames, ctx->H,
-                                          ctx->W, ctx->d_pred, ctx->d_pred));
-    return TZ_OK;
+    if (split && !counts[1].empty()) {
+        TZ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));          // everything queued so far (frames, C0 slots)
+        TZ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    }
+    hipStream_t main_stream = ctx->stream;
+    int rc = TZ_OK;
+    const size_t steps = std::max(counts[0].size(), counts[1].size());
+    for (size_t b = 0; b < steps && rc == TZ_OK; ++b) {
+        if (b < counts[0].size())
+            rc = tz_model_predict_batch_dev(ctx, counts[0][b], ctx->d_sched + offs[0][b], maxB, ctx->d_frames, ctx->H, ctx->W,
+                                            ctx->d_pred, ctx->d_pred, 0);
+        if (rc == TZ_OK && b < counts[1].size()) {
+            ctx->stream = ctx->stream2;   // the launchers take the context's stream
+            rc = tz_model_predict_batch_dev(ctx, counts[1][b], ctx->d_sched + offs[1][b], maxB, ctx->d_frames, ctx->H, ctx->W,
+                                            ctx->d_pred, ctx->d_pred, capA);
+            ctx->stream = main_stream;
+        }
+    }
+    if (split && !counts[1].empty()) {
+        hipError_t e = hipEventRecord(ctx->ev_join, ctx->stream2);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+        if (e != hipSuccess && rc == TZ_OK) rc = tz_fail(ctx, TZ_ERR_HIP, "rollout join: %s", hipGetErrorString(e));
+    }
+    return rc;
 }
 
 // ---- streaming ingestion / delivery: the frame stack enters window by window and the payload
@@ -1109,8 +1188,13 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "hist download: %s", hipGetErrorString(e));
         std::vector<int16_t> lut;
+        const auto t0 = std::chrono::steady_clock::now();
         if (rc == TZ_OK) rc = tz_build_table(hist.data(), TZ_NBINS, table, table_len);  // 356-361
         if (rc == TZ_OK) rc = build_enc_lut(ctx, table, *table_len, &lut);
+        if (ctx->prof_on) {
+            ctx->prof[TZP_TABLE].total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            ctx->prof[TZP_TABLE].launches += 1;
+        }
         if (rc == TZ_OK) rc = remap_out(ctx, (const int16_t*)d_sd, N, lut.data(), &o_pay);  // 369
     }
     if (rc == TZ_OK && shuffle) {
@@ -1281,13 +1365,13 @@ extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, size_t payload_len
         payload = ctx->d_payload;
     }
     ctx->have_decoded = false;
-    if (!frames_out) {  // keep the frames in the context: tz_decoded_get
-        TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_out, &ctx->cap_out, N));
-        frames_out = ctx->d_out;
-        ctx->have_decoded = true;
-    }
     if (payload_len != N)  // decompress.py:240: the reshape raises
         return tz_fail(ctx, TZ_ERR_INVALID, "payload holds %zu elements, the key-frame stack implies %zu", payload_len, N);
+    const bool resident = frames_out == nullptr;
+    if (resident) {  // keep the frames in the context: tz_decoded_get
+        TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_out, &ctx->cap_out, N));
+        frames_out = ctx->d_out;
+    }
     std::vector<tz_out> outs;
     tz_out o;
     const void* d_pay = nullptr;
@@ -1309,6 +1393,7 @@ extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, size_t payload_len
         rc = tzk_reconstruct(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, (const int16_t*)d_diff, nt, H, W,
                              ctx->Hp, ctx->Wp, (uint8_t*)o.dev);
     if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    if (rc == TZ_OK && resident) ctx->have_decoded = true;   // only a decode whose work is queued leaves frames to fetch
     tz_pool_release_all(ctx);
     return rc;
 }

@@ -28,6 +28,7 @@ enum tz_prof_class {
     TZP_CONV_SMALL, // k_conv_small: direct VALU 3 -> 3 convolution
     TZP_CONV_GEN,   // k_conv3x3: general kernel
     TZP_CONVLAT,    // k_convlat: one accumulator tile per wave, for grids that cannot fill the chip
+    TZP_TABLE,      // HOST time: rank table + LUT from the downloaded histogram (compress.py:356-361)
     TZP_COUNT
 };
 
@@ -74,6 +75,11 @@ struct tz_ctx {
     // memory (tz_host_alloc) is DMA'd directly; pageable memory is pipelined through `stage`.
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_keys = nullptr, ev_frames = nullptr, ev_compute = nullptr;
+    // second compute stream of a static rollout schedule (run_schedule): the windows advance as two independent
+    // groups, so that one group's launch fills the CUs the other group's draining launch leaves idle
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int split_rollout = 0;            // TEZIP_SPLIT=1 turns it on (measured in round 3: slower, see run_schedule)
     static constexpr int kStages = 4;
     static constexpr size_t kStageBytes = (size_t)8 << 20;
     uint8_t* stage[kStages] = {nullptr, nullptr, nullptr, nullptr};
@@ -182,7 +188,9 @@ int tzk_sse_launch(tz_ctx*, const uint8_t* orig, const float* pred, int nframes,
 void tz_model_free(tz_ctx* ctx);
 int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int* h_in_idx, const int* h_out_idx,
                            const uint8_t* d_frames_u8, int H, int W, const float* d_in_stack, float* d_out_stack);
+// slot0: first activation slot of the batch (a rollout that advances two groups of windows on two streams
+// gives each group its own range of the max_batch slots)
 int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride, const uint8_t* d_frames_u8, int H, int W,
-                               const float* d_in_stack, float* d_out_stack);
+                               const float* d_in_stack, float* d_out_stack, int slot0 = 0);
 int tz_model_c0_dev(tz_ctx* ctx, const float** c0);
 int tz_model_dims(tz_ctx* ctx, int* Hp, int* Wp, int* max_batch);

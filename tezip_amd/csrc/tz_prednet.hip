@@ -265,6 +265,10 @@ static void launch_conv16_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
 
 extern "C" int tz_set_conv_impl(tz_ctx* ctx, int lds_dma) {
     if (!ctx) return TZ_ERR_INVALID;
+    // a bit field since round 2: reject what is neither 0/1 nor a documented k_convlat selector, so that an old
+    // caller's "any non-zero value = on" does not silently pick something else
+    if (lds_dma < 0 || lds_dma > 5 || (lds_dma >> 1) > 2)
+        return tz_fail(ctx, TZ_ERR_INVALID, "tz_set_conv_impl: %d is not 0 / 1 (+ 2 = never k_convlat, + 4 = k_convlat wherever eligible)", lds_dma);
     ctx->conv_impl = (lds_dma & 1) ? 1 : 0;
     const int lat = lds_dma >> 1;  // 0: cost model (default), 1: never k_convlat, 2: wherever eligible
     ctx->lat_mode = lat == 1 ? 0 : (lat == 2 ? 2 : 1);
@@ -626,16 +630,16 @@ int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int
         idx[2 * m->maxB + i] = h_out_idx[i];
     }
     TZ_TRY(tz_upload(ctx, m->d_idx, idx.data(), sizeof(int) * idx.size()));
-    return tz_model_predict_batch_dev(ctx, n, m->d_idx, m->maxB, d_frames_u8, H, W, d_in_stack, d_out_stack);
+    return tz_model_predict_batch_dev(ctx, n, m->d_idx, m->maxB, d_frames_u8, H, W, d_in_stack, d_out_stack, 0);
 }
 
 // Launch-only form: d_idx holds [is_key | in_idx | out_idx], each `stride` ints apart, already
 // on the device.  Nothing here allocates or copies.
 int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride, const uint8_t* d_frames_u8, int H, int W,
-                               const float* d_in_stack, float* d_out_stack) {
+                               const float* d_in_stack, float* d_out_stack, int slot0) {
     tz_model* m = ctx->model;
     if (!m || !m->prepared) return tz_fail(ctx, TZ_ERR_STATE, "model not prepared");
-    if (n < 1 || n > m->maxB) return tz_fail(ctx, TZ_ERR_INVALID, "batch %d outside 1..%d", n, m->maxB);
+    if (n < 1 || slot0 < 0 || slot0 + n > m->maxB) return tz_fail(ctx, TZ_ERR_INVALID, "batch %d at slot %d outside 1..%d", n, slot0, m->maxB);
     const int L = m->L, Hp = m->Hp, Wp = m->Wp;
     auto hl = [&](int l) { return Hp >> l; };
     auto wl = [&](int l) { return Wp >> l; };
@@ -644,7 +648,7 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         tz_prof_scope ps(ctx, TZP_ERR0);
         int gx = (int)std::min<long long>((npx(0) + 255) / 256, 2048);
         hipLaunchKernelGGL(k_err0, dim3(gx, n), dim3(256), 0, ctx->stream, d_frames_u8, H, W, d_in_stack, d_idx,
-                           d_idx + stride, m->Ahat0[0], Hp, Wp, m->stack[0], m->e0s, m->E[0]);
+                           d_idx + stride, m->Ahat0[0], Hp, Wp, m->stack[0], m->e0s, m->E[0] + (long long)slot0 * npx(0) * m->e0s);
         TZ_HIP(ctx, hipGetLastError());
     }
     // Small grids (64x64-class frames): the launches of a step are latency chains on a mostly idle chip,
@@ -655,9 +659,9 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
     auto gate_args = [&](int l, ConvArgs& a) {
         const PackedConv& pc = m->gate_t1[l];
         memset(&a, 0, sizeof(a));
-        const float* ptrs[2] = {m->E[l], l < L - 1 ? m->R1[l + 1] : nullptr};
         const int ec = l == 0 ? m->e0s : 2 * m->stack[l];
         long long ns[2] = {npx(l) * ec, l < L - 1 ? npx(l + 1) * m->rstack[l + 1] : 0};
+        const float* ptrs[2] = {m->E[l] + slot0 * ns[0], l < L - 1 ? m->R1[l + 1] + slot0 * ns[1] : nullptr};
         fill_srcs(a, pc, ptrs, ns, ec);
         set_geom(a, hl(l), wl(l));
         a.init = m->G0[l];
@@ -666,21 +670,21 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         a.R = m->rstack[l];
         a.aux = m->C0[l];
         a.auxf = m->C0f[l];
-        a.out0 = m->R1[l];
         a.out0_nstride = npx(l) * m->rstack[l];
+        a.out0 = m->R1[l] + slot0 * a.out0_nstride;
     };
     auto aconv_args = [&](int l, ConvArgs& a) {
         const PackedConv& pc = m->a_conv[l];
         memset(&a, 0, sizeof(a));
-        const float* ptrs[2] = {m->E[l], nullptr};
         const int ec = l == 0 ? m->e0s : 2 * m->stack[l];  // floats per pixel of E[l]
         long long ns[2] = {npx(l) * ec, 0};
+        const float* ptrs[2] = {m->E[l] + slot0 * ns[0], nullptr};
         fill_srcs(a, pc, ptrs, ns, ec);
         set_geom(a, hl(l), wl(l));
         a.Cout = m->stack[l + 1];
         a.aux = m->Ahat0[l + 1];
-        a.out0 = m->E[l + 1];
         a.out0_nstride = npx(l + 1) * 2 * m->stack[l + 1];
+        a.out0 = m->E[l + 1] + slot0 * a.out0_nstride;
     };
     bool split[TZ_MAX_LEVELS] = {false};
     for (int l = 0; l < L - 1; ++l) {  // t0 bottom-up
@@ -692,8 +696,8 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
             gate_args(l, ge);
             ge.nsrc = 1;                      // the chain over E_l only
             ge.initf = nullptr;
-            ge.out0 = m->P[l];
             ge.out0_nstride = npx(l) * ge.ncols;
+            ge.out0 = m->P[l] + slot0 * ge.out0_nstride;
             ConvArgs gu;
             gate_args(l, gu);
             gu.src[0] = gu.src[1];
@@ -722,8 +726,8 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
             a.slot0 = a.src[0].cpt * 9;
             a.src[0] = a.src[1];
             a.nsrc = 1;
-            a.init = m->P[l];
             a.init_nstride = npx(l) * a.ncols;
+            a.init = m->P[l] + slot0 * a.init_nstride;
             a.initf = nullptr;
             const LatPlan pu = lat_plan(ctx, 4, EPI_LSTM, true, a.src[0].C % 16 == 0, a, n);
             tz_prof_scope ps(ctx, TZP_CONV);
@@ -739,8 +743,8 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         const PackedConv& pc = m->ahat0_t1;
         ConvArgs a;
         memset(&a, 0, sizeof(a));
-        const float* ptrs[2] = {m->R1[0], nullptr};
         long long ns[2] = {npx(0) * m->rstack[0], 0};
+        const float* ptrs[2] = {m->R1[0] + slot0 * ns[0], nullptr};
         fill_srcs(a, pc, ptrs, ns);
         set_geom(a, Hp, Wp);
         a.Cout = m->stack[0];

@@ -68,4 +68,4 @@ class PredNetConfig:
         return {"class_name": "PredNet", "config": {
             "stack_sizes": list(self.stack_sizes), "R_stack_sizes": list(self.R_stack_sizes),
             "A_filt_sizes": list(self.A_filt_sizes), "Ahat_filt_sizes": list(self.Ahat_filt_sizes),
-            "R_filt_sizes": list(self.R_filt_sizes), "pixel_max": 1.0, "data_format": "channels_last"}}
+            "R_filt_sizes": list(self.R_filt_sizes), "pixel_max": float(self.pixel_max), "data_format": "channels_last"}}

@@ -78,8 +78,17 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOWS, MODE, BOUND_VALU
     from .data_utils import padding_shape
     frames, files, is_rgb = load_images(DATA_DIR)
     nt, H, W = frames.shape[:3]
-    cfg, wts, _ = open_model(WEIGHTS_DIR)
+    cfg, wts, model_shape = open_model(WEIGHTS_DIR)
     hp, wp = padding_shape(H, W)
+    # the same checks as compress.run (compress.py:178-181 and the nt >= warm_up + 2 guard)
+    if model_shape is not None and (model_shape[0] != hp or model_shape[1] != wp):
+        print("ERROR:Image size is out of scope for this model.")
+        print("Compatible sizes for this model are height", model_shape[0] - 7, "to", model_shape[0], "and width",
+              model_shape[1] - 7, "to", model_shape[1])
+        exit()
+    if nt < PREPROCESS + 2:
+        print("ERROR: need at least warm_up+2 images (%d given, warm_up %d)." % (nt, PREPROCESS))
+        exit()
     job = tzdist.active()
     if job:
         device = tzdist.init_from_env()

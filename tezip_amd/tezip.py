@@ -85,10 +85,11 @@ def check_compress(arg):
     of the message to print; prints the mode name where the reference does."""
     if arg.preprocess is None:
         return "no_p"
-    have_w, have_t = arg.window is not None or getattr(arg, "sweep", None) is not None, arg.threshold is not None
+    have_sweep = getattr(arg, "sweep", None) is not None
+    have_w, have_t = arg.window is not None or have_sweep, arg.threshold is not None
     if not have_w and not have_t:
         return "no_window"
-    if have_w and have_t:
+    if (have_w and have_t) or (have_sweep and arg.window is not None):  # --sweep takes the place of -w / -t: not beside them
         return "two_windows"
     if arg.mode is None:  # the reference raises a TypeError here; report it as a bad mode instead
         return "bad_mode"

@@ -8,9 +8,12 @@ means, Adam (lr 1e-3, 1e-4 from epoch 75; Keras defaults beta 0.9/0.999, eps 1e-
 consecutive frames of one source, start drawn from all valid starts (data_utils.py:29-30).
 The forward pass here is ordinary torch conv2d (any device torch has); it is the same function
 as the inference path's TZ-PA1 arithmetic up to float32 summation order, which training does
-not need bit for bit.  Data: X_train.hkl etc. (hickle layout, tezip_amd/hkl.py) or .npy stacks.  Output: prednet_model.json + prednet_weights.hdf5 in WEIGHTS_DIR (the
-reference's own two files, Keras layout: tezip_amd/weights.py), readable by compress.run /
-decompress.run here and by the reference's compress.py:143-173.  Data: X_train.npy etc. from tezip_amd.train_data_create.
+not need bit for bit.
+Data: X_train.hkl / sources_train.hkl / X_val.hkl / sources_val.hkl (hickle 4.0.1 layout as restated in
+tezip_amd/hkl.py, written by tezip_amd.train_data_create) or the same four names as .npy stacks.
+Output: prednet_model.json + prednet_weights.hdf5 in WEIGHTS_DIR -- the reference's two files in Keras' layout
+(tezip_amd/weights.py), read by compress.run / decompress.run here.  Whether the reference's Keras 2.2.4 reads
+them is parity unpinned (no Keras / h5py in this image, no fixture in the reference): see weights.py.
 """
 import os
 

@@ -13,8 +13,12 @@ PredNet layer from them (compress.py:143-173).  Here:
   * `save_model` writes the same two files the reference's trainer leaves behind: a
     `model.to_json()`-shaped prednet_model.json (every layer of train.py:62-71 with the config keys
     Keras 2.2.4 emits, so that `model_from_json` can rebuild it) and a Keras-layout full-model
-    prednet_weights.hdf5 (tezip_amd/h5lite.py writer): a model trained or converted here can be
-    consumed by /root/reference/src/compress.py:143-173.
+    prednet_weights.hdf5 (tezip_amd/h5lite.py writer), laid out for /root/reference/src/compress.py:143-173
+    to consume.  **Parity unpinned**: neither Keras 2.2.4 nor h5py can be imported in the image this was
+    built in and the reference holds no .hdf5 / .json fixture, so both layouts are restated from knowledge
+    of that Keras version; what IS checked is that libhdf5 opens the files (tests/golden/check_h5_with_h5py.py,
+    run by hand where h5py exists) and that this package reads back what it writes.  The .npz form stays
+    as the documented fallback.
 """
 import json
 import os
@@ -90,7 +94,7 @@ def make_model_json(cfg, hp, wp, nt=2):
                 "go_backwards": False, "stateful": False, "unroll": False, "implementation": 0,
                 "stack_sizes": list(cfg.stack_sizes), "R_stack_sizes": list(cfg.R_stack_sizes),
                 "A_filt_sizes": list(cfg.A_filt_sizes), "Ahat_filt_sizes": list(cfg.Ahat_filt_sizes),
-                "R_filt_sizes": list(cfg.R_filt_sizes), "pixel_max": 1.0,
+                "R_filt_sizes": list(cfg.R_filt_sizes), "pixel_max": float(cfg.pixel_max),
                 "error_activation": "relu", "A_activation": "relu", "LSTM_activation": "tanh",
                 "LSTM_inner_activation": "hard_sigmoid", "data_format": "channels_last",
                 "extrap_start_time": None, "output_mode": "error"}
@@ -124,8 +128,8 @@ def save_model(model_dir, cfg, weights, hp, wp):
         f.write(text)
     h5lite.save_prednet_checkpoint(os.path.join(model_dir, H5_NAME), cfg, weights, nt=2, model_config=text)
     stale = os.path.join(model_dir, NPZ_NAME)
-    if os.path.exists(stale):  # a converted copy of OLDER weights would shadow nothing now, but is misleading
-        os.remove(stale)
+    if os.path.exists(stale):  # a converted copy of OLDER weights: load_model prefers the hdf5, so it is only misleading
+        os.replace(stale, stale + ".superseded")   # ... but it is the user's file: renamed, not deleted
 
 
 def _load_h5(path, cfg):
