@@ -1,0 +1,65 @@
+"""Build-time guard for the hand-scheduled kernels.
+
+k_conv16 / k_conv16b / k_convlat stage their operands with inline-asm LDS-DMA (`global_load_lds_dwordx4`) and
+wait for them with hand-counted `s_waitcnt vmcnt(N)` immediates; the asm overwrites m0 / exec around each
+DMA without declaring it.  Those counts are only right while the compiler issues NO vector-memory operation of
+its own between a DMA and its wait -- a scratch spill (or a new compiler that schedules differently) would turn
+the waits into a silent LDS race: wrong bits in rare tiles, encoder and decoder diverging.  The bit-exact GPU
+tests (test_gpu_fullsize.py: every LDS-DMA kernel against the register-staged general kernel at full size,
+test_small_grid_kernel_agrees_with_k_conv16, test_soak_lds_dma_kernels) catch that on hardware; this test
+catches its usual cause on the CPU, from the code object hipcc just built: none of these kernels may use
+scratch memory or spill a register, and the compiler must be the one the counts were validated with."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+OBJ = os.path.join(ROOT, "tezip_amd", "csrc", "tz_prednet.o")
+KNOWN_GOOD_COMPILERS = ("roc-7.2.0",)   # hipcc --version of the toolchains the vmcnt immediates were validated with
+
+
+def _kernel_metadata(tmp_path):
+    if not os.path.exists(OBJ):
+        from tezip_amd import build
+        build.build()
+    work = tmp_path / "co"
+    work.mkdir()
+    shutil.copy(OBJ, work / "k.o")   # llvm-objdump --offloading writes the bundles next to its input
+    subprocess.check_call([os.path.join(LLVM, "llvm-objdump"), "--offloading", "k.o"], cwd=work, stdout=subprocess.DEVNULL)
+    co = [f for f in os.listdir(work) if "amdgcn" in f]
+    assert len(co) == 1, co
+    notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co[0]], cwd=work, text=True)
+    kernels, cur = {}, None
+    for line in notes.splitlines():
+        m = re.match(r"\s+\.(\w+):\s+(\S+)", line)
+        if not m:
+            continue
+        key, val = m.groups()
+        if key == "name" and val.startswith("_Z"):
+            cur = kernels.setdefault(val, {})
+        elif cur is not None and key in ("private_segment_fixed_size", "sgpr_spill_count", "vgpr_spill_count", "vgpr_count"):
+            cur[key] = int(val)
+    return kernels
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="no ROCm LLVM tools")
+def test_hand_scheduled_kernels_use_no_scratch_and_spill_nothing(tmp_path):
+    kernels = _kernel_metadata(tmp_path)
+    guarded = {n: k for n, k in kernels.items() if re.search(r"k_convlat|k_conv16", n)}
+    assert len(guarded) >= 12, sorted(kernels)   # k_conv16 / k_conv16b / k_convlat / k_convlat_pair instantiations
+    for name, k in guarded.items():
+        assert k.get("private_segment_fixed_size") == 0, (name, k)   # scratch = compiler-issued VMEM between DMA and wait
+        assert k.get("sgpr_spill_count") == 0 and k.get("vgpr_spill_count") == 0, (name, k)
+        assert k.get("vgpr_count", 999) <= 128, (name, k)            # the launch bounds these kernels were tuned for
+
+
+def test_compiler_is_the_one_the_waitcnt_immediates_were_validated_with():
+    out = subprocess.check_output([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--version"], text=True)
+    assert any(tag in out for tag in KNOWN_GOOD_COMPILERS), (
+        "hipcc changed:\n%s\nre-run the bit-exact GPU tests (pytest -m gpu tests/test_gpu_fullsize.py) and scripts/soak_conv.py "
+        "with this compiler, then add its tag to KNOWN_GOOD_COMPILERS" % out)

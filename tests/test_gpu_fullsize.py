@@ -240,6 +240,19 @@ def test_small_grid_kernel_agrees_with_k_conv16(ctx, h, w, batch, nt, seed):
     assert preds["never"].std() > 0
 
 
+def test_soak_lds_dma_kernels_forced_small_grid_kernel_included():
+    """scripts/soak_conv.py once per GPU-suite run: 114 rollouts over eleven frame sizes and batch
+    sizes, each through the LDS-DMA kernels, the general kernel and k_convlat forced wherever it is eligible
+    (lat='always': register weight ring, asm LDS-DMA with hand-counted vmcnt waits) -- all bit-identical.  A DMA /
+    wait-count race shows up as rare differing tiles; see tests/test_build_guard.py for the static half."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_conv.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatching" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_the_hot_launches_run_on_the_kernels_the_design_names(ctx):
     """Dispatch guard: at 512x512 with four windows every convolution of levels >= 1 is k_conv16 (95 launches
     per 19-step rollout), the level-0 ones k_conv16b / k_conv_small, and nothing falls back to the general

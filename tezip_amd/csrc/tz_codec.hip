@@ -191,8 +191,8 @@ __device__ __forceinline__ void sdelta8(const uint4 V, unsigned prev16, bool app
 // compress.py:23-70, one chain per (frame, channel) over H*W elements, row-major.
 // Stage 1 (k_q_minmax, k_q_bound): per-chain tolerance E for rel / absrel from max-min of the
 //                      ORIGINAL slab (compress.py:31-33,36-43).
-// Stage 2 (k_q_heads, k_q_stitch): exact wave-parallel form of the greedy interval-intersection
-//                      segmentation (see the kernels).  Result: one bit per element (`spec`, a 64-bit
+// Stage 2 (k_q_width, k_q_tiles, k_q_chain, k_q_bstitch, k_q_serial): exact parallel form of the greedy
+//                      interval-intersection segmentation (see the kernels).  Result: one bit per element (`spec`, a 64-bit
 //                      mask per 64-element chunk and chain) that says where a run starts, and the
 //                      truncated median of every run at its HEAD position of `tmp` (positions that are
 //                      not heads hold garbage: the masks are authoritative, nothing initialises tmp).
@@ -203,8 +203,10 @@ __device__ __forceinline__ void sdelta8(const uint4 V, unsigned prev16, bool app
 //                      exist in memory.
 // The deltas a chain is made of come from a materialised int16 stack or, fused encode, straight from
 // prediction and original (compress.py:292-314 evaluated where it is needed): QSrc.
-// Round 3 traffic at cfg3, `abs 2`: heads 315 MB + fill 270 MB + remap 252 MB against 1.75 GB through
-// k_delta, k_q_init, k_q_last over tmp, k_q_fill, k_sdelta in round 2.
+// Round 3 at cfg3, `abs 2` (profiles/r03/quantiser.md): the tiles read pred / orig (315 MB) and write the values
+// (126 MB), the fill reads them and the masks and writes symbols (270 MB), the remap 252 MB: about 1.0 GB and
+// 0.5 ms against 1.75 GB and 1.1 ms through k_delta, k_q_init, k_q_heads, k_q_last over tmp, k_q_fill, k_sdelta
+// in round 2.
 struct QParams {
     int mode;
     double b0, b1;
@@ -288,47 +290,39 @@ __global__ void k_q_bound(const int* __restrict__ mm, const uint8_t* __restrict_
     E[i] = e;
 }
 
-// Wave-parallel exact greedy segmentation.  The chain of a (frame, channel) is walked in chunks of
-// 64 elements (lane i <-> element).  A run started at s breaks at the first i with
-// min(Du[s..i]) < max(Dl[s..i]) (compress.py:60 -- a-b<0 <=> a<b in IEEE), which is monotone in i, so
-// per chunk:
-//   WORKER waves (carry independent, one chunk each per round; q_chunk):
+// Two forms of the exact greedy segmentation live here.
+//
+// (1) WAVE-parallel, one 64-element chunk at a time (lane i <-> element; q_chunk).  A run started at s breaks
+// at the first i with min(Du[s..i]) < max(Dl[s..i]) (compress.py:60 -- a-b<0 <=> a<b in IEEE), monotone in i, so
+// a wave computes per chunk
 //   1. range tables T_k[i] = (min Du, max Dl) over [i, i+2^k) by shuffles (k = 0..5),
-//   2. nxt[s] = first break after s for EVERY s (fresh start) by binary lifting over T_k,
-//      together with the run's (u, l) up to the break,
-//   3. inclusive prefix (min Du, max Dl) from the chunk start,
-//   2b. heads[s] = bit mask of the run heads reached from a start at s (pointer doubling).
-//   RESOLVER wave (sequential over chunks, one round behind the workers):
-//   4. the run carried in from earlier chunks breaks at the first i with
-//      min(u, P_u[i]) < max(l, P_l[i])  (ballot); the true heads are the nxt-chain from that
-//      break, which the workers have already expanded into a bit mask per start: one lookup,
-//   5. every head whose run closes inside the chunk stores trunc((u+l)/2) (compress.py:61,
-//      truncation by the int64 store) at the head position of `tmp`; the last head carries on.
-// The walk of the resolver is the serial critical path (about 0.3 us per chunk, 4096 chunks per
-// 512x512 chain), so the chain is cut into QSEG SEGMENTS that are walked concurrently, each from a
-// fresh start at its first element (round 2; one workgroup of 1 + QW waves per segment, eight of them
-// share a CU).  A fresh start is a guess -- the true run entering a segment began earlier -- and
-// k_q_stitch repairs it exactly: two greedy chains over the same data never cross and coincide from
-// their first common head on, so the true chain is followed from the segment start only until it
-// hits a head of the speculative chain (typically within the first chunk); the speculative heads
-// before that point are dropped from the masks, the true ones entered, everything behind it is already
-// right.  Nothing depends on run lengths; elements past the chain end are (+inf, -inf) and can neither
-// break nor tighten a run.
+//   2. nxt[s] = first break after s for EVERY s (fresh start) by binary lifting over T_k, together with the
+//      run's (u, l) up to the break,
+//   3. the inclusive prefix (min Du, max Dl) from the chunk start,
+//   2b. heads[s] = bit mask of the run heads reached from a start at s (pointer doubling),
+// and a run carried in from earlier chunks is then resolved without knowing in advance where it breaks:
+//   4. it breaks at the first i with min(u, P_u[i]) < max(l, P_l[i]) (ballot); the true heads of the chunk are
+//      heads[that i],
+//   5. every head whose run closes inside the chunk gets trunc((u+l)/2) (compress.py:61, truncation by the
+//      int64 store) at its position of `tmp`; the last head carries on.
+// That is about 250 vector instructions and 35 cross-lane shuffles per chunk.  Rounds 1-2 ran the whole chain
+// through it (k_q_heads: worker waves + a resolver wave per segment of a chain, 1.29 -> 0.63 ms per cfg3 step;
+// profiles/r02/quantiser.md).  Now it serves where a run of UNKNOWN origin has to be taken into a chunk: at the
+// tile boundaries (k_q_bstitch) and in the serial fallback (k_q_serial).
+//
+// (2) LANE-parallel walks from speculative fresh starts (k_q_tiles, below): a dozen integer instructions per
+// element instead, because a walk that starts fresh never has to ask where somebody else's run breaks.  What
+// makes the guesses exact: two greedy chains over the same data never cross, and they coincide from their first
+// common head on; so the chain that really enters a region is followed only until it hits a head of the region's
+// speculative chain -- speculative heads in front of that point leave the masks, true ones enter, behind it
+// everything is already right.  Nothing depends on run lengths; elements past the chain end are (+inf, -inf)
+// and can neither break nor tighten a run.
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
-
-static constexpr int QW = 3;     // worker waves per segment (+1 resolver wave = 256 threads)
-static constexpr int QSEG = 8;   // segments per chain
 
 struct QChunk {
     double cu, cl, pu, pl;
     unsigned long long heads;
     int nxt;
-};
-
-struct QSlot {
-    double cu[64], cl[64], pu[64], pl[64];
-    unsigned long long heads[64];  // heads[s]: bit mask of the nxt-chain that starts at s
-    int nxt[64];
 };
 
 struct QState {  // the run that is open at a segment boundary
@@ -476,181 +470,617 @@ __device__ __forceinline__ unsigned long long q_rl_u64(unsigned long long v, int
            (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
 }
 
-// Speculative walk of segment `seg` of every chain (blockIdx.x = (frame * 3 + channel) * QSEG + seg):
-// fresh start at the segment's first element.  spec[chain][chunk] receives the heads the walk put into
-// each chunk, seg_out[chain][seg] the run left open at the segment end.
-template <bool FP>
-__global__ __launch_bounds__(64 * (QW + 1)) void k_q_heads(QSrc src, const uint8_t* __restrict__ orig,
-                                                         const uint8_t* __restrict__ skip, int HW, QParams qp,
-                                                         const double* __restrict__ Echain, int16_t* __restrict__ tmp,
-                                                         unsigned long long* __restrict__ spec, QState* __restrict__ seg_out) {
-    const int chain = blockIdx.x / QSEG, seg = blockIdx.x % QSEG;
-    const int f = chain / 3, c = chain % 3;
+// ---------------------------------------------------------------------------------------------------------
+// The segmentation as LANE-parallel greedy walks (round 3; form (2) above).
+//   k_q_tiles   a wave owns 4096 consecutive elements of a chain, staged transposed in LDS; lane j walks chunk j
+//               (64 elements = one mask word) from a fresh start and notes the heads in its mask.  Then the
+//               lanes are stitched: lane j takes the run lane j-1 leaves open, lets it pass if its whole chunk fits
+//               (one test on the chunk's min / max), else walks until the true chain meets a head of its own
+//               speculative chain; heads in front of that point are replaced, behind it the guess stands and the
+//               lane's exit state is the speculative one.  Repeated until no lane's incoming run changes (a lane
+//               whose chunk the true chain leaves unmerged, or passes through, changes its successor's input:
+//               typically 2-3 rounds, 64 at worst).  With the heads final, one more walk forms the run values and
+//               puts them at their heads in the LDS tile, which leaves the way it came: 24 bytes per thread, all
+//               three channels.  Output per tile: masks, values, the run left open, min / max.
+//   k_q_chain   one wave per chain: the tiles' open runs chained -- a run that swallows a whole tile (one test on the
+//               tile's min / max) passes, otherwise the tile's own exit state stands (assuming the true chain meets
+//               the tile's speculative one inside it) -- giving every tile the run that really enters it.
+//   k_q_bstitch one wave per tile boundary, all in parallel: the entering run is walked into the tile with the
+//               wave-parallel machinery (q_chunk) until it meets the tile's chain -- usually in the first chunk.
+//               A tile it crosses without meeting the speculative chain marks its chain for
+//   k_q_serial  the exact serial walk of a whole chain (the algorithm of round 1), which runs only for such chains.
+// For abs / rel / absrel the walks are integer: a run is (min d, max d), and "does it break" is
+// fl(min d + E) < fl(max d - E) (compress.py:55-60), monotone in both arguments; k_q_width finds per chain the
+// widths w = max d - min d that are always fine (w <= wmin) and always a break (w > wmax) by evaluating the
+// double test itself on all 511 x 3 candidate pairs -- the two differ only when 2E sits within a rounding error
+// of an integer, and then the walk evaluates the double test for the widths in between.  Run values are
+// trunc((fl(min d + E) + fl(max d - E)) / 2) in double, as the reference computes them.
+struct QWidth {
+    int wmin, wmax;
+};
+
+__device__ __forceinline__ bool q_ok_exact(int mn, int mx, double E) { return !(((double)mn + E) < ((double)mx - E)); }
+
+__global__ __launch_bounds__(64) void k_q_width(const double* __restrict__ Echain, const uint8_t* __restrict__ skip, QParams qp,
+                                              QWidth* __restrict__ width) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    if (skip[chain / 3]) return;
+    const double E = qp.mode == TZ_MODE_ABS ? fabs(qp.b0) : Echain[chain];
+    int wmin = 511, wmax = -1;
+    for (int mn = -255 + lane; mn <= 255; mn += 64) {
+        // W(mn) = largest w with ok(mn, mn + w) (monotone in w); 511 when every feasible w is fine
+        int W;
+        if (!q_ok_exact(mn, mn, E)) W = -1;
+        else if (q_ok_exact(mn, 255, E)) W = 511;
+        else {
+            int lo = 0, hi = 255 - mn;   // ok(lo), !ok(hi)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (q_ok_exact(mn, mn + mid, E)) lo = mid;
+                else hi = mid;
+            }
+            W = lo;
+        }
+        wmin = min(wmin, W);
+        wmax = max(wmax, W);
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        wmin = min(wmin, __shfl_down(wmin, s, 64));
+        wmax = max(wmax, __shfl_down(wmax, s, 64));
+    }
+    if (lane == 0) width[chain] = QWidth{wmin, wmax};
+}
+
+static constexpr int QT_CHUNKS = 64;                 // chunks (= lanes) per tile
+static constexpr int QT_TILE = QT_CHUNKS * 64;       // elements per tile
+static constexpr int QT_S16 = 66, QT_S32 = 65;       // LDS row strides (int16 / int32 elements): lanes j, j+32 share a bank, no more
+
+// run state of the integer walk: mn > mx = empty
+struct QRunI {
+    int mn, mx, hd;   // hd: chain index of the run's head
+};
+struct QRunD {
+    double u, l;
+    int hd;
+};
+
+template <bool PW, bool FP>
+__global__ __launch_bounds__(192) void k_q_tiles(QSrc src, const uint8_t* __restrict__ orig, const uint8_t* __restrict__ skip,
+                                                 int HW, int ntiles, QParams qp, const double* __restrict__ Echain,
+                                                 const QWidth* __restrict__ width, int16_t* __restrict__ tmp,
+                                                 unsigned long long* __restrict__ spec, QState* __restrict__ tile_out,
+                                                 double2* __restrict__ tile_agg) {
+    __shared__ int lds_raw[3 * (PW ? 64 * QT_S32 : 64 * QT_S16 / 2)];
+    const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;   // one wave per channel of the same pixels (they share cache lines)
+    const int f = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
     if (skip[f]) return;
-    __shared__ QSlot slots[2][QW];
+    const int chain = f * 3 + c;
     const size_t fe0 = (size_t)f * HW * 3;
     int16_t* t = tmp + fe0;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double E = 0.0;
-    if (qp.mode == TZ_MODE_ABS) E = fabs(qp.b0);
-    else if (qp.mode != TZ_MODE_PWREL) E = Echain[chain];
-    const double inf = __builtin_huge_val();
     const int nch = (HW + 63) >> 6;
-    const int cps = (nch + QSEG - 1) / QSEG;          // chunks per segment
-    const int c0 = seg * cps, c1 = min(nch, c0 + cps);
-    unsigned long long* sp = spec + (size_t)chain * nch;
-    if (c0 >= c1) {                                    // empty segment (short chain): passes the state on untouched
-        if (threadIdx.x == 0) seg_out[chain * QSEG + seg] = QState{inf, -inf, -1, 0};
-        return;
-    }
-    const int nrounds = (c1 - c0 + QW - 1) / QW;
-    double u = inf, l = -inf;      // resolver: state of the run that is open at the chunk boundary
-    int chead = c0 * 64;           // resolver: its head (chain index): the fresh start
-    for (int r = 0; r <= nrounds; ++r) {
-        if (wv > 0 && r < nrounds) {
-            const int ch = c0 + r * QW + (wv - 1);
-            if (ch < c1) {
-                const QChunk q = qp.mode == TZ_MODE_PWREL ? q_chunk<true, FP>(src, orig, fe0, c, ch, HW, qp, E, lane)
-                                                          : q_chunk<false, FP>(src, orig, fe0, c, ch, HW, qp, E, lane);
-                QSlot& sl = slots[r & 1][wv - 1];
-                sl.cu[lane] = q.cu;
-                sl.cl[lane] = q.cl;
-                sl.pu[lane] = q.pu;
-                sl.pl[lane] = q.pl;
-                sl.nxt[lane] = q.nxt;
-                sl.heads[lane] = q.heads;
+    const int e0 = tile * QT_TILE;                              // first element of the tile in the chain
+    short* ls = (short*)lds_raw + c * 64 * QT_S16;              // !PW: int16 deltas
+    unsigned* lw = (unsigned*)lds_raw + c * 64 * QT_S32;        //  PW: delta | orig << 16
+    // ---- stage the tile transposed: row r = the 64 elements of chunk r (lane r walks it).
+    // Frames of whole 4-pixel groups: the block's three waves load the tile TOGETHER -- a thread takes 4 pixels =
+    // 12 consecutive samples (three 16-byte loads of the prediction + 12 original bytes, or 24 bytes of the delta
+    // stack), forms the deltas and deals them to the three channel planes.  (A wave per channel fetching its own
+    // samples with a stride of three touched every cache line three times, 2-byte / 4-byte accesses: 141 of the
+    // first version's 280 us.)
+    const bool grouped = (HW & 3) == 0 && (((uintptr_t)src.pred & 15) | ((uintptr_t)src.diff & 7) | ((uintptr_t)orig & 3) | ((uintptr_t)tmp & 7)) == 0;
+    if (grouped) {
+        const int npix = min(QT_TILE, HW - e0);
+        for (int g = threadIdx.x; g < QT_TILE / 4; g += 192) {
+            const int p0 = g * 4;
+            int d[12], o[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) d[k] = o[k] = 0;
+            if (p0 < npix) {
+                const size_t e = fe0 + (size_t)(e0 + p0) * 3;
+                if (FP || PW) {
+                    const uint3 ob = *(const uint3*)(orig + e);
+                    const unsigned ow[3] = {ob.x, ob.y, ob.z};
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) o[k] = (int)((ow[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+                }
+                if (FP) {
+                    const float4* pp = (const float4*)(src.pred + e);
+                    const float4 f0 = pp[0], f1 = pp[1], f2 = pp[2];
+                    const float fv[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) d[k] = (int)(fv[k] * 255.0f) - o[k];
+                } else {
+                    const uint2* dp = (const uint2*)(src.diff + e);
+                    const uint2 a0 = dp[0], a1 = dp[1], a2 = dp[2];
+                    const unsigned dw[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) d[k] = (int)(short)((dw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+                }
             }
-        } else if (wv == 0 && r > 0) {
-            // The walk over the chunks is the serial critical path, so nothing that does not depend on
-            // the carried (u, l) may sit on it: every LDS operand of chunk w+1 is loaded while chunk w
-            // resolves, and the lookups at the wave-uniform positions j0 / last are register reads
-            // (v_readlane), not LDS permutes.
-            struct Pre {
-                double pu, pl, cu, cl;
-                unsigned long long hd;
-                int nx;
-            };
-            auto load = [&](int w) {
-                const QSlot& sl = slots[(r - 1) & 1][w];
-                return Pre{sl.pu[lane], sl.pl[lane], sl.cu[lane], sl.cl[lane], sl.heads[lane], sl.nxt[lane]};
-            };
-            Pre cur = load(0), nx = cur;
-            for (int w = 0; w < QW; ++w) {
-                const int ch = c0 + (r - 1) * QW + w;
-                if (ch >= c1) break;
-                if (w + 1 < QW && ch + 1 < c1) nx = load(w + 1);
-                // 4. where does the carried run break?
-                const double eu = u < cur.pu ? u : cur.pu, el = l > cur.pl ? l : cur.pl;
-                const unsigned long long brk = __ballot(eu - el < 0.0);
-                const unsigned long long first = ch == c0 ? 1ull : 0ull;   // the fresh start is a head of the guess
-                if (brk == 0ull) {
-                    u = q_rl_d(eu, 63);
-                    l = q_rl_d(el, 63);
-                    if (lane == 0) sp[ch] = first;
-                    cur = nx;
-                    continue;
+            const int row = p0 >> 6, col = p0 & 63;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {   // sample k of the group = pixel k / 3, channel k % 3
+                if (PW) {
+                    unsigned* w = (unsigned*)lds_raw + cc * 64 * QT_S32 + row * QT_S32 + col;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[i] = ((unsigned)d[3 * i + cc] & 0xFFFFu) | ((unsigned)o[3 * i + cc] << 16);
+                } else {
+                    unsigned* w = (unsigned*)((short*)lds_raw + cc * 64 * QT_S16 + row * QT_S16 + col);   // 4-byte aligned: 132 r + 2 col
+                    w[0] = ((unsigned)d[cc] & 0xFFFFu) | ((unsigned)d[3 + cc] << 16);
+                    w[1] = ((unsigned)d[6 + cc] & 0xFFFFu) | ((unsigned)d[9 + cc] << 16);
                 }
-                const int j0 = __ffsll((long long)brk) - 1;
-                {
-                    double uc = u, lc = l;
-                    if (j0 > 0) {
-                        uc = q_rl_d(eu, j0 - 1);
-                        lc = q_rl_d(el, j0 - 1);
-                    }
-                    if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
-                }
-                const unsigned long long heads = q_rl_u64(cur.hd, j0);
-                const int last = 63 - __clzll((long long)heads);
-                // 5. closed runs store their value at their head; the last head carries on
-                if (((heads >> lane) & 1ull) && cur.nx < 64)
-                    t[(size_t)(ch * 64 + lane) * 3 + c] = (int16_t)(long long)((cur.cu + cur.cl) / 2);
-                if (lane == 0) sp[ch] = heads | first;
-                u = q_rl_d(cur.cu, last);
-                l = q_rl_d(cur.cl, last);
-                chead = ch * 64 + last;
-                cur = nx;
             }
         }
         __syncthreads();
+    } else {
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) {
+            const int idx = e0 + r * 64 + lane;
+            int d = 0, o = 0;
+            if (idx < HW) {
+                const size_t e = fe0 + (size_t)idx * 3 + c;
+                d = q_delta<FP>(src, orig, e);
+                if (PW) o = orig[e];
+            }
+            if (PW) lw[r * QT_S32 + lane] = ((unsigned)d & 0xFFFFu) | ((unsigned)o << 16);
+            else ls[r * QT_S16 + lane] = (short)d;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (wv == 0 && lane == 0) seg_out[chain * QSEG + seg] = QState{u, l, chead, 0};
+    const int base = e0 + lane * 64;                            // chain index of my chunk's first element
+    const int len = max(0, min(64, HW - base));
+    double E = 0.0;
+    int wmin = 0, wmax = 0;
+    if (!PW) {
+        E = qp.mode == TZ_MODE_ABS ? fabs(qp.b0) : Echain[chain];
+        const QWidth wd = width[chain];
+        wmin = wd.wmin;
+        wmax = wd.wmax;
+    }
+    const double inf = __builtin_huge_val();
+    // element access and the run algebra of the two arithmetic forms
+    auto elem_i = [&](int tt) { return (int)ls[lane * QT_S16 + tt]; };
+    // (wave-uniform, and opaque to the compiler: it would otherwise evaluate the double test speculatively in every step)
+    const bool banded = __builtin_amdgcn_readfirstlane(wmin != wmax) != 0;
+    auto ok_i = [&](int mn, int mx) {   // may the run (mn, mx) stand?  exact form of compress.py:60
+        const int w = mx - mn;
+        bool ok = w <= wmin;
+        if (banded) {
+            const bool amb = !ok && w <= wmax;
+            if (__any(amb)) ok = ok || (amb && q_ok_exact(mn, mx, E));
+        }
+        return ok;
+    };
+    // |value| <= 255 + E: the int conversion is the int64 store of compress.py:61 (one instruction instead of five)
+    auto val_i = [&](int mn, int mx) { return (int)((((double)mn + E) + ((double)mx - E)) / 2); };
+    auto elem_d = [&](int tt, double& du, double& dl) {
+        const unsigned w = lw[lane * QT_S32 + tt];
+        const double df = (double)(int)(short)(w & 0xFFFFu), tol = (double)(int)(w >> 16) * qp.b0;
+        du = df + tol;
+        dl = df - tol;
+    };
+
+    // ---- 1. speculative walk of my chunk from a fresh start: heads only (the values follow once the heads are final)
+    unsigned long long Ms = len > 0 ? 1ull : 0ull;
+    QRunI xi{32767, -32768, base};      // !PW
+    QRunD xd{inf, -inf, base};          //  PW
+    int amn = 32767, amx = -32768;      // chunk aggregate (!PW)
+    double au = inf, al = -inf;         //                 ( PW)
+    for (int tt = 0; tt < 64; ++tt) {
+        const bool act = tt < len;
+        if (!PW) {
+            const int d = elem_i(tt);
+            const int nmn = min(xi.mn, d), nmx = max(xi.mx, d);
+            const bool brk = act && xi.mn <= xi.mx && !ok_i(nmn, nmx);
+            if (brk) {
+                Ms |= 1ull << tt;
+                xi = QRunI{d, d, base + tt};
+            } else if (act) {
+                xi.mn = nmn;
+                xi.mx = nmx;
+            }
+            if (act) {
+                amn = min(amn, d);
+                amx = max(amx, d);
+            }
+        } else {
+            double du, dl;
+            elem_d(tt, du, dl);
+            const double nu = xd.u < du ? xd.u : du, nl = xd.l > dl ? xd.l : dl;
+            const bool brk = act && (nu < nl);   // a fresh run (inf, -inf) cannot break: du >= dl for a tolerance >= 0
+            if (brk) {
+                Ms |= 1ull << tt;
+                xd = QRunD{du, dl, base + tt};
+            } else if (act) {
+                xd.u = nu;
+                xd.l = nl;
+            }
+            if (act) {
+                au = au < du ? au : du;
+                al = al > dl ? al : dl;
+            }
+        }
+    }
+    const QRunI xsi = xi;
+    const QRunD xsd = xd;
+    // ---- 2. stitch the lanes: my incoming run is what lane - 1 leaves open; repeat until nothing changes
+    unsigned long long M = Ms;
+    QRunI pini{0, 0, -2};               // the incoming run my current (M, exit) was computed for; hd -2 = none yet
+    QRunD pind{0.0, 0.0, -2};
+    for (int iter = 0; iter < 66; ++iter) {
+        bool dirty;
+        QRunI ini{};
+        QRunD ind{};
+        if (!PW) {
+            ini.mn = __shfl_up(xi.mn, 1, 64);
+            ini.mx = __shfl_up(xi.mx, 1, 64);
+            ini.hd = __shfl_up(xi.hd, 1, 64);
+            dirty = lane > 0 && len > 0 && (ini.mn != pini.mn || ini.mx != pini.mx || ini.hd != pini.hd);
+        } else {
+            ind.u = __shfl_up(xd.u, 1, 64);
+            ind.l = __shfl_up(xd.l, 1, 64);
+            ind.hd = __shfl_up(xd.hd, 1, 64);
+            dirty = lane > 0 && len > 0 && (ind.u != pind.u || ind.l != pind.l || ind.hd != pind.hd);
+        }
+        if (!__any(dirty)) break;
+        bool walking = false;
+        unsigned long long newm = 0;
+        if (dirty) {
+            pini = ini;
+            pind = ind;
+            if (!PW) {
+                const int qmn = min(ini.mn, amn), qmx = max(ini.mx, amx);
+                if (ok_i(qmn, qmx)) {       // the run passes through my whole chunk
+                    M = 0;
+                    xi = QRunI{qmn, qmx, ini.hd};
+                } else {
+                    walking = true;
+                    xi = ini;
+                }
+            } else {
+                const double qu = ind.u < au ? ind.u : au, ql = ind.l > al ? ind.l : al;
+                if (!(qu < ql)) {
+                    M = 0;
+                    xd = QRunD{qu, ql, ind.hd};
+                } else {
+                    walking = true;
+                    xd = ind;
+                }
+            }
+        }
+        for (int tt = 0; tt < 64 && __any(walking); ++tt) {
+            const bool act = walking && tt < len;
+            bool brk;
+            if (!PW) {
+                const int d = elem_i(tt);
+                const int nmn = min(xi.mn, d), nmx = max(xi.mx, d);
+                brk = act && !ok_i(nmn, nmx);
+                if (brk) xi = QRunI{d, d, base + tt};
+                else if (act) {
+                    xi.mn = nmn;
+                    xi.mx = nmx;
+                }
+            } else {
+                double du, dl;
+                elem_d(tt, du, dl);
+                const double nu = xd.u < du ? xd.u : du, nl = xd.l > dl ? xd.l : dl;
+                brk = act && (nu < nl);
+                if (brk) xd = QRunD{du, dl, base + tt};
+                else if (act) {
+                    xd.u = nu;
+                    xd.l = nl;
+                }
+            }
+            if (brk) {
+                if ((Ms >> tt) & 1ull) {   // the true chain starts a run where my speculative chain does: from here on they are one
+                    M = newm | (Ms & ~((1ull << tt) - 1ull));
+                    xi = xsi;
+                    xd = xsd;
+                    walking = false;
+                } else {
+                    newm |= 1ull << tt;
+                }
+            }
+            if (walking && tt == len - 1) {   // left my chunk without meeting the speculative chain
+                M = newm;
+                walking = false;
+            }
+        }
+    }
+    // ---- 3. the run values, now that the heads are final: one more walk of my chunk, which starts with the run that
+    // really enters it (pini / pind: what the last stitch round was computed for; lane 0 starts fresh).  A run's value
+    // replaces the delta at its head IN the LDS tile -- the element has been consumed by then; the one run that may
+    // close in my chunk but started in an earlier lane's row is written after the walk (its row's owner may not have
+    // read that element yet).  The run open at the end of the tile is closed by k_q_chain / k_q_bstitch.
+    {
+        QRunI ri{32767, -32768, base};
+        QRunD rd{inf, -inf, base};
+        if (lane > 0 && len > 0) {
+            ri = pini;
+            rd = pind;
+        }
+        int late_hd = -1, late_v = 0;
+        for (int tt = 0; tt < 64; ++tt) {
+            const bool act = tt < len;
+            const bool head = act && ((M >> tt) & 1ull);
+            int d = 0;
+            double du = 0.0, dl = 0.0;
+            if (!PW) d = elem_i(tt);
+            else elem_d(tt, du, dl);
+            if (__any(head)) {
+                // (the run in front of a head is empty only for lane 0's first element)
+                if (head && (!PW ? ri.mn <= ri.mx : (rd.u != inf || rd.l != -inf))) {
+                    const int v = !PW ? val_i(ri.mn, ri.mx) : (int)((rd.u + rd.l) / 2);
+                    const int hd = !PW ? ri.hd : rd.hd;
+                    if (hd >= base) {
+                        if (!PW) ls[lane * QT_S16 + (hd - base)] = (short)v;
+                        else lw[lane * QT_S32 + (hd - base)] = (unsigned)v & 0xFFFFu;
+                    } else {
+                        late_hd = hd;
+                        late_v = v;
+                    }
+                }
+            }
+            if (head) {
+                ri = QRunI{d, d, base + tt};
+                rd = QRunD{du, dl, base + tt};
+            } else if (act) {
+                ri.mn = min(ri.mn, d);
+                ri.mx = max(ri.mx, d);
+                rd.u = rd.u < du ? rd.u : du;
+                rd.l = rd.l > dl ? rd.l : dl;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (late_hd >= 0) {
+            const int rel = late_hd - e0;
+            if (!PW) ls[(rel >> 6) * QT_S16 + (rel & 63)] = (short)late_v;
+            else lw[(rel >> 6) * QT_S32 + (rel & 63)] = (unsigned)late_v & 0xFFFFu;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (grouped) {
+            // flush, the way the tile came in: all three planes, 12 consecutive samples = 24 bytes per thread.  Dense -- what is
+            // not a head carries its delta along, which nobody reads (the masks say where the heads are)
+            __syncthreads();
+            const int npix = min(QT_TILE, HW - e0);
+            for (int g = threadIdx.x; g < QT_TILE / 4; g += 192) {
+                const int p0 = g * 4;
+                if (p0 >= npix) continue;
+                const int row = p0 >> 6, col = p0 & 63;
+                unsigned v[12];
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    if (PW) {
+                        const unsigned* w = (const unsigned*)lds_raw + cc * 64 * QT_S32 + row * QT_S32 + col;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[3 * i + cc] = w[i] & 0xFFFFu;
+                    } else {
+                        const unsigned* w = (const unsigned*)((const short*)lds_raw + cc * 64 * QT_S16 + row * QT_S16 + col);
+                        const unsigned w0 = w[0], w1 = w[1];
+                        v[cc] = w0 & 0xFFFFu;
+                        v[3 + cc] = w0 >> 16;
+                        v[6 + cc] = w1 & 0xFFFFu;
+                        v[9 + cc] = w1 >> 16;
+                    }
+                }
+                uint2* dst = (uint2*)(t + (size_t)(e0 + p0) * 3);
+                dst[0] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+                dst[1] = make_uint2(v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+                dst[2] = make_uint2(v[8] | (v[9] << 16), v[10] | (v[11] << 16));
+            }
+        } else {
+            // flush: row r = chunk r, a lane per element; only heads carry a value
+            const unsigned mlo = (unsigned)M, mhi = (unsigned)(M >> 32);
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r) {
+                const unsigned long long mr = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mhi, r) << 32) |
+                                              (unsigned)__builtin_amdgcn_readlane((int)mlo, r);
+                if ((mr >> lane) & 1ull) {
+                    const int v = !PW ? (int)ls[r * QT_S16 + lane] : (int)(short)(lw[r * QT_S32 + lane] & 0xFFFFu);
+                    t[(size_t)(e0 + r * 64 + lane) * 3 + c] = (int16_t)v;
+                }
+            }
+        }
+    }
+    // ---- 4. results
+    const int chunk = tile * QT_CHUNKS + lane;
+    if (chunk < nch) spec[(size_t)chain * nch + chunk] = M;
+    const int lastl = min(63, (min(HW, e0 + QT_TILE) - e0 - 1) >> 6);   // the last lane that holds elements
+    if (!PW) {
+        int tmn = len > 0 ? amn : 32767, tmx = len > 0 ? amx : -32768;
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            tmn = min(tmn, __shfl_xor(tmn, sft, 64));
+            tmx = max(tmx, __shfl_xor(tmx, sft, 64));
+        }
+        if (lane == lastl) {
+            tile_out[(size_t)chain * ntiles + tile] = QState{(double)xi.mn + E, (double)xi.mx - E, xi.hd, 0};
+            tile_agg[(size_t)chain * ntiles + tile] = make_double2((double)tmn + E, (double)tmx - E);
+        }
+    } else {
+        double tu = au, tl = al;
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const double a = __shfl_xor(tu, sft, 64), b = __shfl_xor(tl, sft, 64);
+            tu = tu < a ? tu : a;
+            tl = tl > b ? tl : b;
+        }
+        if (lane == lastl) {
+            tile_out[(size_t)chain * ntiles + tile] = QState{xd.u, xd.l, xd.hd, 0};
+            tile_agg[(size_t)chain * ntiles + tile] = make_double2(tu, tl);
+        }
+    }
 }
 
-// Exact repair of the segment guesses, one wave per chain, segments in order.  `st` is the TRUE open run
-// entering segment k.  It is walked through the segment's chunks (tables recomputed by this wave) until
-// the true chain shares a head with the guessed one (mask spec[chunk]): guessed heads before that point
-// leave the mask, true ones enter it (with their values in tmp); from the common head on the guess is
-// right, so the true state leaving the segment is the guessed one.  A segment without any common head is
-// walked to its end (worst case: the serial walk of round 1).  Finally the run open at the chain end is
-// closed.
+// The run that really enters every tile (see k_q_tiles); closes the run that is open at the end of the chain.
+__global__ __launch_bounds__(64) void k_q_chain(const uint8_t* __restrict__ skip, int HW, int ntiles, const QState* __restrict__ tile_out,
+                                              const double2* __restrict__ tile_agg, QState* __restrict__ tile_in,
+                                              uint8_t* __restrict__ swallowed, int16_t* __restrict__ tmp) {
+    const int chain = blockIdx.x, f = chain / 3, c = chain % 3, lane = threadIdx.x;
+    if (skip[f]) return;
+    double su = 0.0, sl = 0.0;
+    int sh = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += 64) {
+        const int T = t0 + lane;
+        QState o{0.0, 0.0, 0, 0};
+        double2 g = make_double2(0.0, 0.0);
+        if (T < ntiles) {
+            o = tile_out[(size_t)chain * ntiles + T];
+            g = tile_agg[(size_t)chain * ntiles + T];
+        }
+        double iu = 0.0, il = 0.0;
+        int ih = 0, sw = 0;
+        const int cnt = min(64, ntiles - t0);
+        for (int k = 0; k < cnt; ++k) {
+            const double ou = q_rl_d(o.u, k), ol = q_rl_d(o.l, k);
+            const int oh = __builtin_amdgcn_readlane(o.head, k);
+            if (t0 + k == 0) {          // the first tile starts where the chain starts: its guess is the truth
+                su = ou;
+                sl = ol;
+                sh = oh;
+                continue;
+            }
+            const double gu = q_rl_d(g.x, k), gl = q_rl_d(g.y, k);
+            const double qu = su < gu ? su : gu, ql = sl > gl ? sl : gl;
+            const bool pass = !(qu < ql);
+            if (lane == k) {
+                iu = su;
+                il = sl;
+                ih = sh;
+                sw = pass;
+            }
+            if (pass) {
+                su = qu;
+                sl = ql;
+            } else {
+                su = ou;
+                sl = ol;
+                sh = oh;
+            }
+        }
+        if (T < ntiles && T > 0) {
+            tile_in[(size_t)chain * ntiles + T] = QState{iu, il, ih, 0};
+            swallowed[(size_t)chain * ntiles + T] = (uint8_t)sw;
+        }
+    }
+    if (lane == 0 && HW > 0) tmp[((size_t)f * HW + sh) * 3 + c] = (int16_t)(long long)((su + sl) / 2);
+}
+
+// The run entering tile T walked into the tile until it meets the tile's own chain (see k_q_tiles); a tile that is
+// crossed without that marks the chain for k_q_serial.
 template <bool FP>
-__global__ __launch_bounds__(64) void k_q_stitch(QSrc src, const uint8_t* __restrict__ orig,
-                                               const uint8_t* __restrict__ skip, int HW, QParams qp,
-                                               const double* __restrict__ Echain, int16_t* __restrict__ tmp,
-                                               unsigned long long* __restrict__ spec, const QState* __restrict__ seg_out) {
-    const int chain = blockIdx.x, f = chain / 3, c = chain % 3;
-    if (skip[f] || HW <= 0) return;
+__global__ __launch_bounds__(64) void k_q_bstitch(QSrc src, const uint8_t* __restrict__ orig, const uint8_t* __restrict__ skip,
+                                                int HW, int ntiles, QParams qp, const double* __restrict__ Echain,
+                                                int16_t* __restrict__ tmp, unsigned long long* __restrict__ spec,
+                                                const QState* __restrict__ tile_in, const uint8_t* __restrict__ swallowed,
+                                                int* __restrict__ bad) {
+    const int chain = blockIdx.x / (ntiles - 1), T = 1 + blockIdx.x % (ntiles - 1);
+    const int f = chain / 3, c = chain % 3, lane = threadIdx.x;
+    if (skip[f]) return;
     const size_t fe0 = (size_t)f * HW * 3;
     int16_t* t = tmp + fe0;
-    const int lane = threadIdx.x;
+    const int nch = (HW + 63) >> 6;
+    unsigned long long* sp = spec + (size_t)chain * nch;
+    const int c0 = T * QT_CHUNKS, c1 = min(nch, c0 + QT_CHUNKS);
+    if (swallowed[(size_t)chain * ntiles + T]) {   // the entering run covers the whole tile: none of its guessed heads is one
+        if (c0 + lane < c1) sp[c0 + lane] = 0ull;
+        return;
+    }
     double E = 0.0;
     if (qp.mode == TZ_MODE_ABS) E = fabs(qp.b0);
     else if (qp.mode != TZ_MODE_PWREL) E = Echain[chain];
-    const int nch = (HW + 63) >> 6;
-    const int cps = (nch + QSEG - 1) / QSEG;
-    unsigned long long* sp = spec + (size_t)chain * nch;
-    QState st = seg_out[chain * QSEG];          // segment 0 starts where the chain starts: its guess is the truth
+    const QState st = tile_in[(size_t)chain * ntiles + T];
     double u = st.u, l = st.l;
     int chead = st.head;
-    for (int k = 1; k < QSEG; ++k) {
-        const int c0 = k * cps, c1 = min(nch, c0 + cps);
-        if (c0 >= c1) break;
-        bool merged = false;
-        for (int ch = c0; ch < c1 && !merged; ++ch) {
-            const QChunk q = qp.mode == TZ_MODE_PWREL ? q_chunk<true, FP>(src, orig, fe0, c, ch, HW, qp, E, lane)
-                                                      : q_chunk<false, FP>(src, orig, fe0, c, ch, HW, qp, E, lane);
-            const unsigned long long S = sp[ch];
-            const double eu = u < q.pu ? u : q.pu, el = l > q.pl ? l : q.pl;
-            const unsigned long long brk = __ballot(eu - el < 0.0);
-            if (brk == 0ull) {                  // the true run swallows the chunk: every guessed head in it is wrong
-                if (lane == 0) sp[ch] = 0ull;
-                u = q_rl_d(eu, 63);
-                l = q_rl_d(el, 63);
-                continue;
-            }
-            const int j0 = __ffsll((long long)brk) - 1;
-            double uc = u, lc = l;
-            if (j0 > 0) {
-                uc = q_rl_d(eu, j0 - 1);
-                lc = q_rl_d(el, j0 - 1);
-            }
-            const unsigned long long T = q_rl_u64(q.heads, j0);          // true heads of this chunk
-            const unsigned long long common = T & S;
-            const int m = common ? __ffsll((long long)common) - 1 : 64;  // first common head
-            const unsigned long long below = m >= 64 ? ~0ull : ((1ull << m) - 1ull);
-            const bool mine = (below >> lane) & 1ull;
-            if (mine && ((T >> lane) & 1ull) && q.nxt < 64)
-                t[(size_t)(ch * 64 + lane) * 3 + c] = (int16_t)(long long)((q.cu + q.cl) / 2);
-            if (lane == 0) {
-                sp[ch] = (S & ~below) | (T & below);
-                // the carried run closes at j0: its head keeps its mask bit and gets its value
-                t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
-            }
-            if (common) {
-                merged = true;
-            } else {
-                const int last = 63 - __clzll((long long)T);
-                u = q_rl_d(q.cu, last);
-                l = q_rl_d(q.cl, last);
-                chead = ch * 64 + last;
-            }
+    bool merged = false;
+    for (int ch = c0; ch < c1 && !merged; ++ch) {
+        const QChunk q = qp.mode == TZ_MODE_PWREL ? q_chunk<true, FP>(src, orig, fe0, c, ch, HW, qp, E, lane)
+                                                  : q_chunk<false, FP>(src, orig, fe0, c, ch, HW, qp, E, lane);
+        const unsigned long long S = sp[ch];
+        const double eu = u < q.pu ? u : q.pu, el = l > q.pl ? l : q.pl;
+        const unsigned long long brk = __ballot(eu - el < 0.0);
+        if (brk == 0ull) {                  // the true run swallows the chunk: every guessed head in it is wrong
+            if (lane == 0) sp[ch] = 0ull;
+            u = q_rl_d(eu, 63);
+            l = q_rl_d(el, 63);
+            continue;
         }
-        if (merged) {
-            st = seg_out[chain * QSEG + k];
-            u = st.u;
-            l = st.l;
-            chead = st.head;
+        const int j0 = __ffsll((long long)brk) - 1;
+        double uc = u, lc = l;
+        if (j0 > 0) {
+            uc = q_rl_d(eu, j0 - 1);
+            lc = q_rl_d(el, j0 - 1);
         }
+        const unsigned long long Tm = q_rl_u64(q.heads, j0);         // true heads of this chunk
+        const unsigned long long common = Tm & S;
+        const int m = common ? __ffsll((long long)common) - 1 : 64;  // first common head
+        const unsigned long long below = m >= 64 ? ~0ull : ((1ull << m) - 1ull);
+        const bool mine = (below >> lane) & 1ull;
+        if (mine && ((Tm >> lane) & 1ull) && q.nxt < 64)
+            t[(size_t)(ch * 64 + lane) * 3 + c] = (int16_t)(long long)((q.cu + q.cl) / 2);
+        if (lane == 0) {
+            sp[ch] = (S & ~below) | (Tm & below);
+            t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);   // the entering run closes at j0
+        }
+        if (common) {
+            merged = true;
+        } else {
+            const int last = 63 - __clzll((long long)Tm);
+            u = q_rl_d(q.cu, last);
+            l = q_rl_d(q.cl, last);
+            chead = ch * 64 + last;
+        }
+    }
+    if (!merged && lane == 0) atomicOr(&bad[chain], 1);
+}
+
+// Exact serial walk of a whole chain (one wave, chunk after chunk: the algorithm of round 1), for the chains
+// k_q_bstitch marked: the true chain crossed a whole 4096-element tile out of step with the tile's speculative chain
+// (regular ramps do that).  Rewrites every mask word and run value of the chain.
+template <bool FP>
+__global__ __launch_bounds__(64) void k_q_serial(QSrc src, const uint8_t* __restrict__ orig, const uint8_t* __restrict__ skip, int HW,
+                                               QParams qp, const double* __restrict__ Echain, int16_t* __restrict__ tmp,
+                                               unsigned long long* __restrict__ spec, const int* __restrict__ bad) {
+    const int chain = blockIdx.x, f = chain / 3, c = chain % 3, lane = threadIdx.x;
+    if (skip[f] || !bad[chain] || HW <= 0) return;
+    const size_t fe0 = (size_t)f * HW * 3;
+    int16_t* t = tmp + fe0;
+    const int nch = (HW + 63) >> 6;
+    unsigned long long* sp = spec + (size_t)chain * nch;
+    double E = 0.0;
+    if (qp.mode == TZ_MODE_ABS) E = fabs(qp.b0);
+    else if (qp.mode != TZ_MODE_PWREL) E = Echain[chain];
+    double u = __builtin_huge_val(), l = -__builtin_huge_val();
+    int chead = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const QChunk q = qp.mode == TZ_MODE_PWREL ? q_chunk<true, FP>(src, orig, fe0, c, ch, HW, qp, E, lane)
+                                                  : q_chunk<false, FP>(src, orig, fe0, c, ch, HW, qp, E, lane);
+        const unsigned long long first = ch == 0 ? 1ull : 0ull;
+        const double eu = u < q.pu ? u : q.pu, el = l > q.pl ? l : q.pl;
+        const unsigned long long brk = __ballot(eu - el < 0.0);
+        if (brk == 0ull) {
+            u = q_rl_d(eu, 63);
+            l = q_rl_d(el, 63);
+            if (lane == 0) sp[ch] = first;
+            continue;
+        }
+        const int j0 = __ffsll((long long)brk) - 1;
+        double uc = u, lc = l;
+        if (j0 > 0) {
+            uc = q_rl_d(eu, j0 - 1);
+            lc = q_rl_d(el, j0 - 1);
+        }
+        if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((uc + lc) / 2);
+        const unsigned long long heads = q_rl_u64(q.heads, j0);
+        const int last = 63 - __clzll((long long)heads);
+        if (((heads >> lane) & 1ull) && q.nxt < 64) t[(size_t)(ch * 64 + lane) * 3 + c] = (int16_t)(long long)((q.cu + q.cl) / 2);
+        if (lane == 0) sp[ch] = heads | first;
+        u = q_rl_d(q.cu, last);
+        l = q_rl_d(q.cl, last);
+        chead = ch * 64 + last;
     }
     if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((u + l) / 2);
 }
@@ -913,7 +1343,7 @@ static int quant_run(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const QFus
     int HW = H * W;
     size_t fe = (size_t)HW * 3;
     int nblk = (HW + QFB - 1) / QFB;
-    void *d_skip, *d_E, *d_tmp, *d_carry, *d_mm, *d_spec, *d_seg, *d_ftail;
+    void *d_skip, *d_E, *d_tmp, *d_carry, *d_mm, *d_spec, *d_ftail;
     TZ_TRY(tz_pool_alloc(ctx, nframes, &d_skip));
     TZ_TRY(tz_pool_alloc(ctx, sizeof(double) * 3 * nframes, &d_E));
     TZ_TRY(tz_pool_alloc(ctx, sizeof(int) * 6 * nframes, &d_mm));
@@ -922,7 +1352,6 @@ static int quant_run(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const QFus
     TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * 3 * 2, &d_ftail));
     const int nch = (HW + 63) / 64;
     TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * 3 * nch * sizeof(unsigned long long), &d_spec));
-    TZ_TRY(tz_pool_alloc(ctx, (size_t)nframes * 3 * QSEG * sizeof(QState), &d_seg));
     TZ_TRY(tz_upload(ctx, d_skip, h_skip, nframes));
     QParams qp{mode, b0, b1};
     QSrc src{diff, fu ? fu->pred : nullptr};
@@ -935,18 +1364,47 @@ static int quant_run(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const QFus
             hipLaunchKernelGGL(k_q_bound, dim3((3 * nframes + 63) / 64), dim3(64), 0, ctx->stream, (const int*)d_mm,
                                (const uint8_t*)d_skip, qp, nframes, (double*)d_E);
         }
-        if (fu) {
-            hipLaunchKernelGGL(k_q_heads<true>, dim3(nframes * 3 * QSEG), dim3(64 * (QW + 1)), 0, ctx->stream, src, orig,
-                               (const uint8_t*)d_skip, HW, qp, (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec,
-                               (QState*)d_seg);
-            hipLaunchKernelGGL(k_q_stitch<true>, dim3(nframes * 3), dim3(64), 0, ctx->stream, src, orig, (const uint8_t*)d_skip, HW,
-                               qp, (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec, (const QState*)d_seg);
-        } else {
-            hipLaunchKernelGGL(k_q_heads<false>, dim3(nframes * 3 * QSEG), dim3(64 * (QW + 1)), 0, ctx->stream, src, orig,
-                               (const uint8_t*)d_skip, HW, qp, (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec,
-                               (QState*)d_seg);
-            hipLaunchKernelGGL(k_q_stitch<false>, dim3(nframes * 3), dim3(64), 0, ctx->stream, src, orig, (const uint8_t*)d_skip, HW,
-                               qp, (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec, (const QState*)d_seg);
+        {
+            const int ntiles = (nch + QT_CHUNKS - 1) / QT_CHUNKS, nchains = nframes * 3;
+            void *d_width, *d_tout, *d_tin, *d_tagg, *d_swal, *d_bad;
+            TZ_TRY(tz_pool_alloc(ctx, sizeof(QWidth) * nchains, &d_width));
+            TZ_TRY(tz_pool_alloc(ctx, sizeof(QState) * (size_t)nchains * ntiles, &d_tout));
+            TZ_TRY(tz_pool_alloc(ctx, sizeof(QState) * (size_t)nchains * ntiles, &d_tin));
+            TZ_TRY(tz_pool_alloc(ctx, sizeof(double2) * (size_t)nchains * ntiles, &d_tagg));
+            TZ_TRY(tz_pool_alloc(ctx, (size_t)nchains * ntiles, &d_swal));
+            TZ_TRY(tz_pool_alloc(ctx, sizeof(int) * nchains, &d_bad));
+            TZ_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(int) * nchains, ctx->stream));
+            const bool pw = mode == TZ_MODE_PWREL;
+            if (!pw)
+                hipLaunchKernelGGL(k_q_width, dim3(nchains), dim3(64), 0, ctx->stream, (const double*)d_E, (const uint8_t*)d_skip, qp,
+                                   (QWidth*)d_width);
+#define TZ_Q_TILES(PWV, FPV)                                                                                                    \
+    hipLaunchKernelGGL((k_q_tiles<PWV, FPV>), dim3(nframes * ntiles), dim3(192), 0, ctx->stream, src, orig, (const uint8_t*)d_skip, HW, \
+                       ntiles, qp, (const double*)d_E, (const QWidth*)d_width, (int16_t*)d_tmp, (unsigned long long*)d_spec,         \
+                       (QState*)d_tout, (double2*)d_tagg)
+            if (pw && fu) TZ_Q_TILES(true, true);
+            else if (pw) TZ_Q_TILES(true, false);
+            else if (fu) TZ_Q_TILES(false, true);
+            else TZ_Q_TILES(false, false);
+#undef TZ_Q_TILES
+            hipLaunchKernelGGL(k_q_chain, dim3(nchains), dim3(64), 0, ctx->stream, (const uint8_t*)d_skip, HW, ntiles,
+                               (const QState*)d_tout, (const double2*)d_tagg, (QState*)d_tin, (uint8_t*)d_swal, (int16_t*)d_tmp);
+            if (ntiles > 1) {
+                if (fu)
+                    hipLaunchKernelGGL(k_q_bstitch<true>, dim3(nchains * (ntiles - 1)), dim3(64), 0, ctx->stream, src, orig,
+                                       (const uint8_t*)d_skip, HW, ntiles, qp, (const double*)d_E, (int16_t*)d_tmp,
+                                       (unsigned long long*)d_spec, (const QState*)d_tin, (const uint8_t*)d_swal, (int*)d_bad);
+                else
+                    hipLaunchKernelGGL(k_q_bstitch<false>, dim3(nchains * (ntiles - 1)), dim3(64), 0, ctx->stream, src, orig,
+                                       (const uint8_t*)d_skip, HW, ntiles, qp, (const double*)d_E, (int16_t*)d_tmp,
+                                       (unsigned long long*)d_spec, (const QState*)d_tin, (const uint8_t*)d_swal, (int*)d_bad);
+                if (fu)
+                    hipLaunchKernelGGL(k_q_serial<true>, dim3(nchains), dim3(64), 0, ctx->stream, src, orig, (const uint8_t*)d_skip, HW, qp,
+                                       (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec, (const int*)d_bad);
+                else
+                    hipLaunchKernelGGL(k_q_serial<false>, dim3(nchains), dim3(64), 0, ctx->stream, src, orig, (const uint8_t*)d_skip, HW, qp,
+                                       (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec, (const int*)d_bad);
+            }
         }
         hipLaunchKernelGGL(k_q_last, dim3((nframes * nblk * 3 + 255) / 256), dim3(256), 0, ctx->stream, (const int16_t*)d_tmp,
                            (const unsigned long long*)d_spec, (const uint8_t*)d_skip, HW, nch, nblk, nframes, (int16_t*)d_carry);
