@@ -136,7 +136,7 @@ def error_bound_frame(orig_hwc, diff_hwc, mode, value):
         rc = lib().tzo_error_bound(C.c_void_p(orig.ctypes.data + c), C.c_void_p(d.ctypes.data + 2 * c),
                                    n, 3, MODES[mode], float(value[0]), v1)
         if rc:
-            raise ValueError("pwrel bound must be >= 0")
+            raise ValueError("%s bound must be >= 0 (the reference raises on a negative tolerance)" % mode)
     return d
 
 

@@ -71,6 +71,10 @@ def error_bound(orig, diff, mode, value):
         return diff.astype(np.int64)
     bf = np.asarray(orig).reshape(-1).astype(np.int64)
     df = diff.reshape(-1).astype(np.int64)
+    if (mode == "rel" and value[0] < 0) or (mode == "absrel" and value[1] < 0):
+        # a negative tolerance: the reference assigns (inf + -inf)/2 = NaN into its int array at the first
+        # element (compress.py:60-61) and raises; rejected up front like pwrel below
+        raise ValueError("%s bound must be >= 0" % mode)
     if mode == "abs":
         e = np.full(df.shape, float(abs(value[0])))
     elif mode == "rel":

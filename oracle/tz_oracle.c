@@ -42,8 +42,8 @@ void tzo_delta_frame(const float* pred_pad, const uint8_t* orig, int H, int W, i
 }
 
 /* compress.py:23-70 on one (frame, channel) chain of n elements with element stride `stride`.
- * mode: 0 abs, 1 rel, 2 absrel, 3 pwrel.  Returns 0, or -1 for pwrel with a negative bound
- * (the reference raises there). In place on diff. */
+ * mode: 0 abs, 1 rel, 2 absrel, 3 pwrel.  Returns 0, or -1 for a negative pwrel / rel bound or a negative
+ * rel bound of absrel (the reference raises there). In place on diff. */
 int tzo_error_bound(const uint8_t* orig, int16_t* diff, long n, long stride, int mode, double v0, double v1) {
     if (v0 == 0.0) return 0;
     double E = 0.0;
@@ -66,6 +66,9 @@ int tzo_error_bound(const uint8_t* orig, int16_t* diff, long n, long stride, int
     } else if (mode == 3) {
         if (v0 < 0.0) return -1;
     }
+    /* a negative tolerance: the reference assigns (inf + -inf)/2 = NaN into its int array at the first element
+     * (compress.py:60-61) and raises */
+    if ((mode == 1 && v0 < 0.0) || (mode == 2 && v1 < 0.0)) return -1;
     double u = INFINITY, l = -INFINITY;
     long head = 0;
     for (long i = 0; i < n; ++i) {

@@ -51,8 +51,9 @@ def test_c_error_bound_long_chains_match_reference(i):
 
 
 def test_c_error_bound_rejects_negative_pwrel():
-    with pytest.raises(ValueError):
-        coracle.error_bound_frame(np.zeros((2, 2, 3), np.uint8), np.zeros((2, 2, 3), np.int16), "pwrel", [-0.5])
+    for mode, bound in (("pwrel", [-0.5]), ("rel", [-0.01]), ("absrel", [3.0, -0.2])):
+        with pytest.raises(ValueError):
+            coracle.error_bound_frame(np.zeros((2, 2, 3), np.uint8), np.zeros((2, 2, 3), np.int16), mode, bound)
 
 
 def test_c_spatial_delta_both_ways_match_reference():

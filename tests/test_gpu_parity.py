@@ -98,12 +98,65 @@ def test_error_bound_against_reference_long_chains(ctx, i):
     np.testing.assert_array_equal(got3[2], diff)
 
 
+def test_error_bound_chains_that_never_meet_their_speculative_start(ctx):
+    """The lane-parallel quantiser (k_q_tiles) walks every 64-element chunk from a speculative fresh start and
+    relies on the true chain meeting the speculative one; regular ramps keep two greedy chains out of step for
+    ever.  Slow triangle waves over 4+ tiles of 4096 elements: whatever the kernels do -- in-tile stitch rounds
+    that never merge, tiles crossed without a common head, the serial fallback k_q_serial -- the result must be
+    the oracle's, and the fallback must really have run for some of these chains."""
+    h, w = 160, 128                                   # 20,480 elements per chain = 5 tiles
+    n = h * w
+    i = np.arange(n)
+    frames = []
+    for period, step in ((10, 1), (7, 1), (23, 2), (3, 1), (64, 1), (50, 3)):
+        k = (i // period) * step
+        tri = np.abs((k % 400) - 200) - 100           # slope +-step per `period` elements, no jump anywhere
+        frames.append(np.stack([tri, -tri, np.roll(tri, 1234)], axis=-1).reshape(h, w, 3))
+    diff = np.stack(frames).astype(np.int16)
+    orig = np.full(diff.shape, 200, np.uint8)
+    orig[:, 0, 0] = 0                                  # range 200 for `rel`
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    for mode, bound in (("abs", [2.0]), ("abs", [7.0]), ("rel", [0.0126]), ("pwrel", [0.011])):
+        got = ctx.error_bound(orig, diff.copy(), mode, bound)
+        for f in range(diff.shape[0]):
+            np.testing.assert_array_equal(got[f], coracle.error_bound_frame(orig[f], diff[f], mode, bound),
+                                          err_msg="%s %s, frame %d" % (mode, bound, f))
+    serial = ctx.prof_get()["quant_serial_chains"][1]
+    ctx.prof_enable(False)
+    assert serial > 0, "none of the ramp chains took the serial fallback: the test no longer covers it"
+
+
+@pytest.mark.parametrize("mode,bound", [("abs", [0.49999999999999994]), ("abs", [1.4999999999999998]), ("rel", [0.5 / 255 * (1 - 2 ** -53)]),
+                                        ("absrel", [1.4999999999999998, 0.9]), ("abs", [300.0])])
+def test_error_bound_tolerances_on_a_rounding_edge(ctx, mode, bound):
+    """compress.py:60 compares fl(min d + E) with fl(max d - E).  For an E a rounding error away from k/2 the
+    widest run that may stand depends on WHERE the deltas sit (0.49999999999999994: 0 and 1 break, 100 and 101
+    merge), which is the case k_q_width reports as a band and k_q_tiles resolves with the double test; a huge
+    tolerance makes a chain one run.  All against the oracle, which evaluates the doubles literally."""
+    rng = np.random.default_rng(77)
+    h, w = 64, 96                                      # 6144 elements: two tiles
+    walk = np.clip(np.round(np.cumsum(rng.normal(0, 0.6, (2, h * w, 3)), axis=1)), -255, 255)
+    walk[1] += 100                                     # the same kind of data around 0 and around 100
+    near = rng.integers(0, 2, (1, h * w, 3)) + np.array([0, 100, -100])
+    diff = np.concatenate([walk, near]).reshape(3, h, w, 3).astype(np.int16)
+    orig = rng.integers(0, 256, diff.shape).astype(np.uint8)
+    orig[:, 0, 0], orig[:, 0, 1] = 0, 255
+    got = ctx.error_bound(orig, diff.copy(), mode, bound)
+    for f in range(3):
+        np.testing.assert_array_equal(got[f], coracle.error_bound_frame(orig[f], diff[f], mode, bound), err_msg="frame %d" % f)
+
+
 def test_error_bound_rejects_negative_pwrel(ctx):
+    """A negative tolerance makes the reference assign NaN into its int array at the first element
+    (compress.py:60-61): it raises.  pwrel, rel and the rel bound of absrel take the sign of their bound."""
     from tezip_amd._lib import TezipError
     o = np.zeros((1, 8, 8, 3), np.uint8)
     d = np.zeros((1, 8, 8, 3), np.int16)
-    with pytest.raises(TezipError):
-        ctx.error_bound(o, d, "pwrel", [-0.1])
+    for mode, bound in (("pwrel", [-0.1]), ("rel", [-0.01]), ("absrel", [3.0, -0.2])):
+        with pytest.raises(TezipError):
+            ctx.error_bound(o, d, mode, bound)
+    ctx.error_bound(o, d, "abs", [-3.0])   # abs takes |b| (compress.py:29)
 
 
 @pytest.mark.parametrize("n", [1, 7, 8, 4099, 3 * 64 * 64 * 5 + 3])

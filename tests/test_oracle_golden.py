@@ -47,8 +47,9 @@ def test_error_bound_doc_kat():
 
 
 def test_error_bound_rejects_negative_pwrel():
-    with pytest.raises(ValueError):
-        O.error_bound(np.array([1, 2]), np.array([0, 1]), "pwrel", [-0.1])
+    for mode, bound in (("pwrel", [-0.1]), ("rel", [-0.01]), ("absrel", [3.0, -0.2])):
+        with pytest.raises(ValueError):
+            O.error_bound(np.array([1, 2]), np.array([0, 1]), mode, bound)
 
 
 def test_finding_difference_both_ways():

@@ -384,7 +384,7 @@ tz_prof_scope::~tz_prof_scope() {
 static const char* kProfNames[TZP_COUNT] = {"conv3x3_mfma", "err0", "delta", "quant", "spatial_delta_hist",
                                             "lut_remap", "undelta_scan", "reconstruct", "sse",
                                             "conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general",
-                                            "convlat_small_grid", "table_create"};
+                                            "convlat_small_grid", "table_create", "quant_serial_chains"};
 
 extern "C" int tz_prof_enable(tz_ctx* ctx, int on) {
     if (!ctx) return TZ_ERR_INVALID;

@@ -3,6 +3,7 @@
 // allows), LDS-privatised histogram, grid-stride launches of ~8 blocks per CU.
 // Reference semantics are cited per kernel (paths into /root/reference/src).
 #include <algorithm>
+#include <vector>
 
 #include "tz_internal.h"
 
@@ -1404,6 +1405,12 @@ static int quant_run(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const QFus
                 else
                     hipLaunchKernelGGL(k_q_serial<false>, dim3(nchains), dim3(64), 0, ctx->stream, src, orig, (const uint8_t*)d_skip, HW, qp,
                                        (const double*)d_E, (int16_t*)d_tmp, (unsigned long long*)d_spec, (const int*)d_bad);
+                if (ctx->prof_on) {   // how many chains took the fallback (a test asserts that its ramps really do)
+                    std::vector<int> hb(nchains, 0);
+                    TZ_HIP(ctx, hipMemcpyAsync(hb.data(), d_bad, sizeof(int) * nchains, hipMemcpyDeviceToHost, ctx->stream));
+                    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    for (int v : hb) ctx->prof[TZP_QSERIAL].launches += v != 0;
+                }
             }
         }
         hipLaunchKernelGGL(k_q_last, dim3((nframes * nblk * 3 + 255) / 256), dim3(256), 0, ctx->stream, (const int16_t*)d_tmp,
@@ -1448,8 +1455,10 @@ int tzk_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8
     if (mode < 0 || mode > 3) return tz_fail(ctx, TZ_ERR_INVALID, "unknown error-bound mode %d", mode);
     if (b0 == 0.0) return TZ_OK;                          // compress.py:24
     if (mode == TZ_MODE_ABSREL && b1 == 0.0) return TZ_OK;  // compress.py:35
-    if (mode == TZ_MODE_PWREL && b0 < 0.0)
-        return tz_fail(ctx, TZ_ERR_INVALID, "pwrel bound must be >= 0 (the reference raises on a negative one)");
+    if ((mode == TZ_MODE_PWREL || mode == TZ_MODE_REL) && b0 < 0.0)
+        return tz_fail(ctx, TZ_ERR_INVALID, "%s bound must be >= 0 (the reference raises on a negative one)", mode == TZ_MODE_REL ? "rel" : "pwrel");
+    if (mode == TZ_MODE_ABSREL && b1 < 0.0)
+        return tz_fail(ctx, TZ_ERR_INVALID, "the rel bound of absrel must be >= 0 (the reference raises on a negative one)");
     if (nframes <= 0 || H <= 0 || W <= 0) return TZ_OK;
     return quant_run(ctx, orig, diff, nullptr, h_skip, nframes, H, W, mode, b0, b1);
 }
@@ -1461,8 +1470,11 @@ int tzk_quant_sd_fused(tz_ctx* ctx, const float* pred, const uint8_t* orig, cons
                        int16_t* sym, unsigned long long* d_hist, int16_t* d_edge, bool* done) {
     *done = false;
     if (mode < 0 || mode > 3) return tz_fail(ctx, TZ_ERR_INVALID, "unknown error-bound mode %d", mode);
-    if (mode == TZ_MODE_PWREL && b0 < 0.0)
-        return tz_fail(ctx, TZ_ERR_INVALID, "pwrel bound must be >= 0 (the reference raises on a negative one)");
+    // a negative tolerance makes the reference assign NaN into its int array (compress.py:61 at the first element): it raises
+    if ((mode == TZ_MODE_PWREL || mode == TZ_MODE_REL) && b0 < 0.0)
+        return tz_fail(ctx, TZ_ERR_INVALID, "%s bound must be >= 0 (the reference raises on a negative one)", mode == TZ_MODE_REL ? "rel" : "pwrel");
+    if (mode == TZ_MODE_ABSREL && b1 < 0.0)
+        return tz_fail(ctx, TZ_ERR_INVALID, "the rel bound of absrel must be >= 0 (the reference raises on a negative one)");
     if (H != Hp || W != Wp || ((size_t)H * W) % 8 || nframes <= 0 || (((uintptr_t)sym) & 15)) return TZ_OK;
     QFused fu{pred, d_zero_mask, apply_offset, sym, d_hist, d_edge};
     TZ_TRY(quant_run(ctx, orig, nullptr, &fu, h_skip, nframes, H, W, mode, b0, b1));

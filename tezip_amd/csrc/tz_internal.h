@@ -29,6 +29,7 @@ enum tz_prof_class {
     TZP_CONV_GEN,   // k_conv3x3: general kernel
     TZP_CONVLAT,    // k_convlat: one accumulator tile per wave, for grids that cannot fill the chip
     TZP_TABLE,      // HOST time: rank table + LUT from the downloaded histogram (compress.py:356-361)
+    TZP_QSERIAL,    // not a time: `launches` counts the chains the quantiser sent through its serial fallback (k_q_serial)
     TZP_COUNT
 };
 
