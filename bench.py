@@ -297,6 +297,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip host_to_host / lossy_abs2 / cfg4_sharded / the other mode")
     ap.add_argument("--no-trained-ratio", action="store_true", help="skip training a model for compression_ratio_trained")
+    ap.add_argument("--profile-legs", action="store_true",
+                    help="with --no-extras: still run ONE untimed `abs 2` encode and ONE decode of the job, so that a rocprofv3 "
+                         "trace of this command also holds the lossy-tail and the decoder kernels (profiles/collect.sh)")
     ap.add_argument("--frames", type=int, default=NT,
                     help="frames per GPU (default 80 = the BASELINE.json configuration; other values are "
                          "exploration only and are labelled as such in config.workload)")
@@ -407,12 +410,30 @@ def main():
     c16_ms, c16_n = c16_ms + lat_ms, c16_n + lat_n
     c16_flops = conv16_flops_per_px0(cfg) * H * W * n_pred
     c16_tflops = c16_flops / (c16_ms * 1e-3) / 1e12 if c16_ms > 0 else 0.0
-    delta_ms, delta_n = prof["delta"]
+    # the elementwise delta kernel the north star names (compress.py:292-314).  Since round 3 the STEP forms its deltas inside
+    # the fused kernels (k_q_tiles reads pred / orig directly; lossless: k_delta_sd_fused), so the stand-alone kernel is
+    # measured through its own C-ABI entry point (tz_delta_encode) on the step's own prediction stack, device resident
+    pred_dev = torch.empty(frames.shape[0] * H * W * 3, dtype=torch.float32, device=dev)
+    delta_dev = torch.empty(frames.shape[0] * H * W * 3, dtype=torch.int16, device=dev)
+    ctx.get_predictions(out=pred_dev)
+    ctx.synchronize()
+    ctx.delta_encode(pred_dev, frames, own_state["key"].astype(np.uint8), out=delta_dev)   # warm
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    for _ in range(5):
+        ctx.delta_encode(pred_dev, frames, own_state["key"].astype(np.uint8), out=delta_dev)
+    delta_ms, delta_n = ctx.prof_get()["delta"]
+    ctx.prof_enable(False)
+    del pred_dev, delta_dev
     delta_bytes = 7.0 * frames.shape[0] * H * W * 3  # f32 pred + u8 orig in, i16 out
-    delta_gbs = delta_bytes / (delta_ms * 1e-3) / 1e9 if delta_ms > 0 else 0.0
+    delta_gbs = delta_bytes * delta_n / (delta_ms * 1e-3) / 1e9 if delta_ms > 0 else 0.0
 
     extras = {}
     ratio = None
+    if args.no_extras and args.profile_legs and world == 1:
+        own_step("abs", [2.0])
+        own_step()
+        decode_leg(job, ctx, frames, own_state, argparse.Namespace(steps=1))
     if not args.no_extras:
         # ------------------------------------------------------------ host -> host (SURVEY.md §8d wall-clock definition)
         if world == 1:
@@ -567,7 +588,8 @@ def main():
                                           "unit": "TFLOP/s", "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS,
                                           "traffic": measured_traffic("k_conv"), "launches_per_step": conv_n,
                                           "ms_per_step": conv_ms, "algorithmic_flops_per_step": flops_step},
-            "roofline_delta": {"kernel": "k_delta_flat", "bound": "hbm", "achieved": delta_gbs, "peak": PEAK_HBM_GBS,
+            "roofline_delta": {"kernel": "k_delta_flat (stand-alone tz_delta_encode on the step's prediction stack; the step itself forms "
+                                         "its deltas inside the fused quantiser / spatial-delta kernels)", "bound": "hbm", "achieved": delta_gbs, "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": delta_gbs / PEAK_HBM_GBS, "traffic": measured_traffic("k_delta_flat"),
                                "bytes_per_launch": delta_bytes, "ms_per_launch": delta_ms / max(delta_n, 1)},
             "kernel_ms_per_step": {k: v[0] for k, v in prof.items()},

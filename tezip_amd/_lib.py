@@ -359,10 +359,14 @@ class Context:
         self._shape = (nt, h, w)
         return key.astype(bool)
 
-    def get_predictions(self):
+    def get_predictions(self, out=None):
+        """out: a host or device buffer of nt*Hp*Wp*3 float32 (default: a new numpy array)."""
         nt, h, w = self._shape
-        out = np.empty((nt, pad8(h), pad8(w), 3), np.float32)
-        self._ck(self.lib.tz_get_predictions(self.h, out.ctypes.data))
+        if out is None:
+            out = np.empty((nt, pad8(h), pad8(w), 3), np.float32)
+        elif _numel(out) != nt * pad8(h) * pad8(w) * 3:
+            raise ValueError("prediction buffer holds %d elements, expected %d" % (_numel(out), nt * pad8(h) * pad8(w) * 3))
+        self._ck(self.lib.tz_get_predictions(self.h, _ptr(out)))
         return out
 
     def byte_shuffle(self, x, out=None):

@@ -115,18 +115,19 @@ __device__ __forceinline__ void hist_clear(HistLds& h) {
     __syncthreads();
 }
 
-// Eight symbols of one lane, packed two per dword.  The update is ONE unconditional LDS atomic per
+// 2 NDW symbols of one lane, packed two per dword.  The update is ONE unconditional LDS atomic per
 // element in straight-line code (a branch per element cost more than the atomics it saved: the
 // spatial-delta kernel is as much VALU-issue as HBM bound): the centre symbol goes to the lane's own
 // sink word (it is counted by the ballot), symbols within +-64 of the centre to [bin][copy], anything
 // farther to the junk bin of the copy -- and, in a branch the wave takes only when one of its 512
 // symbols is that far out, to the full-range bins.
-__device__ __forceinline__ void hist_add8(HistLds& h, HistAcc& acc, const unsigned* Y, int c) {
+template <int NDW>
+__device__ __forceinline__ void hist_add(HistLds& h, HistAcc& acc, const unsigned* Y, int c) {
     const int lane = threadIdx.x & 63;
     const int base = HL_CENTRAL + (lane & 7), sink = HL_SINK + lane;
     unsigned far = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 2 * NDW; ++k) {
         const int y = (k & 1) ? ((int)Y[k >> 1] >> 16) : (int)(short)(Y[k >> 1] & 0xFFFFu);
         const bool hot = y == c;
         acc.n0 += (unsigned)__popcll(__ballot(hot));
@@ -137,12 +138,13 @@ __device__ __forceinline__ void hist_add8(HistLds& h, HistAcc& acc, const unsign
     }
     if (__any(far != 0)) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 2 * NDW; ++k) {
             const int y = (k & 1) ? ((int)Y[k >> 1] >> 16) : (int)(short)(Y[k >> 1] & 0xFFFFu);
             if ((unsigned)(y - (c - HC_HALF)) >= (unsigned)HC_BINS && (unsigned)y < (unsigned)TZ_NBINS) atomicAdd(&h.w[HL_FULL + y], 1u);
         }
     }
 }
+__device__ __forceinline__ void hist_add8(HistLds& h, HistAcc& acc, const unsigned* Y, int c) { hist_add<4>(h, acc, Y, c); }
 static_assert(HC_BINS == 128, "hist_add8 takes the far flag from bit 7 of the clamped index");
 
 // every thread of the block calls this (after its last add)
@@ -1086,7 +1088,7 @@ __global__ __launch_bounds__(64) void k_q_serial(QSrc src, const uint8_t* __rest
     if (lane == 0) t[(size_t)chead * 3 + c] = (int16_t)(long long)((u + l) / 2);
 }
 
-static constexpr int QFB = 2048;  // pixels per fill item (32 chunks of 64: a lane per mask word when a wave looks back)
+static constexpr int QFB = QT_TILE;  // pixels per fill item = one tile of k_q_tiles (64 chunks of 64: a lane per mask word)
 
 // value of the last run head in each fill item (from the masks: one thread per (frame, item, channel))
 __global__ __launch_bounds__(256) void k_q_last(const int16_t* __restrict__ tmp, const unsigned long long* __restrict__ spec,
@@ -1330,6 +1332,139 @@ __global__ __launch_bounds__(QF_THREADS) void k_q_fill(const QFill a) {
     if (HIST) hist_flush(hl, acc, centre, a.hist);
 }
 
+// Fused encode: forward fill + spatial delta + 1600 offset + histogram, tile by tile (the tiles of k_q_tiles), by
+// resident blocks of three waves.  The values of a tile come in the way k_q_tiles left them -- 24 bytes per thread,
+// dealt to three channel planes in LDS, row r = chunk r --; lane j of the channel's wave fills row j from its mask
+// word (the value in front of the row comes from the nearest lane above that holds a head, else from the tile's carry);
+// then the block walks the tile in memory order again, 4 pixels = 12 consecutive samples per thread: spatial delta in
+// packed int16 arithmetic (the sample in front of a group is channel 2 of the pixel before it: LDS, or the tile's /
+// frame's carry), symbols out in 24 bytes, histogram.  Frames the quantiser skips take their deltas from pred / orig
+// (compress.py:292-314; 0 where zero_mask says so).  About 40 vector instructions per 12 symbols; the first version of
+// the fused fill (a wave per 64-pixel chunk gathering run values from global memory, k_q_fill<true>) spent 300 per
+// 192 and was bound by them: 193 us at cfg3.
+template <bool HIST>
+__global__ __launch_bounds__(192) void k_q_fill_sym(const QFill a) {
+    __shared__ int planes[3 * 64 * QT_S16 / 2];
+    __shared__ unsigned hraw[HIST ? HL_WORDS : 1];
+    HistLds& hl = *(HistLds*)hraw;
+    HistAcc acc;
+    const int centre = a.apply_offset ? TZ_OFFSET : 0;
+    if (HIST) hist_clear(hl);
+    const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int HW = a.HW, nch = a.nch, ntiles = a.nblk;
+    short* ls = (short*)planes + c * 64 * QT_S16;
+    auto raw = [&](size_t e) { return (int)(a.pred[e] * 255.0f) - (int)a.orig[e]; };
+    for (int item = blockIdx.x; item < a.nframes * ntiles; item += gridDim.x) {
+        const int f = item / ntiles, T = item % ntiles;
+        const bool skipped = a.skip[f] != 0, zero = skipped && a.zero[f] != 0;
+        const size_t fe0 = (size_t)f * HW * 3;
+        const int e0 = T * QT_TILE, npix = min(QT_TILE, HW - e0);
+        __syncthreads();   // the previous item's readers of the planes are done
+        // ---- A. the tile's values (or raw deltas) into the channel planes
+        for (int g = threadIdx.x; g < QT_TILE / 4; g += 192) {
+            const int p0 = g * 4;
+            unsigned v[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) v[k] = 0;
+            if (p0 < npix && !zero) {
+                const size_t e = fe0 + (size_t)(e0 + p0) * 3;
+                if (skipped) {
+                    const uint3 ob = *(const uint3*)(a.orig + e);
+                    const unsigned ow[3] = {ob.x, ob.y, ob.z};
+                    const float4* pp = (const float4*)(a.pred + e);
+                    const float4 f0 = pp[0], f1 = pp[1], f2 = pp[2];
+                    const float fv[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) v[k] = (unsigned)((int)(fv[k] * 255.0f) - (int)((ow[k >> 2] >> (8 * (k & 3))) & 0xFFu)) & 0xFFFFu;
+                } else {
+                    const uint2* dp = (const uint2*)(a.tmp + e);
+                    const uint2 a0 = dp[0], a1 = dp[1], a2 = dp[2];
+                    const unsigned dw[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) v[k] = (dw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                }
+            }
+            const int row = p0 >> 6, col = p0 & 63;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                unsigned* w = (unsigned*)((short*)planes + cc * 64 * QT_S16 + row * QT_S16 + col);
+                w[0] = v[cc] | (v[3 + cc] << 16);
+                w[1] = v[6 + cc] | (v[9 + cc] << 16);
+            }
+        }
+        __syncthreads();
+        // ---- B. forward fill of my row
+        const int cv = skipped ? 0 : (int)a.carry[((size_t)f * ntiles + T) * 3 + c];   // value of the last head in front of the tile
+        if (!skipped) {
+            const int chunk = T * QT_CHUNKS + lane;
+            const unsigned long long M = chunk < nch ? a.spec[(size_t)(f * 3 + c) * nch + chunk] : 0ull;
+            const int lastv = M ? (int)ls[lane * QT_S16 + 63 - __clzll((long long)M)] : 0;
+            const unsigned long long has = __ballot(M != 0ull), below = has & ((1ull << lane) - 1ull);
+            const int got = __shfl(lastv, below ? 63 - __clzll((long long)below) : lane, 64);
+            int cur = below ? got : cv;
+            __builtin_amdgcn_wave_barrier();   // every lane has read its lastv before any row is rewritten
+            const int len = max(0, min(64, npix - lane * 64));
+            for (int tt = 0; tt < len; ++tt) {
+                const int x = (int)ls[lane * QT_S16 + tt];
+                cur = ((M >> tt) & 1ull) ? x : cur;
+                ls[lane * QT_S16 + tt] = (short)cur;
+            }
+        }
+        __syncthreads();
+        // ---- C. memory order again: spatial delta, offset, histogram, symbols
+        // the sample in front of the tile's first one
+        int tprev = 0;
+        bool tfirst = false;   // start of the stream: sd[0] = x[0]
+        if (T > 0) {
+            tprev = skipped ? (zero ? 0 : raw(fe0 + (size_t)e0 * 3 - 1)) : (int)a.carry[((size_t)f * ntiles + T) * 3 + 2];
+        } else if (f > 0) {
+            if (a.skip[f - 1]) tprev = a.zero[f - 1] ? 0 : raw(fe0 - 1);
+            else tprev = (int)a.ftail[(f - 1) * 3 + 2];
+        } else {
+            tfirst = true;
+        }
+        for (int g = threadIdx.x; g < QT_TILE / 4; g += 192) {
+            const int p0 = g * 4;
+            if (p0 >= npix) continue;
+            const int row = p0 >> 6, col = p0 & 63;
+            unsigned r[12];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const unsigned* w = (const unsigned*)((const short*)planes + cc * 64 * QT_S16 + row * QT_S16 + col);
+                const unsigned w0 = w[0], w1 = w[1];
+                r[cc] = w0 & 0xFFFFu;
+                r[3 + cc] = w0 >> 16;
+                r[6 + cc] = w1 & 0xFFFFu;
+                r[9 + cc] = w1 >> 16;
+            }
+            unsigned V[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) V[k] = r[2 * k] | (r[2 * k + 1] << 16);
+            unsigned prev16;
+            if (p0 > 0) prev16 = (unsigned)(unsigned short)((const short*)planes)[2 * 64 * QT_S16 + ((p0 - 1) >> 6) * QT_S16 + ((p0 - 1) & 63)];
+            else prev16 = tfirst ? ((V[0] << 1) & 0xFFFFu) : ((unsigned)tprev & 0xFFFFu);   // sd[0] = x[0] as "prev = 2 x[0]"
+            unsigned Y[6];
+            unsigned hi = prev16 << 16;
+            const unsigned C2 = ((unsigned)TZ_OFFSET << 16) | (unsigned)TZ_OFFSET;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const unsigned P = __builtin_amdgcn_alignbit(V[k], hi, 16);
+                hi = V[k];
+                Y[k] = pk_sub(P, V[k]);
+                if (a.apply_offset) Y[k] = pk_sub(C2, Y[k]);
+            }
+            uint2* dst = (uint2*)(a.out + fe0 + (size_t)(e0 + p0) * 3);
+            dst[0] = make_uint2(Y[0], Y[1]);
+            dst[1] = make_uint2(Y[2], Y[3]);
+            dst[2] = make_uint2(Y[4], Y[5]);
+            if (HIST) hist_add<6>(hl, acc, Y, centre);
+            if (f == 0 && T == 0 && p0 == 0) a.edge[0] = (int16_t)(short)r[0];
+            if (f == a.nframes - 1 && e0 + p0 + 4 == HW) a.edge[1] = (int16_t)(short)r[11];
+        }
+    }
+    if (HIST) hist_flush(hl, acc, centre, a.hist);
+}
+
 struct QFused {   // fused encode: symbols + histogram + edge elements instead of a delta stack
     const float* pred;
     const uint8_t* d_zero;
@@ -1443,8 +1578,9 @@ static int quant_run(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const QFus
         a.hist = fu->d_hist;
         a.edge = fu->d_edge;
         a.apply_offset = fu->apply_offset;
-        if (fu->d_hist) hipLaunchKernelGGL((k_q_fill<true, true>), dim3(grid), dim3(QF_THREADS), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_q_fill<true, false>), dim3(grid), dim3(QF_THREADS), 0, ctx->stream, a);
+        const int gsym = std::min(4 * kCUs, nframes * nblk);
+        if (fu->d_hist) hipLaunchKernelGGL(k_q_fill_sym<true>, dim3(gsym), dim3(192), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_q_fill_sym<false>, dim3(gsym), dim3(192), 0, ctx->stream, a);
     }
     TZ_HIP(ctx, hipGetLastError());
     return TZ_OK;
