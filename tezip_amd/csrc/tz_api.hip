@@ -452,12 +452,23 @@ extern "C" int tz_timer_stop(tz_ctx* ctx, float* ms) {
 // ------------------------------------------------------------------------------ rollout
 static int pad8(int v) { return (v + 7) / 8 * 8; }  // data_utils.py:103-107
 
+// decompress.py:123-129: is there a non-zero sample in frame f?  16 bytes per lane where the frame allows it.
 __global__ void k_any_nonzero(const uint8_t* __restrict__ frames, size_t frame_bytes, int* __restrict__ flags) {
     int f = blockIdx.y;
     const uint8_t* p = frames + (size_t)f * frame_bytes;
     int any = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < frame_bytes; i += (size_t)gridDim.x * blockDim.x)
-        any |= p[i] != 0;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)p) & 15) == 0) {
+        const uint4* q = (const uint4*)p;
+        const size_t n16 = frame_bytes / 16;
+        for (size_t i = tid; i < n16; i += nthr) {
+            const uint4 v = q[i];
+            any |= (v.x | v.y | v.z | v.w) != 0;
+        }
+        for (size_t i = n16 * 16 + tid; i < frame_bytes; i += nthr) any |= p[i] != 0;
+    } else {
+        for (size_t i = tid; i < frame_bytes; i += nthr) any |= p[i] != 0;
+    }
     if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&flags[f], 1);
 }
 

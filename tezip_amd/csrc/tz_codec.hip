@@ -1135,18 +1135,12 @@ __global__ __launch_bounds__(64) void k_q_carry(int16_t* __restrict__ carry, con
     if (lane == 0) ftail[id] = (int16_t)run;
 }
 
-// Forward fill of the run values, one wave per 64-element chunk, no communication between waves: the masks
-// say where the run heads are, so a lane finds the head of ITS run with bit operations (highest mask bit at or
-// below its lane; else the highest bit of the nearest non-empty mask word in front of the chunk within its
-// item of 2048 pixels; else the item's carry value from k_q_last / k_q_carry) and fetches the value there --
-// rounds 1-2 propagated the values themselves with 18 shuffles and two barriers per 256 pixels.
-//  SYM == false: the filled values go back into the delta stack (frames flagged in `skip` are not touched).
-//  SYM == true : fused encode.  Every frame is processed: a skipped frame's deltas are trunc(pred*255) - orig
-//                (0 where zero_mask says so: compress.py:314); the values go on through the spatial delta over
-//                the whole flattened stack (compress.py:73-77: the element in front of a pixel's first channel
-//                is the previous pixel's last channel, across chunk, item and frame boundaries), the 1600 offset
-//                and the histogram (compress.py:346-355), and leave as symbols in 16-byte stores (a wave's 192
-//                symbols pass through 384 bytes of its own LDS).
+// Forward fill of the run values back into a DELTA STACK (stand-alone tz_error_bound, delta tap of tz_encode; frames
+// flagged in `skip` are not touched), one wave per 64-element chunk, no communication between waves: the masks say where
+// the run heads are, so a lane finds the head of ITS run with bit operations (highest mask bit at or below its lane;
+// else the highest bit of the nearest non-empty mask word in front of the chunk within its tile; else the tile's carry
+// value from k_q_last / k_q_carry) and fetches the value there -- rounds 1-2 propagated the values themselves with 18
+// shuffles and two barriers per 256 pixels.  (The fused encode uses k_q_fill_sym below.)
 struct QFill {
     const int16_t* tmp;
     const unsigned long long* spec;
@@ -1179,136 +1173,16 @@ __device__ __forceinline__ QFillPre q_fill_pre(const QFill& a, int f, int ch, in
     for (int c = 0; c < 3; ++c) {   // (a skipped frame's entries are never written: loaded all the same, not used)
         const unsigned long long* sp = a.spec + (size_t)(f * 3 + c) * nch;
         const int wi = w0 + lane;
-        r.mw[c] = (lane < QFB / 64 && wi < ch) ? sp[wi] : 0ull;   // the item's mask words in front of the chunk, one per lane
+        r.mw[c] = (lane < QFB / 64 && wi < ch) ? sp[wi] : 0ull;   // the tile's mask words in front of the chunk, one per lane
         r.m[c] = sp[ch];
-        r.cv[c] = (int)a.carry[((size_t)f * a.nblk + b) * 3 + c];  // value of the last head in front of the item
+        r.cv[c] = (int)a.carry[((size_t)f * a.nblk + b) * 3 + c];  // value of the last head in front of the tile
     }
     return r;
 }
 
-// first half of a work item: where the run values are, and the loads that fetch them (issued, not yet used)
-struct QFillMid {
-    int hp[3], before2;
-    int16_t tv[3], tp;
-    int res[3], prev2;   // a skipped frame's raw deltas (fused encode)
-    bool skipped, valid;
-};
-
-template <bool SYM>
-__device__ __forceinline__ QFillMid q_fill_a(const QFill& a, const QFillPre& cur, int f, int ch, int lane, bool valid) {
-    QFillMid m{};
-    m.valid = valid;
-    m.skipped = cur.skipped != 0;
-    if (!valid || (!SYM && m.skipped)) return m;
-    const int HW = a.HW;
-    const size_t fe0 = (size_t)f * HW * 3;
-    const int16_t* t = a.tmp + fe0;
-    const int p = ch * 64 + lane;
-    const int w0 = ((ch * 64) / QFB) * (QFB / 64);  // first mask word of the item this chunk belongs to
-    if (SYM && m.skipped) {
-        const bool zero = a.zero[f] != 0, live = p < HW;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) m.res[c] = (live && !zero) ? (int)(a.pred[fe0 + (size_t)p * 3 + c] * 255.0f) - (int)a.orig[fe0 + (size_t)p * 3 + c] : 0;
-        if (ch > 0) m.prev2 = zero ? 0 : (int)(a.pred[fe0 + (size_t)ch * 192 - 1] * 255.0f) - (int)a.orig[fe0 + (size_t)ch * 192 - 1];
-        return m;
-    }
-    m.before2 = -1;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const unsigned long long mw = cur.mw[c];
-        const unsigned long long nz = __ballot(mw != 0ull);
-        // position of the last head in front of the chunk (within the item), or -1
-        int before = -1;
-        if (nz) {
-            const int wl = 63 - __clzll((long long)nz);
-            const unsigned long long mm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mw >> 32), wl) << 32) |
-                                          (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mw, wl);
-            before = (w0 + wl) * 64 + 63 - __clzll((long long)mm);
-        }
-        const unsigned long long mine = cur.m[c] & ((2ull << lane) - 1ull);
-        m.hp[c] = mine ? ch * 64 + 63 - __clzll((long long)mine) : before;
-        if (c == 2) m.before2 = before;
-    }
-    // the gathers of the three channels (and of the pixel in front) go out together
-#pragma unroll
-    for (int c = 0; c < 3; ++c) m.tv[c] = m.hp[c] >= 0 ? t[(size_t)m.hp[c] * 3 + c] : (int16_t)0;
-    m.tp = (SYM && m.before2 >= 0) ? t[(size_t)m.before2 * 3 + 2] : (int16_t)0;
-    return m;
-}
-
-template <bool SYM, bool HIST>
-__device__ __forceinline__ void q_fill_b(const QFill& a, const QFillPre& cur, const QFillMid& m, int f, int ch, int lane, int wv,
-                                         uint4* stage, HistLds& hl, HistAcc& acc, int centre) {
-    if (!m.valid || (!SYM && m.skipped)) return;
-    const int HW = a.HW;
-    const size_t fe0 = (size_t)f * HW * 3;
-    const int p = ch * 64 + lane;
-    int res[3], prev2;
-    if (SYM && m.skipped) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) res[c] = m.res[c];
-        prev2 = m.prev2;
-    } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) res[c] = m.hp[c] >= 0 ? (int)m.tv[c] : cur.cv[c];
-        prev2 = m.before2 >= 0 ? (int)m.tp : cur.cv[2];
-    }
-    if (!SYM) {
-        if (p < HW)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) a.out[fe0 + (size_t)p * 3 + c] = (int16_t)res[c];
-        return;
-    }
-    // the element in front of the chunk's first sample when the chunk starts a frame
-    bool have_prev = true;
-    if (ch == 0) {
-        if (f == 0) have_prev = false;              // start of the stream: sd[0] = x[0]
-        else if (a.skip[f - 1]) prev2 = a.zero[f - 1] ? 0 : (int)(a.pred[fe0 - 1] * 255.0f) - (int)a.orig[fe0 - 1];
-        else prev2 = (int)a.ftail[(f - 1) * 3 + 2];
-    }
-    int prev = __shfl_up(res[2], 1);
-    if (lane == 0) prev = prev2;
-    int sd0 = prev - res[0];
-    if (!have_prev && lane == 0) sd0 = res[0];
-    const int sd1 = res[0] - res[1], sd2 = res[1] - res[2];
-    const short y0 = a.apply_offset ? (short)(TZ_OFFSET - sd0) : (short)sd0;
-    const short y1 = a.apply_offset ? (short)(TZ_OFFSET - sd1) : (short)sd1;
-    const short y2 = a.apply_offset ? (short)(TZ_OFFSET - sd2) : (short)sd2;
-    if (f == 0 && p == 0) a.edge[0] = (int16_t)res[0];
-    if (f == a.nframes - 1 && p == HW - 1) a.edge[1] = (int16_t)res[2];
-    short* so = (short*)(stage + wv * 24);
-    so[lane * 3 + 0] = y0;
-    so[lane * 3 + 1] = y1;
-    so[lane * 3 + 2] = y2;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int npix = min(64, HW - ch * 64);           // HW % 8 == 0: whole 16-byte vectors
-    if (lane < npix * 3 / 8) {
-        const uint4 y = stage[wv * 24 + lane];
-        ((uint4*)(a.out + fe0 + (size_t)ch * 192))[lane] = y;
-        if (HIST) {
-            const unsigned Y[4] = {y.x, y.y, y.z, y.w};
-            hist_add8(hl, acc, Y, centre);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// The mask / carry words of a wave's NEXT work item are loaded one iteration ahead.  (The kernel is bound by the
-// vector instructions a 64-pixel item costs, about 300 for its 192 symbols, not by memory: two items in flight per
-// wave made it slower, 172 -> 211 us at cfg3.)
-template <bool SYM, bool HIST>
 __global__ __launch_bounds__(QF_THREADS) void k_q_fill(const QFill a) {
-    __shared__ unsigned hraw[HIST ? HL_WORDS : 1];
-    __shared__ uint4 stage[SYM ? QF_WAVES * 24 : 1];   // 64 pixels x 3 symbols x 2 bytes per wave
-    HistLds& hl = *(HistLds*)hraw;
-    HistAcc acc;
-    const int centre = a.apply_offset ? TZ_OFFSET : 0;
-    if (HIST) hist_clear(hl);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nch = a.nch;
+    const int HW = a.HW, nch = a.nch;
     // work item = (frame, chunk of 64 pixels, all three channels); a wave takes every (gridDim * waves)-th of them,
     // (f, ch) advanced without divisions
     const int wstride = (int)gridDim.x * QF_WAVES, df = wstride / nch, dch = wstride % nch;
@@ -1326,10 +1200,33 @@ __global__ __launch_bounds__(QF_THREADS) void k_q_fill(const QFill a) {
             ++f;
         }
         if (f < a.nframes) nxt = q_fill_pre(a, f, ch, lane);
-        const QFillMid m = q_fill_a<SYM>(a, cur, fc, chc, lane, true);
-        q_fill_b<SYM, HIST>(a, cur, m, fc, chc, lane, wv, stage, hl, acc, centre);
+        if (cur.skipped) continue;
+        const size_t fe0 = (size_t)fc * HW * 3;
+        const int16_t* t = a.tmp + fe0;
+        const int p = chc * 64 + lane;
+        const int w0 = ((chc * 64) / QFB) * (QFB / 64);   // first mask word of the tile this chunk belongs to
+        int hp[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned long long mw = cur.mw[c];
+            const unsigned long long nz = __ballot(mw != 0ull);
+            int before = -1;   // position of the last head in front of the chunk (within the tile), or -1
+            if (nz) {
+                const int wl = 63 - __clzll((long long)nz);
+                const unsigned long long mm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mw >> 32), wl) << 32) |
+                                              (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mw, wl);
+                before = (w0 + wl) * 64 + 63 - __clzll((long long)mm);
+            }
+            const unsigned long long mine = cur.m[c] & ((2ull << lane) - 1ull);
+            hp[c] = mine ? chc * 64 + 63 - __clzll((long long)mine) : before;
+        }
+        int16_t tv[3];   // the gathers of the three channels go out together
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tv[c] = hp[c] >= 0 ? t[(size_t)hp[c] * 3 + c] : (int16_t)0;
+        if (p < HW)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.out[fe0 + (size_t)p * 3 + c] = hp[c] >= 0 ? tv[c] : (int16_t)cur.cv[c];
     }
-    if (HIST) hist_flush(hl, acc, centre, a.hist);
 }
 
 // Fused encode: forward fill + spatial delta + 1600 offset + histogram, tile by tile (the tiles of k_q_tiles), by
@@ -1568,7 +1465,7 @@ static int quant_run(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const QFus
     if (!fu) {
         tz_prof_scope ps(ctx, TZP_QUANT);
         a.out = diff;
-        hipLaunchKernelGGL((k_q_fill<false, false>), dim3(grid), dim3(QF_THREADS), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_q_fill, dim3(grid), dim3(QF_THREADS), 0, ctx->stream, a);
     } else {
         tz_prof_scope ps(ctx, TZP_SDELTA);
         a.zero = fu->d_zero;
