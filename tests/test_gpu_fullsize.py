@@ -267,6 +267,9 @@ def test_the_hot_launches_run_on_the_kernels_the_design_names(ctx):
     p = ctx.prof_get()
     assert p["conv16_lds_dma"][1] == 95 and p["conv16b_level0"][1] == 38 and p["conv_small_valu"][1] == 19
     assert p["conv3x3_general"][1] == 0 and p["convlat_small_grid"][1] == 0
+    # the level-0 error unit is launched for the step that starts from the key frames only: every later step finds its
+    # error maps written by the prediction kernel of the step before (round 3)
+    assert p["err0"][1] == 1
     small = synth.moving_blobs(40, 64, 64)
     ctx.prepare(64, 64, max_batch=2)
     ctx.rollout(small, 0, 20)

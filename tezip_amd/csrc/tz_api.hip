@@ -680,12 +680,17 @@ static int run_schedule(tz_ctx* ctx, std::vector<PredItem>& items) {
             chain_of[items[i].out] = g;
         }
     }
-    // per group: batches of one depth, [is_key | in | out] x maxB ints each
+    // per group: batches of one depth, [is_key | in | out | next slot] x maxB ints each.  next slot: where the item's
+    // prediction sits in the NEXT batch of its group when that batch holds its consumer (the next step of the window);
+    // the prediction kernel then writes the consumer's level-0 error maps itself, and a batch all of whose items were
+    // served that way runs without its k_err0 launch (18 of the 19 steps of a cfg3 rollout).
     std::vector<int> table;
     std::vector<int> counts[2];
     std::vector<size_t> offs[2];
+    std::vector<char> all_fed[2];   // per batch: every item's E_0 slot comes from the batch in front
     for (int g = 0; g < (split ? 2 : 1); ++g) {
         const int cap = g == 0 ? capA : capB;
+        std::vector<std::vector<size_t>> batches;
         size_t i = 0;
         while (i < items.size()) {
             const int depth = items[i].depth;
@@ -694,19 +699,38 @@ static int run_schedule(tz_ctx* ctx, std::vector<PredItem>& items) {
             std::vector<size_t> mine;
             for (size_t k = i; k < j; ++k)
                 if (group[k] == g) mine.push_back(k);
-            for (size_t q = 0; q < mine.size(); q += cap) {
-                const size_t nb = std::min<size_t>(cap, mine.size() - q), base = table.size();
-                table.resize(base + 3 * (size_t)maxB, 0);
-                for (size_t k = 0; k < nb; ++k) {
-                    const PredItem& it = items[mine[q + k]];
-                    table[base + k] = it.from_key;
-                    table[base + maxB + k] = it.in;
-                    table[base + 2 * maxB + k] = it.out;
-                }
-                counts[g].push_back((int)nb);
-                offs[g].push_back(base);
-            }
+            for (size_t q = 0; q < mine.size(); q += cap)
+                batches.emplace_back(mine.begin() + q, mine.begin() + std::min(mine.size(), q + (size_t)cap));
             i = j;
+        }
+        for (size_t b = 0; b < batches.size(); ++b) {
+            const size_t nb = batches[b].size(), base = table.size();
+            table.resize(base + 4 * (size_t)maxB, 0);
+            for (size_t k = 0; k < nb; ++k) {
+                const PredItem& it = items[batches[b][k]];
+                table[base + k] = it.from_key;
+                table[base + maxB + k] = it.in;
+                table[base + 2 * maxB + k] = it.out;
+                int next = -1;
+                if (b + 1 < batches.size())
+                    for (size_t k2 = 0; k2 < batches[b + 1].size(); ++k2) {
+                        const PredItem& c = items[batches[b + 1][k2]];
+                        if (!c.from_key && c.in == it.out) next = (int)k2;
+                    }
+                table[base + 3 * maxB + k] = next;
+            }
+            bool fed = b > 0;
+            if (b > 0)
+                for (size_t k = 0; k < nb && fed; ++k) {
+                    const PredItem& c = items[batches[b][k]];
+                    bool found = false;
+                    for (size_t k0 = 0; k0 < batches[b - 1].size() && !found; ++k0)
+                        found = !c.from_key && items[batches[b - 1][k0]].out == c.in;
+                    fed = found;
+                }
+            counts[g].push_back((int)nb);
+            offs[g].push_back(base);
+            all_fed[g].push_back(fed ? 1 : 0);
         }
     }
     TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_sched, &ctx->cap_sched, table.size() * sizeof(int)));
@@ -719,14 +743,17 @@ static int run_schedule(tz_ctx* ctx, std::vector<PredItem>& items) {
     hipStream_t main_stream = ctx->stream;
     int rc = TZ_OK;
     const size_t steps = std::max(counts[0].size(), counts[1].size());
+    bool fused[2] = {false, false};   // did the previous batch of the group write the next one's error maps?
     for (size_t b = 0; b < steps && rc == TZ_OK; ++b) {
-        if (b < counts[0].size())
-            rc = tz_model_predict_batch_dev(ctx, counts[0][b], ctx->d_sched + offs[0][b], maxB, ctx->d_frames, ctx->H, ctx->W,
-                                            ctx->d_pred, ctx->d_pred, 0);
-        if (rc == TZ_OK && b < counts[1].size()) {
-            ctx->stream = ctx->stream2;   // the launchers take the context's stream
-            rc = tz_model_predict_batch_dev(ctx, counts[1][b], ctx->d_sched + offs[1][b], maxB, ctx->d_frames, ctx->H, ctx->W,
-                                            ctx->d_pred, ctx->d_pred, capA);
+        for (int g = 0; g < 2 && rc == TZ_OK; ++g) {
+            if (b >= counts[g].size()) continue;
+            const int slot0 = g == 0 ? 0 : capA;
+            const int* tab = ctx->d_sched + offs[g][b];
+            // the slot numbers of the table are positions in the batch: the activation slots of a group start at slot0
+            const bool skip = fused[g] && all_fed[g][b];
+            if (g == 1) ctx->stream = ctx->stream2;   // the launchers take the context's stream
+            rc = tz_model_predict_batch_dev(ctx, counts[g][b], tab, maxB, ctx->d_frames, ctx->H, ctx->W, ctx->d_pred, ctx->d_pred, slot0,
+                                            tab + 3 * (size_t)maxB, skip, &fused[g]);
             ctx->stream = main_stream;
         }
     }

@@ -57,6 +57,13 @@ struct ConvArgs {
     const int* out_idx; // optional: frame slot of batch item n in out0
     int clip1;          // EPI_RELU: min(.,1)  (prednet.py:270)
     int R;              // EPI_LSTM_PACKED: channels per gate
+    // k_conv_small: the prediction is also the input of the NEXT predictor step of its window, whose first act is the
+    // level-0 error unit e_0 = [relu(Ahat0(t0) - x), relu(x - Ahat0(t0))] (k_err0).  With e0_out set the epilogue writes
+    // that too -- into slot e0_slot[n] of the level-0 error maps (8 floats per pixel), unless the slot is negative.
+    float* e0_out;
+    const float* e0_ahat;   // Ahat_0 at t0 [H*W][3]
+    const int* e0_slot;
+    long long e0_nstride;
 };
 
 static constexpr int SA = 18;    // LDS row stride of one patch pixel (16 channels + 2 pad floats)
@@ -1488,12 +1495,29 @@ __global__ __launch_bounds__(256) void k_conv_small(const ConvArgs a) {
     }
     const int y = ty0 + py, xq = tx0 + px;
     if (y < a.H && xq < a.W) {
-        float* o = a.out0 + (long long)(a.out_idx ? a.out_idx[n] : n) * a.out0_nstride + ((long long)y * a.W + xq) * COUT;
+        const long long pix = (long long)y * a.W + xq;
+        float* o = a.out0 + (long long)(a.out_idx ? a.out_idx[n] : n) * a.out0_nstride + pix * COUT;
+        float v[COUT];
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
-            float v = tz_relu(acc[co]);
-            if (a.clip1 && v > 1.0f) v = 1.0f;
-            o[co] = v;
+            v[co] = tz_relu(acc[co]);
+            if (a.clip1 && v[co] > 1.0f) v[co] = 1.0f;
+            o[co] = v[co];
+        }
+        if (COUT == 3 && a.e0_out) {   // the next step's level-0 error unit, same arithmetic as k_err0
+            const int slot = a.e0_slot[n];
+            if (slot >= 0) {
+                float d1[3], d2[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float h = a.e0_ahat[pix * 3 + c];
+                    d1[c] = h - v[c];
+                    d2[c] = v[c] - h;
+                }
+                float* e = a.e0_out + (long long)slot * a.e0_nstride + pix * 8;
+                *(float4*)e = make_float4(tz_relu(d1[0]), tz_relu(d1[1]), tz_relu(d1[2]), tz_relu(d2[0]));
+                *(float4*)(e + 4) = make_float4(tz_relu(d2[1]), tz_relu(d2[2]), 0.0f, 0.0f);
+            }
         }
     }
 }

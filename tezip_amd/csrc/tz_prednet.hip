@@ -636,7 +636,8 @@ int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int
 // Launch-only form: d_idx holds [is_key | in_idx | out_idx], each `stride` ints apart, already
 // on the device.  Nothing here allocates or copies.
 int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride, const uint8_t* d_frames_u8, int H, int W,
-                               const float* d_in_stack, float* d_out_stack, int slot0) {
+                               const float* d_in_stack, float* d_out_stack, int slot0, const int* d_next_slot, bool skip_err0,
+                               bool* fused_next) {
     tz_model* m = ctx->model;
     if (!m || !m->prepared) return tz_fail(ctx, TZ_ERR_STATE, "model not prepared");
     if (n < 1 || slot0 < 0 || slot0 + n > m->maxB) return tz_fail(ctx, TZ_ERR_INVALID, "batch %d at slot %d outside 1..%d", n, slot0, m->maxB);
@@ -644,7 +645,8 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
     auto hl = [&](int l) { return Hp >> l; };
     auto wl = [&](int l) { return Wp >> l; };
     auto npx = [&](int l) { return (long long)hl(l) * wl(l); };
-    {
+    if (fused_next) *fused_next = false;
+    if (!skip_err0) {   // (skipped when the previous step of every item wrote its E_0 slot from its Ahat_0 epilogue)
         tz_prof_scope ps(ctx, TZP_ERR0);
         int gx = (int)std::min<long long>((npx(0) + 255) / 256, 2048);
         hipLaunchKernelGGL(k_err0, dim3(gx, n), dim3(256), 0, ctx->stream, d_frames_u8, H, W, d_in_stack, d_idx,
@@ -752,6 +754,14 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         a.out0_nstride = npx(0) * m->stack[0];
         a.out_idx = d_idx + 2 * stride;
         a.clip1 = 1;
+        // the prediction feeds the next step of its window: k_conv_small can write that step's level-0 error maps as well
+        if (d_next_slot && ctx->conv_impl && m->stack[0] == 3 && m->rstack[0] == 3 && m->e0s == 8) {
+            a.e0_nstride = npx(0) * m->e0s;
+            a.e0_out = m->E[0] + slot0 * a.e0_nstride;   // (the table's slot numbers are positions in the next batch)
+            a.e0_ahat = m->Ahat0[0];
+            a.e0_slot = d_next_slot;
+            if (fused_next) *fused_next = true;
+        }
         TZ_TRY(launch_conv(ctx, pc.NT, EPI_RELU, a, n));
     }
     return TZ_OK;
