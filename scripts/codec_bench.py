@@ -27,7 +27,7 @@ ap.add_argument("--trained", action="store_true", help="train a model first (tez
 args = ap.parse_args()
 
 dev = torch.device("cuda", 0)
-ctx = _lib.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+ctx = _lib.Context(0)   # own stream: torch.cuda.synchronize() wherever torch and the library hand over buffers
 cfg = PredNetConfig()
 ctx.load_model(cfg, cfg.init_weights(seed=123))
 ctx.prepare(512, 512, 4)

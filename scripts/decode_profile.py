@@ -15,7 +15,7 @@ from tezip_amd import _lib  # noqa: E402
 from tezip_amd.prednet import PredNetConfig  # noqa: E402
 
 dev = torch.device("cuda", 0)
-ctx = _lib.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+ctx = _lib.Context(0)   # own stream: torch.cuda.synchronize() wherever torch and the library hand over buffers
 cfg = PredNetConfig()
 ctx.load_model(cfg, cfg.init_weights(seed=123))
 ctx.prepare(512, 512, 4)

@@ -407,6 +407,47 @@ def test_compress_decompress_matches_oracle(ctx, nt, h, w, p, window, thr, mode,
         np.testing.assert_array_equal(dec, frames)
 
 
+@pytest.mark.parametrize("entropy", [True, False])
+def test_decode_tail_in_one_launch_equals_the_separate_launches(ctx, entropy, monkeypatch):
+    """tz_decode runs inverse remap + inverse spatial delta + reconstruct as ONE launch where the layout allows it
+    (unpadded frames of a multiple of 16 elements); TEZIP_DECODE_UNFUSED=1 keeps the scan and reconstruct launches."""
+    from tezip_amd import _lib
+    cfg = SMALL
+    nt, h, w = 13, 64, 80   # 15360 elements per frame: tiles of 4096 straddle frames and key frames
+    frames = _frames(np.random.default_rng(21), nt, h, w)
+    wts = cfg.init_weights(seed=5, bias_scale=0.2)
+    ctx.load_model(cfg, wts)
+    ctx.prepare(h, w, max_batch=4)
+    key = ctx.rollout(frames, 1, 4, None)[0]
+    payload, table, _ = ctx.encode("abs", [2.0], entropy)
+    key_stack = np.where(key[:, None, None, None] > 0, frames, 0).astype(np.uint8)
+
+    def decode(c):
+        c.rollout_decode(key_stack, 1)
+        c.prof_enable(True)
+        c.prof_reset()
+        out = c.decode(payload, table)
+        prof = c.prof_get()
+        c.prof_enable(False)
+        return out, prof
+
+    one, prof_one = decode(ctx)
+    assert prof_one["undelta_scan"][1] == 1 and prof_one["reconstruct"][1] == 0
+    monkeypatch.setenv("TEZIP_DECODE_UNFUSED", "1")
+    c2 = _lib.Context(0)
+    try:
+        c2.load_model(cfg, wts)
+        c2.prepare(h, w, max_batch=4)
+        two, prof_two = decode(c2)
+    finally:
+        c2.close()
+    assert prof_two["undelta_scan"][1] == 1 and prof_two["reconstruct"][1] == 1
+    np.testing.assert_array_equal(one, two)
+    assert int(np.abs(one.astype(int) - frames.astype(int)).max()) <= 2
+    for _ in range(3):   # the status words of the scan carry the launch's epoch: repeated launches without a clear
+        np.testing.assert_array_equal(decode(ctx)[0], one)
+
+
 def test_rollout_rejects_short_sequences_and_bad_sizes(ctx):
     from tezip_amd._lib import TezipError
     cfg = SMALL

@@ -1,0 +1,57 @@
+"""Results must not depend on what device memory held before: the library's TEZIP_POISON diagnostic fills every device
+buffer it hands out (fresh or recycled) with a byte first.  Each poison value runs in its own process (the switch is read
+once per process) over a lossless and three lossy jobs, SWP and DWP, at a size that uses the LDS-DMA convolution kernels,
+the tile quantiser and the fused encode / decode tails; the digests of everything the jobs return must agree."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+JOB = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from tezip_amd import _lib, synth
+from tezip_amd.prednet import PredNetConfig
+cfg = PredNetConfig()
+ctx = _lib.Context(0)
+ctx.load_model(cfg, cfg.init_weights(seed=11, bias_scale=0.1))
+h = hashlib.sha256()
+for (nt, H, W, p, window, thr, mode, bound) in [(14, 128, 160, 1, 5, None, "abs", [0.0]), (14, 128, 160, 0, 4, None, "abs", [2.0]),
+                                               (12, 64, 80, 0, None, 0.15, "rel", [0.01]), (9, 61, 90, 2, 3, None, "pwrel", [0.1])]:
+    frames = synth.turbulence(nt, H, W, seed=4)
+    ctx.prepare(_lib.pad8(H), _lib.pad8(W), max_batch=4)
+    for rep in range(2):   # the second pass runs on recycled pool blocks
+        key, _ = ctx.rollout(frames, p, window, thr)
+        payload, table, _ = ctx.encode(mode, bound, True)
+        keys = np.where(key[:, None, None, None], frames, 0).astype(np.uint8)
+        ctx.rollout_decode(keys, p)
+        dec = ctx.decode(payload, table)
+        for a in (key, payload, table, dec):
+            h.update(np.ascontiguousarray(a).tobytes())
+        if bound[0] == 0:
+            assert (dec == frames).all()
+print("digest", h.hexdigest())
+'''
+
+
+def _run(poison):
+    env = dict(os.environ)
+    env.pop("TEZIP_POISON", None)
+    if poison is not None:
+        env["TEZIP_POISON"] = str(poison)
+    out = subprocess.run([sys.executable, "-c", JOB % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [ln for ln in out.stdout.splitlines() if ln.startswith("digest")][-1]
+
+
+def test_results_do_not_depend_on_stale_device_memory():
+    ref = _run(None)
+    for poison in (255, 0, 165):
+        assert _run(poison) == ref, "TEZIP_POISON=%d changes the result" % poison

@@ -7,8 +7,10 @@ raise.
 
 Streams: work on device buffers is enqueued on the context's stream and is complete only after
 `Context.synchronize()`.  When torch produces or consumes those buffers either create the
-context on torch's stream (`Context(dev, stream=torch.cuda.current_stream().cuda_stream)`, as
-bench.py does) or synchronise both sides explicitly."""
+context on a torch stream (`s = torch.cuda.Stream(); Context(dev, stream=s.cuda_stream)` and run
+the torch side under `torch.cuda.stream(s)`) or synchronise both sides explicitly (bench.py and
+tezip_amd.dist.HipEngine do the latter).  torch's DEFAULT stream has the handle 0, which the C ABI
+reads as "make your own stream": such a context does not share anything with torch."""
 import ctypes as C
 import os
 import threading
@@ -224,6 +226,8 @@ class Context:
     """One context per GPU/process (tz_ctx)."""
 
     def __init__(self, device=0, stream=None):
+        """stream: a hipStream_t handle as an int (a torch.cuda.Stream's .cuda_stream), or None / 0 for a stream of the
+        context's own (see the module docstring)."""
         self.lib = load()
         h = C.c_void_p()
         rc = self.lib.tz_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))

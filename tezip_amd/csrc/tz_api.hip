@@ -74,6 +74,8 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
     {
         const char* e = getenv("TEZIP_SPLIT");
         if (e) ctx->split_rollout = atoi(e);
+        e = getenv("TEZIP_DECODE_UNFUSED");
+        if (e) ctx->decode_unfused = atoi(e);
         if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -102,6 +104,7 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
     if (ctx->d_sched) (void)hipFree(ctx->d_sched);
     if (ctx->d_payload) (void)hipFree(ctx->d_payload);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->d_scan_status) (void)hipFree(ctx->d_scan_status);
     for (auto& s : ctx->prof)
         for (auto& e : s.pending) {
             (void)hipEventDestroy(e.first);
@@ -271,6 +274,25 @@ int tz_d2h(tz_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s)
 
 static constexpr size_t kPoolUsed = (size_t)1 << 63;  // top bit of the size marks "handed out"
 
+// TEZIP_POISON=<byte> (diagnostic): every device buffer handed out -- fresh or recycled -- is first filled with that byte,
+// so that a kernel reading something nobody wrote shows up as a parity failure instead of depending on what the memory
+// held before (tests/test_gpu_poison.py runs the parity cases this way).
+int tz_poison_byte() {
+    static const int v = [] {
+        const char* e = getenv("TEZIP_POISON");
+        return e && *e ? (atoi(e) & 0xff) | 0x100 : 0;
+    }();
+    return v;
+}
+int tz_poison(tz_ctx* ctx, void* p, size_t bytes) {
+    const int v = tz_poison_byte();
+    if (v && p && bytes) {   // finished before the caller goes on: some initialisations are synchronous copies
+        TZ_HIP(ctx, hipMemsetAsync(p, v & 0xff, bytes, ctx->stream));
+        TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return TZ_OK;
+}
+
 int tz_pool_alloc(tz_ctx* ctx, size_t bytes, void** out) {
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~(size_t)255;
@@ -283,14 +305,14 @@ int tz_pool_alloc(tz_ctx* ctx, size_t bytes, void** out) {
     if (best >= 0 && ctx->pool[best].second <= 2 * bytes + (1 << 20)) {
         ctx->pool[best].second |= kPoolUsed;
         *out = ctx->pool[best].first;
-        return TZ_OK;
+        return tz_poison(ctx, *out, ctx->pool[best].second & ~kPoolUsed);
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return tz_fail(ctx, TZ_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     ctx->pool.push_back({p, bytes | kPoolUsed});
     *out = p;
-    return TZ_OK;
+    return tz_poison(ctx, p, bytes);
 }
 
 void tz_pool_release_all(tz_ctx* ctx) {
@@ -308,7 +330,7 @@ int tz_ensure(tz_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
     hipError_t e = hipMalloc(buf, bytes ? bytes : 16);
     if (e != hipSuccess) return tz_fail(ctx, TZ_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     *cap = bytes;
-    return TZ_OK;
+    return tz_poison(ctx, *buf, bytes);
 }
 
 int tz_upload(tz_ctx* ctx, void* dst, const void* src, size_t bytes) {
@@ -1417,19 +1439,23 @@ extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, size_t payload_len
     int rc = tz_dev_in(ctx, payload, N * 2, &d_pay);
     if (rc == TZ_OK) rc = tz_dev_out(ctx, frames_out, N, &o);
     if (rc == TZ_OK) outs.push_back(o);
-    if (rc == TZ_OK) rc = tz_pool_alloc(ctx, N * 2, &d_diff);
     if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_mask);
     if (rc == TZ_OK) rc = tz_upload(ctx, d_mask, ctx->key_mask.data(), nt);
-    if (rc == TZ_OK && table_len >= 0) {  // decompress.py:203-236 fused into the scan of 240-245
-        std::vector<int16_t> lut;
-        build_dec_lut(table, table_len, 1, &lut);
-        rc = tzk_unmap_undelta(ctx, (const int16_t*)d_pay, N, lut.data(), 1, (int16_t*)d_diff);
-    } else if (rc == TZ_OK) {
-        rc = tzk_undelta(ctx, (const int16_t*)d_pay, N, 0, 0, (int16_t*)d_diff);  // decompress.py:240-245
+    std::vector<int16_t> lut;
+    if (table_len >= 0) build_dec_lut(table, table_len, 1, &lut);  // decompress.py:203-236 rides on the scan of 240-245
+    const int16_t* h_lut = table_len >= 0 ? lut.data() : nullptr;
+    bool fused = false;
+    if (rc == TZ_OK && !ctx->decode_unfused)   // one launch: inverse remap + inverse spatial delta + reconstruct
+        rc = tzk_decode_tail_fused(ctx, (const int16_t*)d_pay, h_lut, 1, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, nt,
+                                   H, W, ctx->Hp, ctx->Wp, (uint8_t*)o.dev, &fused);
+    if (rc == TZ_OK && !fused) {
+        rc = tz_pool_alloc(ctx, N * 2, &d_diff);
+        if (rc == TZ_OK && h_lut) rc = tzk_unmap_undelta(ctx, (const int16_t*)d_pay, N, h_lut, 1, (int16_t*)d_diff);
+        else if (rc == TZ_OK) rc = tzk_undelta(ctx, (const int16_t*)d_pay, N, 0, 0, (int16_t*)d_diff);  // decompress.py:240-245
+        if (rc == TZ_OK)                                                    // decompress.py:252-256,269
+            rc = tzk_reconstruct(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, (const int16_t*)d_diff, nt, H, W,
+                                 ctx->Hp, ctx->Wp, (uint8_t*)o.dev);
     }
-    if (rc == TZ_OK)                                                        // decompress.py:252-256,269
-        rc = tzk_reconstruct(ctx, ctx->d_pred, ctx->d_frames, (const uint8_t*)d_mask, (const int16_t*)d_diff, nt, H, W,
-                             ctx->Hp, ctx->Wp, (uint8_t*)o.dev);
     if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
     if (rc == TZ_OK && resident) ctx->have_decoded = true;   // only a decode whose work is queued leaves frames to fetch
     tz_pool_release_all(ctx);

@@ -1777,9 +1777,8 @@ int tzk_shuffle(tz_ctx* ctx, const int16_t* in, size_t n, uint8_t* out, int inve
 // (4 of 8 possible workgroups per CU) and workgroups are dispatched in index order, so every block a
 // waiter waits for is running.
 static constexpr int SCAN_EPT = 16;                 // elements per thread
-static constexpr int SCAN_BLK = 256 * SCAN_EPT;     // elements per tile
-static constexpr int SCAN_G = 1024;                 // resident blocks
-static constexpr unsigned SCAN_VALID = 1u << 16;
+static constexpr int SCAN_G = 4096;                 // most blocks a launch uses (status words of the context)
+static constexpr int SCAN_G_DEFAULT = 1024;
 
 __device__ __forceinline__ unsigned block_scan_excl(unsigned v, unsigned* total) {
     __shared__ unsigned wsum[4];
@@ -1836,60 +1835,141 @@ __device__ __forceinline__ void st_store(unsigned* p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// status[g] = SCAN_VALID | (sum of chunk g mod 2^16); all zero at launch
-template <bool LUT>
-__global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, size_t n, int tiles_per_block, int has_carry,
+// What phase 3 does with the scanned values: store them (tz_spatial_undelta, tz_decode_delta's producer), or -- RECON, the
+// decoder's tail in one kernel -- go straight on to decompress.py:252-256,269: the thread's 16 elements lie in one frame
+// (frame_elems % 16 == 0, unpadded frames), whose base is 16 key bytes or 16 truncated predictions (loaded before the
+// tile's scan so that their latency hides behind its barriers); 16 bytes out.  9 B/element move instead of 13.
+struct ScanRecon {
+    const float4* pred;       // [frame][H*W*3] floats
+    const uint8_t* key;       // key-frame stack (bytes of non-key slots unused)
+    const uint8_t* key_mask;  // [frame]
+    unsigned long long fe;    // elements per frame
+    uint8_t* out;
+};
+
+// status[g] = epoch << 16 | (sum of block g's chunk mod 2^16); the words of a launch carry its epoch (1..65535, the
+// context counts them), so nothing has to be cleared between launches.  Inside a block every WAVE owns a contiguous run of
+// `wtiles` wave-tiles (64 lanes x 16 elements), so that the walks of phases 1 and 3 need wave shuffles only -- the block
+// meets at two barriers, around the exchange of sums.
+static constexpr int SCAN_WT = 64 * SCAN_EPT;   // elements per wave-tile
+
+__device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
+    const int lane = threadIdx.x & 63;
+    for (int s = 1; s < 64; s <<= 1) {
+        const unsigned up = __shfl_up(v, s);
+        if (lane >= s) v += up;
+    }
+    return v;
+}
+
+template <bool LUT, bool RECON>
+__global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, size_t n, int wtiles, int has_carry,
                                                 int16_t carry, int vec, const int16_t* __restrict__ lut, int post_offset,
-                                                unsigned* __restrict__ status, int16_t* __restrict__ out) {
+                                                unsigned* __restrict__ status, unsigned epoch, int16_t* __restrict__ out,
+                                                const ScanRecon rc) {
     __shared__ int16_t sl[LUT ? TZ_NBINS + 1 : 1];
+    __shared__ unsigned wsum[4];
     if (LUT) {
         for (int k = threadIdx.x; k < TZ_NBINS + 1; k += 256) sl[k] = lut[k];
         __syncthreads();
     }
-    const int g = blockIdx.x;
-    const size_t chunk0 = (size_t)g * tiles_per_block * SCAN_BLK;
-    // (1) the chunk's sum
+    const int g = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t chunk0 = ((size_t)g * 4 + wv) * (size_t)wtiles * SCAN_WT;   // of this wave
+    // (1) the sum of the wave's run, then of the block's
     unsigned s = 0;
-    for (int t = 0; t < tiles_per_block; ++t) {
-        const size_t base = chunk0 + (size_t)t * SCAN_BLK + (size_t)threadIdx.x * SCAN_EPT;
+    for (int t = 0; t < wtiles; ++t) {
+        const size_t base = chunk0 + (size_t)t * SCAN_WT + (size_t)lane * SCAN_EPT;
         if (base >= n) break;
         int v[SCAN_EPT];
         scan_load16<LUT>(in, base, n, vec != 0, !has_carry, sl, post_offset, v);
 #pragma unroll
         for (int k = 0; k < SCAN_EPT; ++k) s += (unsigned)v[k];
     }
-    unsigned tot;
-    block_scan_excl(s, &tot);
-    if (threadIdx.x == 0) st_store(&status[g], SCAN_VALID | (tot & 0xFFFFu));
-    // (2) the sums of the chunks in front: thread t takes chunks t, t + 256, ...
+    s = wave_scan_incl(s);
+    if (lane == 63) wsum[wv] = s;
+    __syncthreads();
+    unsigned front = 0, tot = 0;   // of the waves in front of this one in the block; of the block
+    for (int w = 0; w < 4; ++w) {
+        if (w < wv) front += wsum[w];
+        tot += wsum[w];
+    }
+    if (threadIdx.x == 0) st_store(&status[g], epoch << 16 | (tot & 0xFFFFu));
+    // (2) the sums of the blocks in front: thread t takes blocks t, t + 256, ...
     unsigned mine = 0;
     for (int b = threadIdx.x; b < g; b += 256) {
         unsigned w = st_load(&status[b]);
-        while ((w >> 16) == 0) w = st_load(&status[b]);
+        while ((w >> 16) != epoch) w = st_load(&status[b]);
         mine += w & 0xFFFFu;
     }
     unsigned run;
     block_scan_excl(mine, &run);
-    // (3) scan the chunk tile by tile
+    run += front;
+    // (3) scan the wave's run tile by tile
     const unsigned c0 = has_carry ? (unsigned)(int)carry : 0u;
-    for (int t = 0; t < tiles_per_block; ++t) {
-        const size_t base = chunk0 + (size_t)t * SCAN_BLK + (size_t)threadIdx.x * SCAN_EPT;
-        if (chunk0 + (size_t)t * SCAN_BLK >= n) break;   // uniform for the block: the barriers below stay matched
+    unsigned long long fr = 0, rr = 0;   // RECON: frame and offset in it of the tile's first element
+    if (RECON) {
+        fr = chunk0 / rc.fe;
+        rr = chunk0 - fr * rc.fe;
+    }
+    for (int t = 0; t < wtiles; ++t) {
+        const size_t base = chunk0 + (size_t)t * SCAN_WT + (size_t)lane * SCAN_EPT;
+        if (chunk0 + (size_t)t * SCAN_WT >= n) break;   // uniform for the wave
+        int bv[SCAN_EPT];
+        if (RECON) {
+            unsigned long long f = fr, r = rr + (unsigned long long)lane * SCAN_EPT;
+            while (r >= rc.fe) {
+                r -= rc.fe;
+                ++f;
+            }
+            rr += SCAN_WT;
+            while (rr >= rc.fe) {
+                rr -= rc.fe;
+                ++fr;
+            }
+            if (base < n) {   // n is a multiple of 16 here: all 16 elements exist
+                if (rc.key_mask[f]) {
+                    const uint4 k = *(const uint4*)(rc.key + base);
+                    const unsigned kw[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+                    for (int j = 0; j < SCAN_EPT; ++j) bv[j] = (kw[j >> 2] >> (8 * (j & 3))) & 0xff;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 p = rc.pred[base / 4 + j];
+                        bv[4 * j] = (int)(p.x * 255.0f);
+                        bv[4 * j + 1] = (int)(p.y * 255.0f);
+                        bv[4 * j + 2] = (int)(p.z * 255.0f);
+                        bv[4 * j + 3] = (int)(p.w * 255.0f);
+                    }
+                }
+            }
+        }
         int v[SCAN_EPT];
         scan_load16<LUT>(in, base, n, vec != 0, !has_carry, sl, post_offset, v);
         unsigned q = 0;
 #pragma unroll
         for (int k = 0; k < SCAN_EPT; ++k) q += (unsigned)v[k];
-        unsigned ttot;
-        unsigned pre = block_scan_excl(q, &ttot) + run;
-        run += ttot;
+        const unsigned incl = wave_scan_incl(q);
+        unsigned pre = incl - q + run;
+        run += __shfl(incl, 63);
         short r[SCAN_EPT];
 #pragma unroll
         for (int k = 0; k < SCAN_EPT; ++k) {
             pre += (unsigned)v[k];
             r[k] = (short)(uint16_t)(c0 - pre);
         }
-        if (vec && base + SCAN_EPT <= n) {
+        if (RECON) {
+            if (base < n) {
+                unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < SCAN_EPT; ++k) {
+                    int x = bv[k] - (int)r[k];
+                    x = x < 0 ? 0 : (x > 255 ? 255 : x);
+                    w[k >> 2] |= (unsigned)x << (8 * (k & 3));
+                }
+                *(uint4*)(rc.out + base) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        } else if (vec && base + SCAN_EPT <= n) {
             short8 a, b;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -1907,27 +1987,38 @@ __global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, 
 }
 
 static int scan_launch(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, int16_t carry, const int16_t* h_lut2112,
-                       int post_offset, int16_t* out) {
+                       int post_offset, int16_t* out, const ScanRecon* recon = nullptr) {
     if (n == 0) return TZ_OK;
-    const size_t tiles = (n + SCAN_BLK - 1) / SCAN_BLK;
-    const int G = (int)std::min<size_t>(SCAN_G, tiles);
-    const size_t tpb = (tiles + G - 1) / G;
+    const size_t tiles = (n + SCAN_WT - 1) / SCAN_WT;                 // wave-tiles
+    static const int g_env = getenv("TEZIP_SCAN_G") ? atoi(getenv("TEZIP_SCAN_G")) : 0;
+    const int G = (int)std::min<size_t>(g_env > 0 && g_env <= SCAN_G ? g_env : SCAN_G_DEFAULT, (tiles + 3) / 4);
+    const size_t tpb = (tiles + (size_t)G * 4 - 1) / ((size_t)G * 4);   // per wave
     if (tpb > 0x7FFFFFFFull) return tz_fail(ctx, TZ_ERR_INVALID, "inverse scan: too many elements");
-    void *d_status, *d_lut = nullptr;
-    TZ_TRY(tz_pool_alloc(ctx, sizeof(unsigned) * (size_t)G, &d_status));
+    void* d_lut = nullptr;
     if (h_lut2112) {
         TZ_TRY(tz_pool_alloc(ctx, (TZ_NBINS + 1) * 2, &d_lut));
         TZ_TRY(tz_upload(ctx, d_lut, h_lut2112, (TZ_NBINS + 1) * 2));
     }
+    if (!ctx->d_scan_status) TZ_HIP(ctx, hipMalloc((void**)&ctx->d_scan_status, sizeof(unsigned) * SCAN_G));
     tz_prof_scope ps(ctx, TZP_SCAN);
-    TZ_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(unsigned) * (size_t)G, ctx->stream));
+    if (ctx->scan_epoch == 0 || ctx->scan_epoch == 0xFFFFu) {   // first launch, or the epochs have gone round
+        TZ_HIP(ctx, hipMemsetAsync(ctx->d_scan_status, 0, sizeof(unsigned) * SCAN_G, ctx->stream));
+        ctx->scan_epoch = 0;
+    }
+    const unsigned epoch = ++ctx->scan_epoch;
     const int vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
-    if (h_lut2112)
-        hipLaunchKernelGGL(k_scan2p<true>, dim3(G), dim3(256), 0, ctx->stream, in, n, (int)tpb, has_carry, carry, vec,
-                           (const int16_t*)d_lut, post_offset, (unsigned*)d_status, out);
-    else
-        hipLaunchKernelGGL(k_scan2p<false>, dim3(G), dim3(256), 0, ctx->stream, in, n, (int)tpb, has_carry, carry, vec,
-                           (const int16_t*)nullptr, 0, (unsigned*)d_status, out);
+    const ScanRecon none = {};
+#define TZ_SCAN_LAUNCH(L, R)                                                                                              \
+    hipLaunchKernelGGL((k_scan2p<L, R>), dim3(G), dim3(256), 0, ctx->stream, in, n, (int)tpb, has_carry, carry, vec,      \
+                       (const int16_t*)d_lut, post_offset, ctx->d_scan_status, epoch, out, recon ? *recon : none)
+    if (recon) {
+        if (h_lut2112) TZ_SCAN_LAUNCH(true, true);
+        else TZ_SCAN_LAUNCH(false, true);
+    } else {
+        if (h_lut2112) TZ_SCAN_LAUNCH(true, false);
+        else TZ_SCAN_LAUNCH(false, false);
+    }
+#undef TZ_SCAN_LAUNCH
     TZ_HIP(ctx, hipGetLastError());
     return TZ_OK;
 }
@@ -1939,6 +2030,23 @@ int tzk_undelta(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, int16_t
 // decoder: inverse rank remap (+ 1600 - x) and inverse spatial delta in one pass over the payload
 int tzk_unmap_undelta(tz_ctx* ctx, const int16_t* in, size_t n, const int16_t* h_lut2112, int post_offset, int16_t* out) {
     return scan_launch(ctx, in, n, 0, 0, h_lut2112, post_offset, out);
+}
+
+// the decoder's tail in one launch (inverse remap when there is a table, inverse spatial delta, reconstruct) where the
+// layout allows it: unpadded frames of a multiple of 16 elements, 16-byte aligned buffers.  *done = false: the caller
+// runs the two separate launches.
+int tzk_decode_tail_fused(tz_ctx* ctx, const int16_t* in, const int16_t* h_lut2112, int post_offset, const float* pred,
+                          const uint8_t* key, const uint8_t* d_key_mask, int nframes, int H, int W, int Hp, int Wp,
+                          uint8_t* out, bool* done) {
+    *done = false;
+    const size_t fe = (size_t)H * W * 3, n = (size_t)nframes * fe;
+    if (n == 0 || H != Hp || W != Wp || fe % SCAN_EPT != 0 || !key ||
+        ((((uintptr_t)in | (uintptr_t)pred | (uintptr_t)key | (uintptr_t)out) & 15) != 0))
+        return TZ_OK;
+    const ScanRecon rc = {(const float4*)pred, key, d_key_mask, (unsigned long long)fe, out};
+    TZ_TRY(scan_launch(ctx, in, n, 0, 0, h_lut2112, post_offset, nullptr, &rc));
+    *done = true;
+    return TZ_OK;
 }
 
 // ----------------------------------------------------------------------------- reconstruct

@@ -90,6 +90,9 @@ struct tz_ctx {
     bool staged = false;                    // d_frames was filled by tz_frames_begin / tz_frames_put
     int16_t* d_payload = nullptr;           // resident payload of a tz_encode(payload = NULL)
     size_t cap_payload = 0, payload_len = 0;
+    unsigned* d_scan_status = nullptr;      // inverse scan: one word per resident block, tagged with the launch's epoch
+    unsigned scan_epoch = 0;
+    int decode_unfused = 0;                 // TEZIP_DECODE_UNFUSED=1: tz_decode as scan + reconstruct launches (cross-check)
     uint8_t* d_out = nullptr;               // resident decoded frames of a tz_decode(frames_out = NULL)
     size_t cap_out = 0;
     bool have_decoded = false;
@@ -122,6 +125,8 @@ int tz_fail(tz_ctx* ctx, int status, const char* fmt, ...);
 
 // ---- device memory helpers -------------------------------------------------------------
 bool tz_is_device_ptr(const void* p);
+int tz_poison_byte();                                 // TEZIP_POISON diagnostic: 0x100 | byte, or 0
+int tz_poison(tz_ctx*, void* p, size_t bytes);        // fill a freshly handed-out device buffer when it is on
 int tz_pool_alloc(tz_ctx* ctx, size_t bytes, void** out);   // freed by tz_pool_release_all
 void tz_pool_release_all(tz_ctx* ctx);
 int tz_ensure(tz_ctx* ctx, void** buf, size_t* cap, size_t bytes);  // persistent buffer growth
@@ -178,6 +183,9 @@ int tzk_lut(tz_ctx*, const int16_t* in, size_t n, const int16_t* h_lut2112, int 
 int tzk_shuffle(tz_ctx*, const int16_t* in, size_t n, uint8_t* out, int inverse);
 int tzk_undelta(tz_ctx*, const int16_t* in, size_t n, int has_carry, int16_t carry, int16_t* out);
 int tzk_unmap_undelta(tz_ctx*, const int16_t* in, size_t n, const int16_t* h_lut2112, int post_offset, int16_t* out);
+int tzk_decode_tail_fused(tz_ctx*, const int16_t* in, const int16_t* h_lut2112, int post_offset, const float* pred,
+                          const uint8_t* key, const uint8_t* d_key_mask, int nframes, int H, int W, int Hp, int Wp,
+                          uint8_t* out, bool* done);
 int tzk_reconstruct(tz_ctx*, const float* pred, const uint8_t* key, const uint8_t* d_key_mask, const int16_t* diff,
                     int nframes, int H, int W, int Hp, int Wp, uint8_t* out);
 int tzk_sse(tz_ctx*, const uint8_t* orig, const float* pred, int nframes, int H, int W, int Hp, int Wp,

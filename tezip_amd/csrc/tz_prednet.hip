@@ -76,7 +76,7 @@ static int dmalloc(tz_ctx* ctx, tz_model* m, void** p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) return tz_fail(ctx, TZ_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     m->allocs.push_back(*p);
-    return TZ_OK;
+    return tz_poison(ctx, *p, bytes);
 }
 
 struct ColSrc {

@@ -45,11 +45,21 @@ class HipEngine:
     def _new(self, n, dtype):
         return self.torch.empty(int(n), dtype=dtype, device=self.dev)
 
+    def _shared(self):
+        """Does the context launch on torch's current stream (then the two are ordered by the stream itself)?"""
+        mine = self.ctx.stream_ptr()
+        return bool(mine) and mine == self.torch.cuda.current_stream(self.dev).cuda_stream
+
     def _sync(self):
-        # a context with its OWN stream: torch / RCCL consume the buffers afterwards, so wait.  A
-        # context created on torch's current stream (bench.py) is already ordered with them.
-        if self.ctx.stream_ptr() != self.torch.cuda.current_stream(self.dev).cuda_stream:
+        # a context with its OWN stream (the CLI, bench.py): torch / RCCL consume the buffers afterwards, so wait
+        if not self._shared():
             self.ctx.synchronize()
+
+    def _sync_in(self, x):
+        # ... and the other way round: a device tensor torch may still be writing is complete before the library reads it
+        if not isinstance(x, np.ndarray) and getattr(x, "is_cuda", False) and not self._shared():
+            self.torch.cuda.current_stream(self.dev).synchronize()
+        return x
 
     def _buf(self, x):
         """numpy (host) and torch tensors are both accepted by the C ABI."""
@@ -57,7 +67,7 @@ class HipEngine:
 
     # encoder: the two phases of tz_encode around the exchange of carry + histogram
     def encode_begin(self, frames, warm_up, window, mode, bound, entropy):
-        frames = self._buf(frames)
+        frames = self._sync_in(self._buf(frames))
         key, _ = self.ctx.rollout(frames, warm_up, window)
         hist, first, last = self.ctx.encode_begin(mode, bound, entropy)
         return key, hist, first, last
@@ -77,10 +87,10 @@ class HipEngine:
 
     # decoder
     def decode_prepare(self, key_frames, warm_up):
-        return self.ctx.rollout_decode(self._buf(key_frames), warm_up)
+        return self.ctx.rollout_decode(self._sync_in(self._buf(key_frames)), warm_up)
 
     def unmap(self, payload, table):
-        payload = self._buf(payload)
+        payload = self._sync_in(self._buf(payload))
         n = payload.size if isinstance(payload, np.ndarray) else payload.numel()
         out = self._new(n, self.torch.int16)
         self.ctx.unmap(payload, table, offset=True, out=out)
@@ -92,14 +102,14 @@ class HipEngine:
 
     def undelta(self, sd, carry):
         out = self._new(sd.numel(), self.torch.int16)
-        self.ctx.spatial_undelta(sd, carry=carry, out=out)
+        self.ctx.spatial_undelta(self._sync_in(sd), carry=carry, out=out)
         self._sync()
         return out
 
     def reconstruct(self, delta):
         nt, h, w = self.ctx._shape
         out = self._new(nt * h * w * 3, self.torch.uint8)
-        self.ctx.decode_delta(delta, out=out)
+        self.ctx.decode_delta(self._sync_in(delta), out=out)
         self._sync()
         return out
 
