@@ -1760,25 +1760,24 @@ int tzk_shuffle(tz_ctx* ctx, const int16_t* in, size_t n, uint8_t* out, int inve
 // decompress.py:22-29 is a serial loop x[i] = x[i-1] - s[i] (pure Python, forced onto the
 // CPU by the reference, docs/index.rst:1392-1396).  It is the wrap-around prefix scan
 //   x[i] = c0 - sum_{j<=i} s'[j]   (mod 2^16),  s'[0] = -s[0] and c0 = 0 without a carry.
-// ONE launch of SCAN_G resident blocks (round 3; rounds 1-2: three launches, 85 us per 62.9 M elements):
-// block g owns a contiguous chunk of tiles; it (1) sums its chunk, (2) publishes the sum and reads
-// the sums of the chunks in front of it -- they all run at the same time and do the same work, so they
-// are there within one round trip --, (3) walks its chunk again, scanning tile by tile.  6 B/element
-// move for 4 algorithmic, as before, but without the launch gaps and the scan-of-sums kernel in
-// between: 60 us = 4.2 TB/s algorithmic, which is what 6 B/element at the chip's copy rate
-// (6.3 TB/s) allows.  A single pass with decoupled look-back (4 B/element) was built and measured and
-// is NOT faster here: a look-back hop between workgroups on different XCDs takes several microseconds
+// ONE launch of up to SCAN_G blocks (round 3; rounds 1-2: three launches, 85 us per 62.9 M elements):
+// every wave of a block owns a contiguous run of wave-tiles; the block (1) sums its runs, (2) publishes the
+// sum and reads the sums of the blocks in front of it -- they run at the same time (or ran before) and do the
+// same work, so they are there within a round trip --, (3) walks its runs again, scanning tile by tile with
+// wave shuffles only.  6 B/element move for 4 algorithmic, as before, but without the launch gaps and the
+// scan-of-sums kernel in between.  A single pass with decoupled look-back (4 B/element) was built and measured
+// and is NOT faster here: a look-back hop between workgroups on different XCDs takes several microseconds
 // under streaming load (and a ticket counter serialises at 12 ns per block): 170-220 us in every
 // variant (scripts/microbench/scan_lookback.hip, profiles/r03/scan_lookback.txt).
 // With LUT the decoder's inverse rank remap (decompress.py:31-36,236: rank -> 1600 - symbol) is
 // applied to the elements as they are loaded (both times), which removes the separate k_lut pass
-// over the payload (4 B/element) from tz_decode.
-// The blocks of phase 2 wait for lower-numbered blocks only; SCAN_G is far below what the chip holds
-// (4 of 8 possible workgroups per CU) and workgroups are dispatched in index order, so every block a
-// waiter waits for is running.
+// over the payload (4 B/element) from tz_decode; with RECON the reconstruction follows in the same walk.
+// Progress: a block waits for lower-numbered blocks only, and the workgroups of a launch start in index order
+// (per XCD), so the lowest-numbered unfinished block is always running and waits for nothing unfinished -- also
+// when the grid is larger than what the chip holds at once (it is: two rounds measured fastest).
 static constexpr int SCAN_EPT = 16;                 // elements per thread
-static constexpr int SCAN_G = 4096;                 // most blocks a launch uses (status words of the context)
-static constexpr int SCAN_G_DEFAULT = 1024;
+static constexpr int SCAN_G = 4096;                 // blocks of a launch: two rounds of the 2048 the chip holds (measured at
+                                                    // 62.9 M elements, fused tail: 1024 108 us, 2048 107, 4096 96, 8192 110)
 
 __device__ __forceinline__ unsigned block_scan_excl(unsigned v, unsigned* total) {
     __shared__ unsigned wsum[4];
@@ -1990,8 +1989,7 @@ static int scan_launch(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, 
                        int post_offset, int16_t* out, const ScanRecon* recon = nullptr) {
     if (n == 0) return TZ_OK;
     const size_t tiles = (n + SCAN_WT - 1) / SCAN_WT;                 // wave-tiles
-    static const int g_env = getenv("TEZIP_SCAN_G") ? atoi(getenv("TEZIP_SCAN_G")) : 0;
-    const int G = (int)std::min<size_t>(g_env > 0 && g_env <= SCAN_G ? g_env : SCAN_G_DEFAULT, (tiles + 3) / 4);
+    const int G = (int)std::min<size_t>(SCAN_G, (tiles + 3) / 4);
     const size_t tpb = (tiles + (size_t)G * 4 - 1) / ((size_t)G * 4);   // per wave
     if (tpb > 0x7FFFFFFFull) return tz_fail(ctx, TZ_ERR_INVALID, "inverse scan: too many elements");
     void* d_lut = nullptr;
