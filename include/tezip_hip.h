@@ -90,6 +90,12 @@ int tz_predict_tap(tz_ctx* ctx, int kind, int level, float* out);
  * model expects it to be faster (default; env TEZIP_LAT=0|1|2 sets a context's start value),
  * 1 (value 2) = never, 2 (value 4) = wherever a convolution is eligible. */
 int tz_set_conv_impl(tz_ctx* ctx, int lds_dma);
+/* Diagnostic: the device's own statement of the predictor's scalar functions (prednet.py:79-81,198-205: Keras
+ * hard_sigmoid and tanh in the fixed arithmetic of DESIGN.md section 3) on n caller-chosen inputs, so that a test can
+ * compare them bit for bit with the oracle's; recip_mismatches (may be NULL) receives the number of float32 values d in
+ * [4, 2^27] for which the kernels' division-free 1 - 2/d differs from the IEEE division it stands for (must be 0). */
+int tz_act_probe(tz_ctx* ctx, const float* x, size_t n, float* hard_sigmoid, float* tanh_out,
+                 unsigned long long* recip_mismatches);
 
 /* ---- rollout (compress.py:183-268 encoder; decompress.py:115-186 decoder) -----------------
  * frames: nt*H*W*3 uint8.  window > 0: SWP (-w); window == 0: DWP with `threshold` (-t).

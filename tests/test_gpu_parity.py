@@ -250,6 +250,23 @@ def test_reconstruct_and_sse(ctx, h, w):
 
 
 # ------------------------------------------------------------------------------ predictor
+def test_activations_bit_exact_vs_oracle_and_division_free_reciprocal(ctx):
+    """The device's hard_sigmoid / tanh against the C oracle's on every float32 of tanh's middle branch [0.625, 9) and a
+    dense sample elsewhere (both signs, zeros, the branch points, huge and tiny values); and the kernels' 1 - 2/d without
+    a division against the IEEE division for EVERY float32 d in [4, 2^27] (tz_math.hip.h)."""
+    lo, hi = np.float32(0.625).view(np.uint32), np.float32(9.0).view(np.uint32)
+    mid = np.arange(int(lo) - 64, int(hi) + 64, dtype=np.uint32).view(np.float32)
+    rng = np.random.default_rng(3)
+    rest = np.concatenate([rng.uniform(-0.7, 0.7, 1 << 20), rng.uniform(-30, 30, 1 << 20), rng.normal(0, 1e-3, 1 << 16),
+                           [0.0, -0.0, 0.625, -0.625, 9.0, -9.0, 1e-8, 1e-30, 1e-41, 30.0, -1e30, 2.5, -2.5, 7.5]]).astype(np.float32)
+    x = np.concatenate([mid, -mid[::7], rest])
+    hs, th, bad = ctx.act_probe(x, check_reciprocal=True)
+    assert bad == 0
+    ref_hs, ref_th = coracle.act_probe(x)
+    np.testing.assert_array_equal(hs.view(np.uint32), ref_hs.view(np.uint32))
+    np.testing.assert_array_equal(th.view(np.uint32), ref_th.view(np.uint32))
+
+
 @pytest.mark.parametrize("cfg,hp,wp,bias", [(SMALL, 16, 24, 0.3), (SMALL, 40, 48, 0.2), (FULL, 64, 64, 0.1),
                                             (FULL, 72, 88, 0.0)])
 def test_prednet_bit_exact_vs_canonical_oracle(ctx, cfg, hp, wp, bias):

@@ -39,6 +39,7 @@ _SIGS = {
     "tz_predict_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tz_predict_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "tz_set_conv_impl": (C.c_int, [C.c_void_p, C.c_int]),
+    "tz_act_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tz_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                              C.c_void_p, C.c_void_p]),
     "tz_rollout_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -285,6 +286,16 @@ class Context:
         out = np.empty((self.hp >> level, self.wp >> level, ch), np.float32)
         self._ck(self.lib.tz_predict_tap(self.h, kind, level, out.ctypes.data))
         return out
+
+    def act_probe(self, x, check_reciprocal=False):
+        """Diagnostic: (hard_sigmoid(x), tanh(x)) as the kernels compute them; check_reciprocal adds the count of
+        float32 d in [4, 2^27] whose division-free 1 - 2/d differs from the division (must be 0)."""
+        x = np.ascontiguousarray(x, np.float32).reshape(-1)
+        hs, th = np.empty_like(x), np.empty_like(x)
+        bad = C.c_ulonglong(0)
+        self._ck(self.lib.tz_act_probe(self.h, x.ctypes.data, x.size, hs.ctypes.data, th.ctypes.data,
+                                       C.byref(bad) if check_reciprocal else None))
+        return (hs, th, int(bad.value)) if check_reciprocal else (hs, th)
 
     def set_conv_impl(self, lds_dma, lat=None):
         """Diagnostic: 1 = LDS-DMA convolution kernels where they apply (default), 0 = the general kernel.

@@ -803,6 +803,65 @@ extern "C" int tz_predict_next(tz_ctx* ctx, const float* frames, int n, float* o
     return rc;
 }
 
+// ---- activation probe (diagnostic): the device's TZ-PA1 scalar functions on caller-chosen inputs, and an exhaustive
+// check of the division-free 1 - 2/d against the IEEE division it stands for
+__global__ __launch_bounds__(256) void k_act_probe(const float* __restrict__ x, size_t n, float* __restrict__ hs,
+                                                   float* __restrict__ th) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        hs[i] = tz_hard_sigmoid(x[i]);
+        th[i] = tz_tanh(x[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_recip_check(unsigned lo_bits, unsigned hi_bits, unsigned long long* __restrict__ bad) {
+    const unsigned stride = gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (unsigned long long b = (unsigned long long)lo_bits + blockIdx.x * blockDim.x + threadIdx.x; b <= hi_bits; b += stride) {
+        const float d = __uint_as_float((unsigned)b);
+        const float q = 2.0f / d;
+        const float want = 1.0f - q;
+        mine += __float_as_uint(tz_one_minus_two_over(d)) != __float_as_uint(want);
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+extern "C" int tz_act_probe(tz_ctx* ctx, const float* x, size_t n, float* hard_sigmoid, float* tanh_out,
+                            unsigned long long* recip_mismatches) {
+    if (!ctx || (n && (!x || !hard_sigmoid || !tanh_out))) return TZ_ERR_INVALID;
+    int rc = TZ_OK;
+    if (n) {
+        const void* dx = nullptr;
+        std::vector<tz_out> outs;
+        tz_out o1, o2;
+        rc = tz_dev_in(ctx, x, n * 4, &dx);
+        if (rc == TZ_OK) rc = tz_dev_out(ctx, hard_sigmoid, n * 4, &o1);
+        if (rc == TZ_OK) outs.push_back(o1);
+        if (rc == TZ_OK) rc = tz_dev_out(ctx, tanh_out, n * 4, &o2);
+        if (rc == TZ_OK) outs.push_back(o2);
+        if (rc == TZ_OK) {
+            hipLaunchKernelGGL(k_act_probe, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
+                               (const float*)dx, n, (float*)o1.dev, (float*)o2.dev);
+            if (hipGetLastError() != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "k_act_probe launch failed");
+        }
+        if (rc == TZ_OK) rc = tz_dev_out_finish(ctx, outs);
+    }
+    if (rc == TZ_OK && recip_mismatches) {   // every float32 d in [4, 2^27]: tz_tanh reaches [4.49, 6.6e7]
+        void* d_bad = nullptr;
+        rc = tz_pool_alloc(ctx, 8, &d_bad);
+        if (rc == TZ_OK) {
+            TZ_HIP(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(k_recip_check, dim3(4096), dim3(256), 0, ctx->stream, 0x40800000u, 0x4D000000u,
+                               (unsigned long long*)d_bad);
+            TZ_HIP(ctx, hipGetLastError());
+            TZ_HIP(ctx, hipMemcpyAsync(recip_mismatches, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+            TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    tz_pool_release_all(ctx);
+    return rc;
+}
+
 extern "C" int tz_predict_tap(tz_ctx* ctx, int kind, int level, float* out) {
     if (!ctx || !out) return TZ_ERR_INVALID;
     tz_model* m = ctx->model;
