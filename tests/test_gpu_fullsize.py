@@ -279,3 +279,68 @@ def test_the_hot_launches_run_on_the_kernels_the_design_names(ctx):
     ctx.prof_enable(False)
     # per step: pair (A1 + gates-1 E part), pair (A2 + gates-2 E part), gates 3, gates-2 / gates-1 upsampled parts
     assert p["convlat_small_grid"][1] == 19 * 5 and p["conv16_lds_dma"][1] == 0 and p["conv3x3_general"][1] == 0
+
+
+def test_more_than_2_31_elements_on_one_gpu():
+    """720 frames of 1024x1024x3 = 2,264,924,160 elements -- past what a signed or unsigned 31-bit index reaches -- through
+    rollout (18 windows in one batch), the fused lossless and lossy encodes, the tapped encode, and the decoder's one-launch
+    tail: lossless round trip bit-exact, `abs 2` within the bound, fused payload = tapped payload = the C oracle's back half
+    (spatial delta, offset, histogram, table, remap) of the device's own delta stack, table for table, byte for byte."""
+    import torch
+    from oracle import coracle
+    from tezip_amd import _lib
+    dev = torch.device("cuda", 0)
+    cfg = PredNetConfig()
+    c = _lib.Context(0)
+    try:
+        c.load_model(cfg, cfg.init_weights(seed=123))
+        nt, h, w = 720, 1024, 1024
+        n = nt * h * w * 3
+        assert n > 2 ** 31
+        g = torch.Generator(device=dev).manual_seed(4)
+        frames = torch.empty((nt, h, w, 3), dtype=torch.uint8, device=dev)
+        yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+        for a in range(0, nt, 40):   # detector-like: Poisson background + drifting peaks (cfg4's kind of data)
+            base = torch.poisson(torch.full((40, h, w), 3.0, device=dev), generator=g)
+            t = torch.arange(a, a + 40, device=dev).view(-1, 1, 1)
+            for k in range(6):
+                y0, x0 = 100 + 140 * k, 90 + 150 * k
+                base += 180 * torch.exp(-(((yy - y0 - 0.2 * t) ** 2 + (xx - x0 + 0.1 * t) ** 2) / 18.0))
+            frames[a:a + 40] = base.clamp(0, 255).to(torch.uint8)[..., None]
+        del base
+        c.prepare(h, w, max_batch=18)
+        payload = torch.empty(n, dtype=torch.int16, device=dev)
+        out = torch.empty_like(frames)
+        torch.cuda.synchronize()   # the context launches on a stream of its own
+        key, _ = c.rollout(frames, 0, 40)
+        assert key.nonzero()[0].tolist() == list(range(0, nt, 40))
+        keys = torch.zeros_like(frames)
+        kidx = torch.from_numpy(key).to(dev)
+        keys[kidx] = frames[kidx]
+        torch.cuda.synchronize()
+
+        def max_err():
+            return max(int((out[a:a + 80].to(torch.int16) - frames[a:a + 80].to(torch.int16)).abs().max()) for a in range(0, nt, 80))
+
+        for bound in (0.0, 2.0):
+            c.rollout(frames, 0, 40)
+            _, table, _ = c.encode("abs", [bound], True, payload=payload)
+            c.synchronize()
+            if bound:
+                delta = torch.empty(n, dtype=torch.int16, device=dev)
+                tapped = torch.empty(n, dtype=torch.int16, device=dev)
+                _, table2, _ = c.encode("abs", [bound], True, payload=tapped, delta_out=delta)
+                c.synchronize()
+                assert torch.equal(payload, tapped) and np.array_equal(table, table2)
+                delta_h = delta.cpu().numpy()
+                del delta, tapped
+                ref_payload, ref_table = coracle.encode_tail(delta_h, True)
+                np.testing.assert_array_equal(table, ref_table)
+                assert np.array_equal(payload.cpu().numpy(), ref_payload)
+                del delta_h, ref_payload
+            c.rollout_decode(keys, 0)
+            c.decode(payload, table, out=out)
+            c.synchronize()
+            assert max_err() <= bound
+    finally:
+        c.close()
