@@ -338,6 +338,18 @@ RUNS_2 = [
         ("dwp_mixed_p2_abs3_entropy", 26, 21, 30, False, 2, None, 0.0085, "abs", [3.0], True),
         ("dwp_mixed_p1_pwrel_gray", 24, 19, 27, True, 1, None, 0.012, "pwrel", [0.04], True),
 ]
+# round 3: the edge cases the GPU parity tests exercise against the oracle, as the REFERENCE runs them -- one-frame
+# windows (every frame after the warm-up a key frame), a window longer than the sequence, the shortest legal sequence
+# (nt = warm_up + 2), DWP with a threshold that every prediction exceeds / none reaches, absrel with an absolute bound of 0
+RUNS_3 = [
+        ("swp_p3_w1_every_frame_a_key", 7, 8, 8, False, 3, 1, None, "abs", [0.0], True),
+        ("swp_p0_w50_one_window", 7, 9, 9, False, 0, 50, None, "abs", [1.0], True),
+        ("swp_p2_w2_shortest_sequence", 4, 8, 16, False, 2, 2, None, "abs", [0.0], False),
+        ("dwp_p0_thr0_every_prediction_rejected", 8, 16, 8, False, 0, None, 0.0, "abs", [0.0], True),
+        ("dwp_p1_thr_never_reached", 8, 16, 8, False, 1, None, 1e9, "rel", [0.05], True),
+        ("swp_p0_w2_absrel_abs0", 6, 8, 8, False, 0, 2, None, "absrel", [0.0, 0.5], True),
+        ("swp_p1_w3_rel_no_entropy_gray", 9, 10, 14, True, 1, 3, None, "rel", [0.1], False),
+]
 
 
 def _runs(compress, decompress, out, runs=None, seed=777, make_frames=None):
@@ -426,6 +438,10 @@ def main():
     _runs(compress, decompress, runs2, RUNS_2, seed=778, make_frames=_make_frames_uneven)
     np.savez_compressed(os.path.join(HERE, "ref_runs2.npz"), **runs2)
     print("ref_runs2.npz:", len(runs2), "arrays")
+    runs3 = {}
+    _runs(compress, decompress, runs3, RUNS_3, seed=779)
+    np.savez_compressed(os.path.join(HERE, "ref_runs3.npz"), **runs3)
+    print("ref_runs3.npz:", len(runs3), "arrays")
 
 
 if __name__ == "__main__":

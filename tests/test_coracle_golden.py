@@ -1,6 +1,6 @@
 """Pins the C oracle's codec functions (oracle/tz_oracle.c through oracle/coracle.py) to the
 reference's own outputs: tests/golden/ref_helpers.npz, ref_long.npz (helper outputs) and
-ref_runs.npz / ref_runs2.npz (whole compress.run / decompress.run executions of the reference with
+ref_runs.npz / ref_runs2.npz / ref_runs3.npz (whole compress.run / decompress.run executions of the reference with
 the stand-in predictor).  The GPU tests compare the HIP kernels with THIS library at sizes the
 numpy oracle cannot reach, so the chain HIP -> C oracle -> reference must not have an unpinned link:
 every tzo_* integer function is checked here against data the reference itself produced."""
@@ -20,6 +20,8 @@ R = np.load(os.path.join(GOLDEN, "ref_runs.npz"))
 R2 = np.load(os.path.join(GOLDEN, "ref_runs2.npz"))
 RUNS = {str(n): R for n in R["run_names"]}
 RUNS.update({str(n): R2 for n in R2["run_names"]})
+R3 = np.load(os.path.join(GOLDEN, "ref_runs3.npz"))
+RUNS.update({str(n): R3 for n in R3["run_names"]})
 PRED = O.FnPredictor(fake_predictor.c0_image, fake_predictor.g_next)
 
 

@@ -16,6 +16,8 @@ R2 = np.load(os.path.join(GOLDEN, "ref_runs2.npz"))   # DWP runs with windows of
 LC = np.load(os.path.join(GOLDEN, "ref_long.npz"))    # error_bound of the reference on 12k..65k-element chains
 RUNS = {str(n): R for n in R["run_names"]}
 RUNS.update({str(n): R2 for n in R2["run_names"]})
+R3 = np.load(os.path.join(GOLDEN, "ref_runs3.npz"))   # edge cases: one-frame windows, one window, shortest sequence, DWP extremes
+RUNS.update({str(n): R3 for n in R3["run_names"]})
 PRED = O.FnPredictor(fake_predictor.c0_image, fake_predictor.g_next)
 
 
