@@ -2,6 +2,7 @@
 //   MODE 0  v_mfma_f32_16x16x4_f32 from registers only
 //   MODE 1  + A/B fragments re-read from LDS per k-step as 6 x ds_read_b32 per 8 MFMAs (k_conv3x3 v3)
 //   MODE 2  + fragments read as ds_read_b128 (A: 4 k-steps per read, B: 4 column tiles per read)
+//   MODE 3  A fragments as Winograd input-transform elements formed on the fly (4 x ds_read_b32 + 3 adds each)
 // each with or without one workgroup barrier per 32 MFMAs.  512-thread workgroups, 2 x 4 tiles per
 // wave, 3 workgroups per CU -- the shape of the conv kernel.  Prints TFLOP/s and the in-kernel clock
 // (s_memtime / s_memrealtime), so that the DVFS clock under a sustained fp32-MFMA load is known.
@@ -48,6 +49,31 @@ __global__ __launch_bounds__(512, 6) void k(float* out, unsigned long long* stam
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        } else if (MODE == 3) {
+            // Winograd F(2x2, 3x3) in the transformed domain, position xi outermost: the A fragment of a k-step is one element
+            // of B^T d B = a signed sum of FOUR patch values (rows / columns xi selects), formed on the fly: 4 LDS reads and
+            // 3 vector adds per A fragment instead of 1 read; B fragments as one ds_read_b128 per k-step (the weights of xi).
+            // An MFMA of this loop stands for 2.25 MFMAs of the direct form (16 instead of 36 multiplies per 2x2 outputs).
+            const int xi = st % 16, r0 = (xi >> 2), c0 = (xi & 3);
+            const int o00 = (r0 * 18 + c0) * 20, o02 = o00 + 2 * 20, o20 = o00 + 2 * 18 * 20, o22 = o20 + 2 * 20;
+            const float* pa = sA + (lane >> 4);
+            const float* pb = sB + cur * 16 * 80 + lane * 4;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float fa[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float* q = pa + (i ? arow1 : arow0) + 4 * kk;
+                    const float t0 = q[o00] - q[o02];
+                    const float t1 = q[o20] - q[o22];
+                    fa[i] = t0 - t1;
+                }
+                const f32x4 b = *(const f32x4*)(pb + kk * 256);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], b[j], acc[i][j], 0, 0, 0);
             }
         } else {
             // A image: pixel stride 20 floats, channel (4kk+g) at 4g+kk ; B image [kk][g][j][nt]
@@ -122,6 +148,8 @@ int main() {
         run<1, true>("ds_read_b32 + barrier/step", out, st, seed, blocks, steps);
         run<2, false>("ds_read_b128", out, st, seed, blocks, steps);
         run<2, true>("ds_read_b128 + barrier/step", out, st, seed, blocks, steps);
+        run<3, false>("winograd A: 4 reads + 3 adds", out, st, seed, blocks, steps);
+        run<3, true>("winograd A + barrier/step", out, st, seed, blocks, steps);
     }
     return 0;
 }
