@@ -13,7 +13,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE, bool BAR>
-__global__ __launch_bounds__(512, 6) void k(float* out, unsigned long long* stamps, int steps, const float* seed) {
+__global__ __launch_bounds__(512, MODE == 4 ? 2 : 6) void k(float* out, unsigned long long* stamps, int steps, const float* seed) {
     __shared__ __attribute__((aligned(16))) float sA[18 * 18 * 20];
     __shared__ __attribute__((aligned(16))) float sB[2 * 16 * 80];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -23,6 +23,10 @@ __global__ __launch_bounds__(512, 6) void k(float* out, unsigned long long* stam
     f32x4 acc[2][4];
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 y[MODE == 4 ? 4 : 1][2][4];
+    for (int q = 0; q < (MODE == 4 ? 4 : 1); ++q)
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 4; ++j) y[q][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float ra = seed[tid], rb = seed[tid + 512];
     const int arow0 = ((2 * wv) * 18 + (lane & 15)) * 20, arow1 = ((2 * wv + 1) * 18 + (lane & 15)) * 20;
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -75,6 +79,46 @@ __global__ __launch_bounds__(512, 6) void k(float* out, unsigned long long* stam
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], b[j], acc[i][j], 0, 0, 0);
             }
+        } else if (MODE == 4) {
+            // MODE 3 with the channel BLOCK outermost (the patch of a block is staged once, as in k_conv16): every step is one
+            // transform position of one 16-channel block -- D = 4 k-steps from a zero accumulator, then D is folded into the 2x2
+            // output accumulators Y (A^T D A: a corner position feeds 1 of the 4 outputs, an edge 2, a centre position 4 --
+            // 36 signed adds per 16 positions = 2.25 vector adds per D register and step).
+            const int xi = st % 16, r0 = (xi >> 2), c0 = (xi & 3);
+            const int o00 = (r0 * 18 + c0) * 20, o02 = o00 + 2 * 20, o20 = o00 + 2 * 18 * 20, o22 = o20 + 2 * 20;
+            const float* pa = sA + (lane >> 4);
+            const float* pb = sB + cur * 16 * 80 + lane * 4;
+            f32x4 d[2][4];
+            const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float fa[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float* q = pa + (i ? arow1 : arow0) + 4 * kk;
+                    const float t0 = q[o00] - q[o02];
+                    const float t1 = q[o20] - q[o22];
+                    fa[i] = t0 - t1;
+                }
+                const f32x4 b = *(const f32x4*)(pb + kk * 256);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], b[j], kk ? d[i][j] : zero, 0, 0, 0);
+            }
+            // fold: the number of outputs this position feeds (1, 2 or 4), uniform per step
+            const int nr = (r0 == 0 || r0 == 3) ? 1 : 2, nc = (c0 == 0 || c0 == 3) ? 1 : 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    y[0][i][j] += d[i][j];
+                    if (nc == 2) y[1][i][j] -= d[i][j];
+                    if (nr == 2) {
+                        y[2][i][j] += d[i][j];
+                        if (nc == 2) y[3][i][j] -= d[i][j];
+                    }
+                }
         } else {
             // A image: pixel stride 20 floats, channel (4kk+g) at 4g+kk ; B image [kk][g][j][nt]
             const f32x4 a0 = *(const f32x4*)(sA + toff + arow0 + 4 * (lane >> 4));
@@ -97,6 +141,9 @@ __global__ __launch_bounds__(512, 6) void k(float* out, unsigned long long* stam
     float s = 0.f;
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    for (int q = 0; q < (MODE == 4 ? 4 : 1); ++q)
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 4; ++j) s += y[q][i][j][0] + y[q][i][j][1] + y[q][i][j][2] + y[q][i][j][3];
     out[(size_t)blockIdx.x * 512 + tid] = s;
     if (tid == 0) {
         stamps[2 * blockIdx.x] = t1 - t0;
@@ -150,6 +197,8 @@ int main() {
         run<2, true>("ds_read_b128 + barrier/step", out, st, seed, blocks, steps);
         run<3, false>("winograd A: 4 reads + 3 adds", out, st, seed, blocks, steps);
         run<3, true>("winograd A + barrier/step", out, st, seed, blocks, steps);
+        run<4, false>("winograd, block outermost + fold", out, st, seed, blocks, steps);
+        run<4, true>("... + barrier/step", out, st, seed, blocks, steps);
     }
     return 0;
 }
