@@ -13,7 +13,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE, bool BAR>
-__global__ __launch_bounds__(512, MODE == 4 ? 2 : 6) void k(float* out, unsigned long long* stamps, int steps, const float* seed) {
+__global__ __launch_bounds__(512, MODE == 4 ? 2 : (MODE == 5 ? 3 : 6)) void k(float* out, unsigned long long* stamps, int steps, const float* seed) {
     __shared__ __attribute__((aligned(16))) float sA[18 * 18 * 20];
     __shared__ __attribute__((aligned(16))) float sB[2 * 16 * 80];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -27,6 +27,13 @@ __global__ __launch_bounds__(512, MODE == 4 ? 2 : 6) void k(float* out, unsigned
     for (int q = 0; q < (MODE == 4 ? 4 : 1); ++q)
         for (int i = 0; i < 2; ++i)
             for (int j = 0; j < 4; ++j) y[q][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 d5[4][4], y5[MODE == 5 ? 16 : 1];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) d5[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < (MODE == 5 ? 16 : 1); ++q) {
+        y5[q] = (f32x4){seed[tid + q], 0.f, 0.f, 0.f};
+        asm volatile("" : "+v"(y5[q]));
+    }
     float ra = seed[tid], rb = seed[tid + 512];
     const int arow0 = ((2 * wv) * 18 + (lane & 15)) * 20, arow1 = ((2 * wv + 1) * 18 + (lane & 15)) * 20;
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -119,6 +126,28 @@ __global__ __launch_bounds__(512, MODE == 4 ? 2 : 6) void k(float* out, unsigned
                         if (nc == 2) y[3][i][j] -= d[i][j];
                     }
                 }
+        } else if (MODE == 5) {
+            // The middle road: positions in four groups of four (one transform ROW per pass over the channels).  Four accumulator
+            // sets d[pos] stay live (ONE 16-row tile per wave x 4 column tiles), the 64 output registers y[] are only live, not
+            // touched; per k-step the four A fragments of the row come from 8 reads + 12 adds (column transform shared).
+            const int r0 = st & 3;
+            const float* pa = sA + (lane >> 4) + arow0 + (r0 * 18) * 20;
+            const float* pb = sB + cur * 16 * 80 + lane * 4;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float* q = pa + 4 * kk;
+                const float a0 = q[0], a1 = q[20], a2 = q[40], a3 = q[60];
+                const float c0 = q[2 * 18 * 20], c1 = q[2 * 18 * 20 + 20], c2 = q[2 * 18 * 20 + 40], c3 = q[2 * 18 * 20 + 60];
+                const float ta0 = a0 - a2, ta1 = a1 + a2, ta2 = a2 - a1, ta3 = a1 - a3;
+                const float tc0 = c0 - c2, tc1 = c1 + c2, tc2 = c2 - c1, tc3 = c1 - c3;
+                const float fa[4] = {ta0 - tc0, ta1 - tc1, ta2 - tc2, ta3 - tc3};
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                    const f32x4 b = *(const f32x4*)(pb + ((pos * 4 + kk) & 7) * 256);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d5[pos][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[pos], b[j], d5[pos][j], 0, 0, 0);
+                }
+            }
         } else {
             // A image: pixel stride 20 floats, channel (4kk+g) at 4g+kk ; B image [kk][g][j][nt]
             const f32x4 a0 = *(const f32x4*)(sA + toff + arow0 + 4 * (lane >> 4));
@@ -144,6 +173,13 @@ __global__ __launch_bounds__(512, MODE == 4 ? 2 : 6) void k(float* out, unsigned
     for (int q = 0; q < (MODE == 4 ? 4 : 1); ++q)
         for (int i = 0; i < 2; ++i)
             for (int j = 0; j < 4; ++j) s += y[q][i][j][0] + y[q][i][j][1] + y[q][i][j][2] + y[q][i][j][3];
+    for (int q = 0; q < (MODE == 5 ? 16 : 1); ++q) {
+        asm volatile("" : "+v"(y5[q]));
+        s += y5[q][0] + y5[q][1] + y5[q][2] + y5[q][3];
+    }
+    if (MODE == 5)
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) s += d5[i][j][0] + d5[i][j][1] + d5[i][j][2] + d5[i][j][3];
     out[(size_t)blockIdx.x * 512 + tid] = s;
     if (tid == 0) {
         stamps[2 * blockIdx.x] = t1 - t0;
@@ -171,7 +207,7 @@ static void run(const char* name, float* out, unsigned long long* st, const floa
     double clk = 0;
     for (int i = 0; i < blocks; ++i) clk += (double)h[2 * i] / (double)h[2 * i + 1] * 100.0;  // MHz
     clk /= blocks;
-    double flops = (double)blocks * 8 * steps * 32.0 * 2048.0;
+    double flops = (double)blocks * 8 * steps * (MODE == 5 ? 64.0 : 32.0) * 2048.0;
     printf("%-28s %7.2f ms  %6.1f TFLOP/s  in-kernel clock %.0f MHz  -> MFMA pipe busy %.1f %%\n", name, ms,
            flops / (ms * 1e-3) / 1e12, clk, 100.0 * (flops / (ms * 1e-3)) / (256.0 * 4 * 64 * clk * 1e6));
     free(h);
@@ -199,6 +235,8 @@ int main() {
         run<3, true>("winograd A + barrier/step", out, st, seed, blocks, steps);
         run<4, false>("winograd, block outermost + fold", out, st, seed, blocks, steps);
         run<4, true>("... + barrier/step", out, st, seed, blocks, steps);
+        run<5, false>("winograd, 4 groups of 4 positions", out, st, seed, blocks, steps);
+        run<5, true>("... + barrier/step", out, st, seed, blocks, steps);
     }
     return 0;
 }
