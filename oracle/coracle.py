@@ -1,5 +1,6 @@
 """ctypes loader for oracle/libtzoracle.so (the C restatement; test infrastructure only)."""
 import ctypes as C
+import ctypes as C_
 import os
 import subprocess
 
@@ -138,6 +139,27 @@ def error_bound_frame(orig_hwc, diff_hwc, mode, value):
         if rc:
             raise ValueError("%s bound must be >= 0 (the reference raises on a negative tolerance)" % mode)
     return d
+
+
+def conv_probe(x, xu, w, bias, winograd):
+    """One 3x3 'same' convolution in the oracle's direct statement (TZ-PA1) or its Winograd F(2x2, 3x3) statement (not used
+    by the predictor yet).  x: (H, W, C) or None; xu: (H/2, W/2, Cu) nearest-upsampled source or None; w: HWIO."""
+    H, W = (x.shape[:2] if x is not None else (2 * xu.shape[0], 2 * xu.shape[1]))
+    C = 0 if x is None else x.shape[2]
+    Cu = 0 if xu is None else xu.shape[2]
+    w = np.ascontiguousarray(w, np.float32)
+    bias = np.ascontiguousarray(bias, np.float32)
+    assert w.shape[:3] == (3, 3, C + Cu)
+    out = np.empty((H, W, w.shape[3]), np.float32)
+    xs = None if x is None else np.ascontiguousarray(x, np.float32)
+    xus = None if xu is None else np.ascontiguousarray(xu, np.float32)
+    L = lib()
+    L.tzo_conv_probe.argtypes = [C_.c_int, C_.c_void_p, C_.c_int, C_.c_void_p, C_.c_int, C_.c_int, C_.c_int, C_.c_void_p,
+                                 C_.c_void_p, C_.c_int, C_.c_void_p]
+    L.tzo_conv_probe.restype = None
+    L.tzo_conv_probe(int(bool(winograd)), None if xs is None else xs.ctypes.data, C, None if xus is None else xus.ctypes.data, Cu,
+                     H, W, w.ctypes.data, bias.ctypes.data, w.shape[3], out.ctypes.data)
+    return out
 
 
 def spatial_delta(x, offset):

@@ -319,6 +319,209 @@ tzo_model* tzo_model_create(int L, const int* stack, const int* rstack, int Hp, 
     return m;
 }
 
+/* ------------------------------------------------------------------------------------------------------
+ * A SECOND statement of the same convolution, NOT used by the predictor yet: Winograd F(2x2, 3x3) on the
+ * same-resolution sources ("TZ-PA2", profiles/r03/winograd_skeleton.md: 2.25x fewer multiplies, still one
+ * fmaf chain along the input channels per transformed position, i.e. what an MFMA k-loop computes).  Stated
+ * here first so that a device kernel has something to be bit-exact with.
+ *   tile (ty, tx) = outputs (2ty+a, 2tx+b), a, b in {0,1}; its input patch d[r][c] = x[2ty-1+r][2tx-1+c], zero outside
+ *   input transform V = B^T d B, columns first:  t[r][0] = d[r][0]-d[r][2]  t[r][1] = d[r][1]+d[r][2]
+ *                                                t[r][2] = d[r][2]-d[r][1]  t[r][3] = d[r][1]-d[r][3]
+ *       then rows the same way: V[0][j] = t[0][j]-t[2][j]  V[1][j] = t[1][j]+t[2][j]  V[2][j] = t[2][j]-t[1][j]  V[3][j] = t[1][j]-t[3][j]
+ *   weights U = G g G^T per (ci, co), float32, rows first: s = g[0][c]+g[2][c]; w[1][c] = 0.5(s+g[1][c]); w[2][c] = 0.5(s-g[1][c]);
+ *       w[0][c] = g[0][c]; w[3][c] = g[2][c]; then the same along c
+ *   products: D[i][j] = chain over sources in concat order, channels ascending, from 0:  D = fmaf(V[i][j](ci), U[i][j](ci, co), D)
+ *   outputs, transform row i = 0..3 in turn (one pass over the channels each):
+ *       Z[i][0] = (D[i][0]+D[i][1])+D[i][2]     Z[i][1] = (D[i][1]-D[i][2])-D[i][3]
+ *       y[0][b] = ((bias + Z[0][b]) + Z[1][b]) + Z[2][b]     y[1][b] = ((bias + Z[1][b]) - Z[2][b]) - Z[3][b]
+ *   an upsampled source then continues each output's chain with its 4 collapsed taps exactly as in conv3x3 (the four
+ *   outputs of a tile are the four parity classes over the same 2x2 half-resolution pixels). */
+static void wino_u(const float* Wt, int Cin, int Cout, int ci, int co, float U[4][4]) {
+    float g[3][3], w[4][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) g[r][c] = Wt[((size_t)(r * 3 + c) * Cin + ci) * Cout + co];
+    for (int c = 0; c < 3; ++c) {
+        float s_ = g[0][c] + g[2][c];
+        w[0][c] = g[0][c];
+        w[1][c] = 0.5f * (s_ + g[1][c]);
+        w[2][c] = 0.5f * (s_ - g[1][c]);
+        w[3][c] = g[2][c];
+    }
+    for (int i = 0; i < 4; ++i) {
+        float s_ = w[i][0] + w[i][2];
+        U[i][0] = w[i][0];
+        U[i][1] = 0.5f * (s_ + w[i][1]);
+        U[i][2] = 0.5f * (s_ - w[i][1]);
+        U[i][3] = w[i][2];
+    }
+}
+
+static void conv3x3_wino(const tzo_src* src, int nsrc, int H, int W, const float* Wt, const float* bias, int Cout, float* out) {
+    int Cin = 0, Csame = 0;
+    for (int s = 0; s < nsrc; ++s) Cin += src[s].C;
+    /* transformed weights of the same-resolution sources: Us[pos][c][co], c counting the live same-resolution channels in
+       concat order; collapsed weights of upsampled sources as in conv3x3 */
+    int coff = 0;
+    for (int s = 0; s < nsrc; ++s)
+        if (src[s].p && !src[s].up) Csame += src[s].C;
+    float* Us = (float*)malloc(sizeof(float) * 16 * (size_t)(Csame ? Csame : 1) * Cout);
+    {
+        int c = 0;
+        coff = 0;
+        for (int s = 0; s < nsrc; ++s) {
+            if (src[s].p && !src[s].up)
+                for (int ci = 0; ci < src[s].C; ++ci, ++c)
+                    for (int co = 0; co < Cout; ++co) {
+                        float U[4][4];
+                        wino_u(Wt, Cin, Cout, coff + ci, co, U);
+                        for (int q = 0; q < 16; ++q) Us[((size_t)q * Csame + c) * Cout + co] = U[q >> 2][q & 3];
+                    }
+            coff += src[s].C;
+        }
+    }
+    float* Wc[4] = {0, 0, 0, 0};
+    coff = 0;
+    for (int s = 0; s < nsrc; ++s) {
+        int C = src[s].C;
+        if (src[s].p && src[s].up) {
+            Wc[s] = (float*)malloc(sizeof(float) * 16 * (size_t)C * Cout);
+            for (int cls = 0; cls < 4; ++cls)
+                for (int tp = 0; tp < 4; ++tp) {
+                    int kys[2], kxs[2];
+                    int nky = collapse_set(cls >> 1, tp >> 1, kys), nkx = collapse_set(cls & 1, tp & 1, kxs);
+                    for (int ci = 0; ci < C; ++ci)
+                        for (int co = 0; co < Cout; ++co) {
+                            float v = 0.0f;
+                            int first = 1;
+                            for (int iy = 0; iy < nky; ++iy)
+                                for (int ix = 0; ix < nkx; ++ix) {
+                                    float w = Wt[((size_t)(kys[iy] * 3 + kxs[ix]) * Cin + coff + ci) * Cout + co];
+                                    v = first ? w : v + w;
+                                    first = 0;
+                                }
+                            Wc[s][(((size_t)cls * 4 + tp) * C + ci) * Cout + co] = v;
+                        }
+                }
+        }
+        coff += C;
+    }
+    const int TY = (H + 1) / 2, TX = (W + 1) / 2;
+#pragma omp parallel for schedule(static)
+    for (int ty = 0; ty < TY; ++ty) {
+        float* D = (float*)malloc(sizeof(float) * 4 * (size_t)Cout);
+        float* Y = (float*)malloc(sizeof(float) * 4 * (size_t)Cout);
+        float* V = (float*)malloc(sizeof(float) * 4 * (size_t)(Csame ? Csame : 1));
+        for (int tx = 0; tx < TX; ++tx) {
+            for (int q = 0; q < 4; ++q)
+                for (int co = 0; co < Cout; ++co) Y[q * Cout + co] = bias[co];
+            for (int i = 0; i < 4 && Csame; ++i) {   /* one pass over the channels per transform row */
+                int c = 0;
+                for (int s = 0; s < nsrc; ++s) {
+                    if (!(src[s].p && !src[s].up)) continue;
+                    int C = src[s].C;
+                    for (int ci = 0; ci < C; ++ci, ++c) {
+                        float d[4][4], t[4][4];
+                        for (int r = 0; r < 4; ++r)
+                            for (int cc = 0; cc < 4; ++cc) {
+                                int yy = 2 * ty - 1 + r, xx = 2 * tx - 1 + cc;
+                                d[r][cc] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[s].p[((size_t)yy * W + xx) * C + ci] : 0.0f;
+                            }
+                        for (int r = 0; r < 4; ++r) {
+                            t[r][0] = d[r][0] - d[r][2];
+                            t[r][1] = d[r][1] + d[r][2];
+                            t[r][2] = d[r][2] - d[r][1];
+                            t[r][3] = d[r][1] - d[r][3];
+                        }
+                        for (int j = 0; j < 4; ++j) {
+                            float v;
+                            if (i == 0) v = t[0][j] - t[2][j];
+                            else if (i == 1) v = t[1][j] + t[2][j];
+                            else if (i == 2) v = t[2][j] - t[1][j];
+                            else v = t[1][j] - t[3][j];
+                            V[(size_t)j * Csame + c] = v;
+                        }
+                    }
+                }
+                for (int j = 0; j < 4; ++j) {
+                    const float* up = Us + (size_t)(i * 4 + j) * Csame * Cout;
+                    for (int co = 0; co < Cout; ++co) D[j * Cout + co] = 0.0f;
+                    for (int cc = 0; cc < Csame; ++cc) {
+                        const float xv = V[(size_t)j * Csame + cc];
+                        const float* wr = up + (size_t)cc * Cout;
+                        for (int co = 0; co < Cout; ++co) D[j * Cout + co] = fmaf(xv, wr[co], D[j * Cout + co]);
+                    }
+                }
+                for (int co = 0; co < Cout; ++co) {
+                    const float d0 = D[co], d1 = D[Cout + co], d2 = D[2 * Cout + co], d3 = D[3 * Cout + co];
+                    float z0 = d0 + d1;
+                    z0 = z0 + d2;
+                    float z1 = d1 - d2;
+                    z1 = z1 - d3;
+                    if (i == 0) {
+                        Y[0 * Cout + co] = Y[0 * Cout + co] + z0;
+                        Y[1 * Cout + co] = Y[1 * Cout + co] + z1;
+                    } else if (i == 1) {
+                        Y[0 * Cout + co] = Y[0 * Cout + co] + z0;
+                        Y[1 * Cout + co] = Y[1 * Cout + co] + z1;
+                        Y[2 * Cout + co] = Y[2 * Cout + co] + z0;
+                        Y[3 * Cout + co] = Y[3 * Cout + co] + z1;
+                    } else if (i == 2) {
+                        Y[0 * Cout + co] = Y[0 * Cout + co] + z0;
+                        Y[1 * Cout + co] = Y[1 * Cout + co] + z1;
+                        Y[2 * Cout + co] = Y[2 * Cout + co] - z0;
+                        Y[3 * Cout + co] = Y[3 * Cout + co] - z1;
+                    } else {
+                        Y[2 * Cout + co] = Y[2 * Cout + co] - z0;
+                        Y[3 * Cout + co] = Y[3 * Cout + co] - z1;
+                    }
+                }
+            }
+            /* upsampled sources: each output's chain goes on with its collapsed taps */
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    const int y = 2 * ty + a, x = 2 * tx + b;
+                    if (y >= H || x >= W) continue;
+                    float* acc = Y + (a * 2 + b) * Cout;
+                    for (int s = 0; s < nsrc; ++s) {
+                        if (!(src[s].p && src[s].up)) continue;
+                        int C = src[s].C, H2 = H >> 1, W2 = W >> 1, cls = (a << 1) | b;
+                        for (int c0 = 0; c0 < C; c0 += 16)
+                            for (int tp = 0; tp < 4; ++tp) {
+                                int ly = (y >> 1) - 1 + (y & 1) + (tp >> 1), lx = (x >> 1) - 1 + (x & 1) + (tp & 1);
+                                int inside = ly >= 0 && ly < H2 && lx >= 0 && lx < W2;
+                                const float* ip = inside ? src[s].p + ((size_t)ly * W2 + lx) * C : NULL;
+                                const float* wp = Wc[s] + ((size_t)cls * 4 + tp) * C * Cout;
+                                int c1 = c0 + 16 < C ? c0 + 16 : C;
+                                for (int ci = c0; ci < c1; ++ci) {
+                                    float xv = inside ? ip[ci] : 0.0f;
+                                    const float* wr = wp + (size_t)ci * Cout;
+                                    for (int co = 0; co < Cout; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+                                }
+                            }
+                    }
+                    memcpy(out + ((size_t)y * W + x) * Cout, acc, sizeof(float) * (size_t)Cout);
+                }
+        }
+        free(D);
+        free(Y);
+        free(V);
+    }
+    free(Us);
+    for (int s = 0; s < 4; ++s) free(Wc[s]);
+}
+
+/* probe for tests: one convolution in either statement.  x: [H][W][C] same-resolution source (or NULL), xu: [H/2][W/2][Cu]
+ * upsampled source (or NULL), Wt: HWIO (3,3,C+Cu,Cout) */
+void tzo_conv_probe(int winograd, const float* x, int C, const float* xu, int Cu, int H, int W, const float* Wt,
+                    const float* bias, int Cout, float* out) {
+    tzo_src src[2];
+    int ns = 0;
+    if (C > 0) { src[ns].p = x; src[ns].C = C; src[ns].up = 0; ++ns; }
+    if (Cu > 0) { src[ns].p = xu; src[ns].C = Cu; src[ns].up = 1; ++ns; }
+    if (winograd) conv3x3_wino(src, ns, H, W, Wt, bias, Cout, out);
+    else conv3x3(src, ns, H, W, Wt, bias, Cout, out);
+}
+
 void tzo_model_destroy(tzo_model* m) {
     if (!m) return;
     for (int l = 0; l < TZO_MAXL; ++l) { free(m->r0[l]); free(m->c0[l]); free(m->ahat0[l]); }
