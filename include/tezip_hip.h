@@ -90,6 +90,12 @@ int tz_predict_tap(tz_ctx* ctx, int kind, int level, float* out);
  * model expects it to be faster (default; env TEZIP_LAT=0|1|2 sets a context's start value),
  * 1 (value 2) = never, 2 (value 4) = wherever a convolution is eligible. */
 int tz_set_conv_impl(tz_ctx* ctx, int lds_dma);
+/* Diagnostic: the inverse scan of decompress.py:22-29 (k_scan2p) lets a workgroup wait for the block sums of the workgroups
+ * in front of it; that wait is bounded, and an expiry surfaces as TZ_ERR_HIP at the context's next stream synchronisation
+ * (tz_ctx_synchronize, or any call that delivers host results).  This entry makes the next scans wait for the status words
+ * of the launch `epoch_skew` launches ahead (never written when != 0) and give up after poll_limit polls (0 = built-in
+ * 2^22), so that a test can see the failure path; (0, 0) restores normal operation. */
+int tz_scan_fault_inject(tz_ctx* ctx, unsigned epoch_skew, unsigned poll_limit);
 /* Diagnostic: the device's own statement of the predictor's scalar functions (prednet.py:79-81,198-205: Keras
  * hard_sigmoid and tanh in the fixed arithmetic of DESIGN.md section 3) on n caller-chosen inputs, so that a test can
  * compare them bit for bit with the oracle's; recip_mismatches (may be NULL) receives the number of float32 values d in
@@ -179,7 +185,13 @@ int tz_decode_delta(tz_ctx* ctx, const int16_t* delta, uint8_t* frames_out);
 int tz_delta_encode(tz_ctx* ctx, const float* pred, const uint8_t* orig, const uint8_t* zero_mask,
                     int nframes, int H, int W, int16_t* out);
 /* tz_error_bound: compress.py:23-70 applied per frame and channel as compress.py:316-319 does.
- * diff is updated in place; skip_mask[nframes] (host): 1 => frame left untouched. */
+ * diff is updated in place; skip_mask[nframes] (host): 1 => frame left untouched.
+ * Domain: any int16 stack (the deltas of compress.py:292-314 lie in [-255, 255]; wider values take the reference's
+ * double test at every step instead of the integer walk's width table -- same results, slower).
+ * Negative tolerances: `abs` takes |b| (compress.py:29).  For rel / pwrel with b < 0 and absrel with a negative relative
+ * bound the reference fails only where E < 0 meets the FIRST element of a chain ((inf + -inf)/2 = NaN stored into an int
+ * array, compress.py:60-61) and otherwise carries on with every element a run of its own; this library rejects every
+ * such call with TZ_ERR_INVALID -- a deliberate superset of the reference's failure, both oracles do the same. */
 int tz_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8_t* skip_mask,
                    int nframes, int H, int W, int mode, double b0, double b1);
 /* tz_spatial_delta: compress.py:73-77 (+ the 1600 offset of :348 when apply_offset).

@@ -96,6 +96,31 @@ class OracleEngine:
         return self.O.reconstruct(self.x_hat[:, :h, :w], delta)
 
 
+class OracleContext:
+    """Test double for tezip_amd._lib.Context as sweep.sweep drives it (prepare / rollout / encode), computed by
+    the CPU oracle."""
+
+    def __init__(self, pred, fail_on_window=None):
+        from oracle import oracle
+        self.O, self.pred, self.fail_on_window = oracle, pred, fail_on_window
+
+    def prepare(self, hp, wp, max_batch):
+        self.prepared = (hp, wp, max_batch)
+
+    def rollout(self, frames, warm_up, window):
+        if window == self.fail_on_window:
+            raise MemoryError("injected failure at window %d" % window)
+        self.job = (frames, warm_up, window)
+        self.ro = self.O.rollout(frames, warm_up, window, None, self.pred)
+        return self.ro["key"], None
+
+    def encode(self, mode, bound, entropy):
+        frames, warm_up, window = self.job
+        st = self.O.encode_stream(frames, self.ro, warm_up, mode, bound, entropy=entropy)
+        payload, table, _, _ = self.O.parse_stream(st["stream"])
+        return payload, table, None
+
+
 def _case():
     import fake_predictor
     from oracle import oracle as O
@@ -219,3 +244,65 @@ def _free_port():
 def test_sharded_equals_single_process(world, p, window, mode, bound, entropy):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), p, window, mode, bound, entropy), nprocs=world, join=True)
+
+
+def _sweep_worker(rank, world, port, windows, p, mode, bound, fail_on_window):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), os.path.join(here, "golden")]
+    import torch.distributed as dist
+    from tezip_amd import sweep
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        frames, pred = _case()
+        # what one process finds (compress.py:249 run once per candidate -w by hand)
+        ref_rows, (ref_w, ref_kb, ref_eb) = sweep.sweep(OracleContext(pred), frames, p, windows, mode, bound)
+        if fail_on_window is None:
+            rows, bw, blobs = sweep.sweep_sharded(OracleContext(pred), frames, p, windows, mode, bound)
+            assert rows == sorted(ref_rows, key=lambda r: r["window"])
+            assert bw == ref_w
+            owner = list(windows).index(bw) % world
+            if rank == owner:      # the rank that compressed the best candidate holds its two files
+                assert blobs is not None and blobs[0] == ref_kb and blobs[1] == ref_eb
+            else:
+                assert blobs is None
+            return
+        owner = list(windows).index(fail_on_window) % world
+        try:
+            sweep.sweep_sharded(OracleContext(pred, fail_on_window), frames, p, windows, mode, bound)
+        except MemoryError:
+            assert rank == owner
+        except RuntimeError as e:
+            assert rank != owner and "window sweep failed on rank(s) [%d]" % owner in str(e), str(e)
+        else:
+            raise AssertionError("a failed rank went unnoticed")
+        # a rank that could not even make its context reports through the same collective
+        try:
+            sweep.sweep_sharded(None if rank == 1 else OracleContext(pred), frames, p, windows, mode, bound,
+                                ctx_error=OSError("no device") if rank == 1 else None)
+        except OSError:
+            assert rank == 1
+        except RuntimeError as e:
+            assert rank != 1 and "[1]" in str(e)
+        else:
+            raise AssertionError("a rank without a context went unnoticed")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,windows,p,mode,bound", [
+    (2, (2, 3, 4, 5, 7), 0, "abs", [0.0]),
+    (3, (1, 2, 3, 4, 5, 6, 13, 20), 0, "abs", [0.0]),     # 8 candidates on 3 ranks (3 + 3 + 2), a window longer than nt
+    (3, (3, 4), 2, "abs", [2.0]),                          # fewer candidates than ranks: rank 2 has nothing to do
+])
+def test_sweep_sharded_equals_single_process(world, windows, p, mode, bound):
+    """BASELINE configs[4] on N ranks: one candidate window size per rank (sweep.sweep_sharded), sizes all-gathered --
+    rows, best window and the owner's two files equal the one-process sweep."""
+    import torch.multiprocessing as mp
+    mp.spawn(_sweep_worker, args=(world, _free_port(), windows, p, mode, bound, None), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world,fail_on_window", [(2, 3), (3, 5)])
+def test_sweep_failure_on_one_rank_stops_every_rank(world, fail_on_window):
+    import torch.multiprocessing as mp
+    mp.spawn(_sweep_worker, args=(world, _free_port(), (2, 3, 4, 5, 7), 0, "abs", [0.0], fail_on_window), nprocs=world, join=True)

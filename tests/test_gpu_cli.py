@@ -139,6 +139,47 @@ def test_cli_under_torchrun_shards_windows_and_writes_identical_files(tmp_path):
     np.testing.assert_array_equal(got, ref)
 
 
+def test_sweep_under_torchrun_writes_the_files_of_one_process(tmp_path):
+    """BASELINE configs[4] on N GPUs: `torch.distributed.run --nproc-per-node 2 -m tezip_amd.tezip -c ... --sweep 5 10 20 40`
+    (gloo transport, both ranks on GPU 0 here) -- one candidate window size per rank and turn, the sizes all-gathered
+    (sweep.sweep_sharded), the owner of the best candidate writes its files: the three files and sweep.txt must be
+    byte-identical to the one-process sweep, and equal to what `-w <best>` writes (compress.py:249)."""
+    import socket
+    import subprocess
+    import sys
+    from tezip_amd import sweep
+    cfg = PredNetConfig(stack_sizes=(3, 16, 32))
+    nt, h, w = 44, 24, 40
+    frames = synth.translating_scene(nt, h, w, seed=25)
+    mdir = str(tmp_path / "model")
+    weights.save_model(mdir, cfg, cfg.init_weights(seed=8, bias_scale=0.1), 24, 40)
+    ddir = _write(tmp_path, frames, False)
+    one, two, direct = str(tmp_path / "one"), str(tmp_path / "two"), str(tmp_path / "direct")
+    rows, bw = sweep.run(mdir, ddir, one, 0, [5, 10, 20, 40], "abs", [0.0], False, True)
+    assert [r["window"] for r in rows] == [5, 10, 20, 40] and bw in (5, 10, 20, 40)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, TEZIP_DIST_BACKEND="gloo", TEZIP_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "tezip_amd.tezip", "-c", mdir, ddir, two, "--sweep", "5", "10",
+           "20", "40", "-m", "abs", "-b", "0"]
+    r = subprocess.run(cmd, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert sorted(os.listdir(two)) == ["entropy.dat", "filename.txt", "key_frame.dat", "sweep.txt"]
+    for name in ("filename.txt", "key_frame.dat", "entropy.dat", "sweep.txt"):
+        assert open(os.path.join(one, name), "rb").read() == open(os.path.join(two, name), "rb").read(), name
+    assert open(os.path.join(two, "sweep.txt")).read().count("<- best") == 1
+    compress.run(mdir, ddir, direct, 0, bw, None, "abs", [0.0], True, False, True)
+    assert open(os.path.join(direct, "filename.txt"), "rb").read() == open(os.path.join(two, "filename.txt"), "rb").read()
+    # compress.run streams its two frames through ZSTD_compressStream2, the sweep packs them in one shot: same content
+    for name in ("key_frame.dat", "entropy.dat"):
+        a = zstd.decompress(open(os.path.join(direct, name), "rb").read())
+        assert a == zstd.decompress(open(os.path.join(two, name), "rb").read()), name
+
+
 def test_opt_in_byte_shuffle_roundtrip_and_default_off(tmp_path):
     """--shuffle (not a reference feature): entropy.dat holds the payload as byte planes and says so
     in its trailer (first shape entry 2); this build decodes it; without the flag the stream is the

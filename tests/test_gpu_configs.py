@@ -172,7 +172,25 @@ def test_cfg5_512_dwp_lossless_windows_5_to_40(ctx):
         stop = run / ((idx - k0 + 1) * fe_pad)
         assert stop == pytest.approx(mse[idx], rel=1e-12) and stop <= thr
     assert key.nonzero()[0].tolist() == expect   # a rejected frame becomes the next key frame
-    payload, table, _ = ctx.encode("abs", [0.0], True)
+    # the integer back half of the DWP job vs the C oracle (compress.py:329-373) on the delta tap, and the same job
+    # through the fused kernels (no delta stack in memory)
+    payload, table, delta = ctx.encode("abs", [0.0], True, want_delta=True)
+    assert (delta[key] == 0).all()
+    ref_payload, ref_table = coracle.encode_tail(delta, True)
+    np.testing.assert_array_equal(table, ref_table)
+    np.testing.assert_array_equal(payload, ref_payload)
+    payload = np.array(payload)
+    fused_payload, fused_table, _ = ctx.encode("abs", [0.0], True)
+    np.testing.assert_array_equal(fused_table, table)
+    np.testing.assert_array_equal(fused_payload, payload)
+    # the B = 1 rollout takes other kernels than the batched SWP job (k_convlat on the upper levels): its first window's
+    # predictions to depth 3, and the deltas formed from them, vs the C oracle
+    net = coracle.CPredNet(WTS, CFG.stack_sizes, CFG.R_stack_sizes, 512, 512)
+    cur = coracle.u8_to_f32_frame(frames[0], 512, 512)
+    for d in range(1, min(4, expect[1] if len(expect) > 1 else 4)):
+        cur = net.next(cur)
+        np.testing.assert_array_equal(pred[d], cur, err_msg="depth %d" % d)
+        np.testing.assert_array_equal(delta[d], coracle.delta_frame(cur, frames[d]))
     key_stack = np.zeros_like(frames)
     key_stack[key] = frames[key]
     kd = ctx.rollout_decode(key_stack, 0)

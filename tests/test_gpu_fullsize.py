@@ -99,7 +99,8 @@ def test_cfg4_full_length_on_one_gpu(ctx):
     compared with the C ORACLE at this size -- spatial delta, 1600 offset, histogram, table, remap
     and trailer of the whole 1,006,632,960-element stack (64-bit offsets, multi-block histogram
     merge), payload and table byte for byte (compress.py:329-395) -- plus the quantiser of two whole
-    frames; then the round trip within the bound."""
+    frames and two predicted frames of the first window (the convolutions at 1024x1024); then the round trip within
+    the bound."""
     import torch
     from oracle import coracle
     from oracle import oracle as O
@@ -142,6 +143,15 @@ def test_cfg4_full_length_on_one_gpu(ctx):
     del payload2
     # --- quantiser of two whole frames (3 chains of 1,048,576 elements each) vs the C oracle
     pred = ctx.get_predictions()
+    # --- the predictor itself at this size: the first window's predictions to depth 2 (frame 1 from the key frame,
+    # frame 2 from that prediction: prednet.py:235-308 on 1024x1024 levels), bit for bit vs the C oracle
+    net = coracle.CPredNet(CFG.init_weights(seed=123), CFG.stack_sizes, CFG.R_stack_sizes, 1024, 1024)
+    np.testing.assert_array_equal(pred[0], net.c0())
+    cur = coracle.u8_to_f32_frame(frames[0].cpu().numpy(), 1024, 1024)
+    for d in (1, 2):
+        cur = net.next(cur)
+        np.testing.assert_array_equal(pred[d], cur, err_msg="1024x1024 prediction, depth %d" % d)
+    del net, cur
     for f in (1, 279):
         fr = frames[f].cpu().numpy()
         raw = coracle.delta_frame(pred[f], fr)

@@ -70,6 +70,33 @@ def test_error_bound(ctx, mode, bound):
         np.testing.assert_array_equal(got[i], ref, err_msg="frame %d" % i)
 
 
+@pytest.mark.parametrize("mode,bound", [("abs", [300.0]), ("abs", [700.0]), ("abs", [2.0]), ("abs", [0.49999999999999994]),
+                                        ("rel", [1.5]), ("absrel", [400.0, 3.0])])
+def test_error_bound_takes_any_int16_stack(ctx, mode, bound):
+    """The stand-alone operator is compress.py:23-70 on ANY int16 slab, not only on the [-255, 255] deltas of
+    compress.py:292-314 that the integer walk's width table covers: a tile that holds a wider value evaluates the
+    reference's double test directly.  Diffs of +-2000 and up to the int16 limits, runs wider than 511 that
+    compress.py:60 merges under a tolerance of 300 / 700, wide and narrow tiles side by side (frame 1 keeps
+    some tiles in range), vs the C oracle."""
+    rng = np.random.default_rng(22)
+    n, h, w = 3, 96, 128          # chains of 12,288 elements = 3 tiles of the quantiser
+    orig = _frames(rng, n, h, w)
+    walk = np.round(np.cumsum(rng.normal(0, 40.0, (h * w, 3)), axis=0))
+    d0 = np.clip(walk + rng.integers(-1000, 1001, (h * w, 3)), -2000, 2000).reshape(h, w, 3)
+    d1 = np.clip(np.round(np.cumsum(rng.normal(0, 1.0, (h * w, 3)), axis=0)), -255, 255).reshape(h, w, 3)
+    d1[40:50] += rng.integers(-2000, 2001, (10, w, 3))           # only the middle tile is wide
+    d2 = rng.integers(-32768, 32768, (h, w, 3))
+    d2[::2] = np.clip(d2[::2], -600, 600)
+    diff = np.stack([d0, d1, d2]).astype(np.int16)
+    assert int(np.abs(diff[0]).max()) > 1500 and int(np.abs(diff[1][:30]).max()) <= 255
+    got = ctx.error_bound(orig, diff.copy(), mode, bound)
+    for i in range(n):
+        ref = coracle.error_bound_frame(orig[i], diff[i], mode, bound)
+        np.testing.assert_array_equal(got[i], ref, err_msg="frame %d" % i)
+    if mode == "abs" and bound[0] >= 300:
+        assert (np.diff(got[0].reshape(-1, 3), axis=0) == 0).mean() > 0.5   # runs really merge across widths > 511
+
+
 def _long_chain_cases():
     import os
     from conftest import GOLDEN
@@ -220,6 +247,39 @@ def test_undelta_wraparound_matches_reference_loop(ctx):
     s = rng.integers(-32768, 32768, 10007).astype(np.int16)
     np.testing.assert_array_equal(ctx.spatial_undelta(s), coracle.spatial_undelta(s, 0))
     np.testing.assert_array_equal(ctx.spatial_undelta(s), O.finding_difference_dec(s))
+
+
+def test_inverse_scan_wait_is_bounded_and_fails_loudly(ctx):
+    """k_scan2p's workgroups wait for the block sums of the workgroups in front of them.  The wait is bounded: with the
+    poll pointed at an epoch nobody publishes (tz_scan_fault_inject) every waiting thread gives up after `poll_limit`
+    polls, the launch drains, and the call reports TZ_ERR_HIP instead of hanging the GPU or returning wrong data as
+    good; with a device output the error arrives at the context's next synchronisation.  Afterwards the scan works."""
+    import torch
+    from tezip_amd._lib import TezipError
+    rng = np.random.default_rng(14)
+    s = rng.integers(-300, 300, 3 * 1024 * 1024 + 5).astype(np.int16)     # thousands of wave-tiles: hundreds of blocks
+    want = coracle.spatial_undelta(s, 0)
+    np.testing.assert_array_equal(ctx.spatial_undelta(s), want)
+    ctx.scan_fault_inject(epoch_skew=1, poll_limit=64)
+    try:
+        with pytest.raises(TezipError) as e:
+            ctx.spatial_undelta(s)                                         # host output: the call itself synchronises
+        assert e.value.status == -3 and "k_scan2p" in str(e.value)
+        d_in = torch.from_numpy(s).cuda()
+        d_out = torch.empty_like(d_in)
+        torch.cuda.synchronize()
+        ctx.spatial_undelta(d_in, out=d_out)                               # device output: asynchronous ...
+        with pytest.raises(TezipError):
+            ctx.synchronize()                                              # ... the fault is reported here
+    finally:
+        ctx.scan_fault_inject(0, 0)
+    ctx.synchronize()                                                      # the fault word was consumed
+    np.testing.assert_array_equal(ctx.spatial_undelta(s), want)
+    d_out.zero_()
+    torch.cuda.synchronize()
+    ctx.spatial_undelta(d_in, out=d_out)
+    ctx.synchronize()
+    np.testing.assert_array_equal(d_out.cpu().numpy(), want)
 
 
 def test_unmap_chained_table(ctx):

@@ -39,6 +39,7 @@ _SIGS = {
     "tz_predict_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tz_predict_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "tz_set_conv_impl": (C.c_int, [C.c_void_p, C.c_int]),
+    "tz_scan_fault_inject": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint]),
     "tz_act_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tz_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                              C.c_void_p, C.c_void_p]),
@@ -302,6 +303,10 @@ class Context:
         lat: None = k_convlat where the cost model picks it (default), "never", "always"."""
         code = {None: 0, "never": 1, "always": 2}[lat]
         self._ck(self.lib.tz_set_conv_impl(self.h, int(bool(lds_dma)) | (code << 1)))
+
+    def scan_fault_inject(self, epoch_skew=0, poll_limit=0):
+        """Diagnostic: make the inverse scan's bounded wait expire (see tz_scan_fault_inject); (0, 0) = normal."""
+        self._ck(self.lib.tz_scan_fault_inject(self.h, int(epoch_skew), int(poll_limit)))
 
     # ---- rollout + encode / decode
     @staticmethod

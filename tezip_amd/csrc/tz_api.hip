@@ -20,6 +20,47 @@ int tz_fail(tz_ctx* ctx, int status, const char* fmt, ...) {
     return status;
 }
 
+// Kernels whose waits are hand-built (k_scan2p polls status words of other workgroups) bound those waits and report an
+// expiry here instead of hanging the GPU: one pinned host word the device can write.
+int tz_fault_word(tz_ctx* ctx) {
+    if (ctx->h_fault) return TZ_OK;
+    void* h = nullptr;
+    TZ_HIP(ctx, hipHostMalloc(&h, sizeof(unsigned), hipHostMallocMapped));
+    *(volatile unsigned*)h = 0;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+        (void)hipHostFree(h);
+        return tz_fail(ctx, TZ_ERR_HIP, "no device pointer for the fault word");
+    }
+    ctx->h_fault = (volatile unsigned*)h;
+    ctx->d_fault = (unsigned*)d;
+    return TZ_OK;
+}
+
+int tz_stream_sync(tz_ctx* ctx) {
+    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_fault && *ctx->h_fault) {
+        const unsigned f = *ctx->h_fault;
+        *ctx->h_fault = 0;
+        if (f & TZ_FAULT_SCAN_POLL)
+            return tz_fail(ctx, TZ_ERR_HIP,
+                           "inverse scan (k_scan2p): a workgroup gave up waiting for the block sum of a workgroup in front of it "
+                           "(workgroups not dispatched in index order?); the scanned output of that launch is invalid");
+        return tz_fail(ctx, TZ_ERR_HIP, "a kernel reported fault 0x%x", f);
+    }
+    return TZ_OK;
+}
+
+// diagnostic: makes the next inverse scans poll for the epoch `epoch_skew` launches ahead (never published when != 0) and
+// give up after `poll_limit` polls (0 = the built-in 2^22); (0, 0) restores normal operation.  tests/test_gpu_parity.py
+// uses it to see the bounded wait fail loudly.
+extern "C" int tz_scan_fault_inject(tz_ctx* ctx, unsigned epoch_skew, unsigned poll_limit) {
+    if (!ctx) return TZ_ERR_INVALID;
+    ctx->scan_dbg_skew = epoch_skew & 0xFFFFu;
+    ctx->scan_dbg_limit = poll_limit;
+    return TZ_OK;
+}
+
 extern "C" int tz_version(void) { return 100; }
 
 extern "C" const char* tz_strerror(int s) {
@@ -105,6 +146,7 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
     if (ctx->d_payload) (void)hipFree(ctx->d_payload);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_scan_status) (void)hipFree(ctx->d_scan_status);
+    if (ctx->h_fault) (void)hipHostFree((void*)ctx->h_fault);
     for (auto& s : ctx->prof)
         for (auto& e : s.pending) {
             (void)hipEventDestroy(e.first);
@@ -138,8 +180,7 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
 
 extern "C" int tz_ctx_synchronize(tz_ctx* ctx) {
     if (!ctx) return TZ_ERR_INVALID;
-    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return TZ_OK;
+    return tz_stream_sync(ctx);
 }
 
 extern "C" void* tz_ctx_stream(tz_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -383,7 +424,7 @@ int tz_dev_out_finish(tz_ctx* ctx, std::vector<tz_out>& outs) {
             TZ_TRY(tz_d2h(ctx, o.host, o.dev, o.bytes, ctx->stream));
             any = true;
         }
-    if (any) TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (any) TZ_TRY(tz_stream_sync(ctx));
     return TZ_OK;
 }
 
@@ -834,6 +875,7 @@ extern "C" int tz_frames_get(tz_ctx* ctx, int first, int count, uint8_t* out) {
 
 extern "C" int tz_payload_begin(tz_ctx* ctx, size_t count) {
     if (!ctx) return TZ_ERR_INVALID;
+    ctx->enc_pending = false;   // the resident symbols of a tz_encode_begin are about to be overwritten
     TZ_TRY(tz_ensure(ctx, (void**)&ctx->d_payload, &ctx->cap_payload, std::max<size_t>(count, 8) * 2));
     ctx->payload_len = count;
     TZ_HIP(ctx, hipEventRecord(ctx->ev_compute, ctx->stream));  // earlier work may still read the old payload
@@ -853,8 +895,7 @@ extern "C" int tz_decoded_get(tz_ctx* ctx, int first, int count, uint8_t* out) {
         return tz_fail(ctx, TZ_ERR_INVALID, "frames [%d, %d) outside the resident decoded stack", first, first + count);
     const size_t fsz = (size_t)ctx->H * ctx->W * 3;
     TZ_TRY(tz_d2h(ctx, out, ctx->d_out + (size_t)first * fsz, (size_t)count * fsz, ctx->stream));
-    TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return TZ_OK;
+    return tz_stream_sync(ctx);
 }
 
 extern "C" int tz_payload_get(tz_ctx* ctx, size_t offset, size_t count, int16_t* out) {
@@ -868,6 +909,7 @@ extern "C" int tz_payload_get(tz_ctx* ctx, size_t offset, size_t count, int16_t*
 extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int W, int warm_up, int window,
                           double threshold, uint8_t* key_mask, double* mse_log) {
     if (!ctx) return TZ_ERR_INVALID;
+    ctx->enc_pending = false;   // a tz_encode_begin belongs to the rollout before it
     if (window < 0) return tz_fail(ctx, TZ_ERR_INVALID, "window must be >= 0");
     if (nt < warm_up + 2)  // the reference breaks here
         return tz_fail(ctx, TZ_ERR_INVALID, "need at least warm_up+2 frames (nt=%d, warm_up=%d)", nt, warm_up);
@@ -1020,6 +1062,7 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
 extern "C" int tz_rollout_decode(tz_ctx* ctx, const uint8_t* key_frames, int nt, int H, int W, int warm_up,
                                  uint8_t* key_mask) {
     if (!ctx) return TZ_ERR_INVALID;
+    ctx->enc_pending = false;
     int rc = rollout_setup(ctx, key_frames, nt, H, W, warm_up);
     if (rc != TZ_OK) return rc;
     // decompress.py:123-129: a frame is a key frame iff it has a non-zero sample
@@ -1310,6 +1353,10 @@ extern "C" int tz_encode_finish(tz_ctx* ctx, int has_carry, int16_t carry, const
     if (ctx->enc_entropy != (table_len >= 0) || (table_len > 0 && !table) || table_len > TZ_MAX_TABLE)
         return tz_fail(ctx, TZ_ERR_INVALID, "tz_encode_finish: table does not match the entropy flag of tz_encode_begin");
     const size_t N = ctx->payload_len;
+    if (!ctx->have_rollout || ctx->rollout_is_decode || N != (size_t)ctx->nt * ctx->H * ctx->W * 3) {
+        ctx->enc_pending = false;
+        return tz_fail(ctx, TZ_ERR_STATE, "tz_encode_finish: the resident symbols (%zu) are not those of the current rollout", N);
+    }
     int rc = TZ_OK;
     if (has_carry) {
         // the first element of the shard: sd = carry - x[0] instead of x[0] (compress.py:73-77 across the boundary)

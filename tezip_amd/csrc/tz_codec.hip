@@ -571,6 +571,10 @@ __global__ __launch_bounds__(192) void k_q_tiles(QSrc src, const uint8_t* __rest
     // samples with a stride of three touched every cache line three times, 2-byte / 4-byte accesses: 141 of the
     // first version's 280 us.)
     const bool grouped = (HW & 3) == 0 && (((uintptr_t)src.pred & 15) | ((uintptr_t)src.diff & 7) | ((uintptr_t)orig & 3) | ((uintptr_t)tmp & 7)) == 0;
+    // The integer walk below rests on k_q_width's table, which covers deltas in [-255, 255] -- everything compress.py:292-314
+    // can produce.  The stand-alone tz_error_bound takes ANY int16 stack: a tile that holds a value outside that range
+    // (`wide`) evaluates the double test of compress.py:60 itself at every step instead.
+    int wide = 0;
     if (grouped) {
         const int npix = min(QT_TILE, HW - e0);
         for (int g = threadIdx.x; g < QT_TILE / 4; g += 192) {
@@ -597,7 +601,10 @@ __global__ __launch_bounds__(192) void k_q_tiles(QSrc src, const uint8_t* __rest
                     const uint2 a0 = dp[0], a1 = dp[1], a2 = dp[2];
                     const unsigned dw[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
 #pragma unroll
-                    for (int k = 0; k < 12; ++k) d[k] = (int)(short)((dw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+                    for (int k = 0; k < 12; ++k) {
+                        d[k] = (int)(short)((dw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+                        wide |= (unsigned)(d[k] + 255) > 510u;
+                    }
                 }
             }
             const int row = p0 >> 6, col = p0 & 63;
@@ -614,7 +621,8 @@ __global__ __launch_bounds__(192) void k_q_tiles(QSrc src, const uint8_t* __rest
                 }
             }
         }
-        __syncthreads();
+        if (FP || PW) __syncthreads();
+        else wide = __syncthreads_or(wide);
     } else {
 #pragma unroll 8
         for (int r = 0; r < 64; ++r) {
@@ -624,6 +632,7 @@ __global__ __launch_bounds__(192) void k_q_tiles(QSrc src, const uint8_t* __rest
                 const size_t e = fe0 + (size_t)idx * 3 + c;
                 d = q_delta<FP>(src, orig, e);
                 if (PW) o = orig[e];
+                if (!FP && !PW) wide |= (unsigned)(d + 255) > 510u;
             }
             if (PW) lw[r * QT_S32 + lane] = ((unsigned)d & 0xFFFFu) | ((unsigned)o << 16);
             else ls[r * QT_S16 + lane] = (short)d;
@@ -641,6 +650,10 @@ __global__ __launch_bounds__(192) void k_q_tiles(QSrc src, const uint8_t* __rest
         const QWidth wd = width[chain];
         wmin = wd.wmin;
         wmax = wd.wmax;
+        if (!FP && __any(wide)) {   // no width is taken from the table: "ambiguous" always, q_ok_exact decides
+            wmin = -1;
+            wmax = 0x7FFFFFFF;
+        }
     }
     const double inf = __builtin_huge_val();
     // element access and the run algebra of the two arithmetic forms
@@ -1775,6 +1788,8 @@ int tzk_shuffle(tz_ctx* ctx, const int16_t* in, size_t n, uint8_t* out, int inve
 // Progress: a block waits for lower-numbered blocks only, and the workgroups of a launch start in index order
 // (per XCD), so the lowest-numbered unfinished block is always running and waits for nothing unfinished -- also
 // when the grid is larger than what the chip holds at once (it is: two rounds measured fastest).
+static constexpr unsigned SCAN_POLL_LIMIT = 1u << 22;   // polls of ONE status word before a thread gives up (a healthy wait is
+                                                        // tens of polls; 2^22 L2 round trips are seconds)
 static constexpr int SCAN_EPT = 16;                 // elements per thread
 static constexpr int SCAN_G = 4096;                 // blocks of a launch: two rounds of the 2048 the chip holds (measured at
                                                     // 62.9 M elements, fused tail: 1024 108 us, 2048 107, 4096 96, 8192 110)
@@ -1864,7 +1879,8 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
 template <bool LUT, bool RECON>
 __global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, size_t n, int wtiles, int has_carry,
                                                 int16_t carry, int vec, const int16_t* __restrict__ lut, int post_offset,
-                                                unsigned* __restrict__ status, unsigned epoch, int16_t* __restrict__ out,
+                                                unsigned* __restrict__ status, unsigned epoch, unsigned poll_epoch,
+                                                unsigned poll_limit, unsigned* __restrict__ fault, int16_t* __restrict__ out,
                                                 const ScanRecon rc) {
     __shared__ int16_t sl[LUT ? TZ_NBINS + 1 : 1];
     __shared__ unsigned wsum[4];
@@ -1894,10 +1910,20 @@ __global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, 
     }
     if (threadIdx.x == 0) st_store(&status[g], epoch << 16 | (tot & 0xFFFFu));
     // (2) the sums of the blocks in front: thread t takes blocks t, t + 256, ...
+    // The poll is BOUNDED: the argument above rests on the dispatch order of today's hardware, which HIP does not
+    // promise.  A thread that has polled one word poll_limit times gives up, says so in the context's fault word (pinned
+    // host memory, read by the host at its next synchronisation: TZ_ERR_HIP) and goes on with a wrong sum -- every block
+    // has published its own sum BEFORE it polls, so a launch always drains.
     unsigned mine = 0;
     for (int b = threadIdx.x; b < g; b += 256) {
-        unsigned w = st_load(&status[b]);
-        while ((w >> 16) != epoch) w = st_load(&status[b]);
+        unsigned w = st_load(&status[b]), spins = 0;
+        while ((w >> 16) != poll_epoch) {
+            if (++spins > poll_limit) {
+                *(volatile unsigned*)fault = TZ_FAULT_SCAN_POLL;
+                break;
+            }
+            w = st_load(&status[b]);
+        }
         mine += w & 0xFFFFu;
     }
     unsigned run;
@@ -1998,6 +2024,7 @@ static int scan_launch(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, 
         TZ_TRY(tz_upload(ctx, d_lut, h_lut2112, (TZ_NBINS + 1) * 2));
     }
     if (!ctx->d_scan_status) TZ_HIP(ctx, hipMalloc((void**)&ctx->d_scan_status, sizeof(unsigned) * SCAN_G));
+    TZ_TRY(tz_fault_word(ctx));
     tz_prof_scope ps(ctx, TZP_SCAN);
     if (ctx->scan_epoch == 0 || ctx->scan_epoch == 0xFFFFu) {   // first launch, or the epochs have gone round
         TZ_HIP(ctx, hipMemsetAsync(ctx->d_scan_status, 0, sizeof(unsigned) * SCAN_G, ctx->stream));
@@ -2008,7 +2035,8 @@ static int scan_launch(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, 
     const ScanRecon none = {};
 #define TZ_SCAN_LAUNCH(L, R)                                                                                              \
     hipLaunchKernelGGL((k_scan2p<L, R>), dim3(G), dim3(256), 0, ctx->stream, in, n, (int)tpb, has_carry, carry, vec,      \
-                       (const int16_t*)d_lut, post_offset, ctx->d_scan_status, epoch, out, recon ? *recon : none)
+                       (const int16_t*)d_lut, post_offset, ctx->d_scan_status, epoch, (epoch + ctx->scan_dbg_skew) & 0xFFFFu,       \
+                       ctx->scan_dbg_limit ? ctx->scan_dbg_limit : SCAN_POLL_LIMIT, ctx->d_fault, out, recon ? *recon : none)
     if (recon) {
         if (h_lut2112) TZ_SCAN_LAUNCH(true, true);
         else TZ_SCAN_LAUNCH(false, true);

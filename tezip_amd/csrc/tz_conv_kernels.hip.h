@@ -592,11 +592,19 @@ __device__ __forceinline__ void glds16_lanes(const float* ubase, unsigned voff, 
 
 // ... and the gather form of the same: lane i fetches 16 bytes from ubase + voff_i if bit i of `mask` is set and
 // does nothing otherwise (its LDS slot keeps what it holds: k_conv16 zeroes the slots of out-of-image pixels once
-// per workgroup).  The wave runs with all lanes enabled around it.
+// per workgroup).  The block saves the wave's exec mask in a scalar pair of its own and puts it back (until round 3 it
+// ended with `exec = -1`, i.e. assumed a fully enabled wave around it).
+// m0 and exec cannot be DECLARED: hipcc (roc-7.2.0) answers a "m0" / "exec" clobber with "inline asm clobber list contains
+// reserved registers ... may not be preserved across the asm statement, and clobbering them may lead to undefined
+// behaviour" and ignores it.  What makes the blocks safe instead: the compiler treats m0 as reserved and loads it itself
+// in front of every instruction of its own that reads it (LDS-DMA builtins, s_movrel, ...), and exec is back to its value
+// before the block ends.
 __device__ __forceinline__ void glds16_gather(const float* ubase, unsigned voff, unsigned long long mask, const float* l) {
     const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)l);
-    asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
-                 : : "v"(voff), "s"(ubase), "s"(la), "s"(mask) : "memory");
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(voff), "s"(ubase), "s"(la), "s"(mask) : "memory");
 }
 
 // waits for all of this wave's vector-memory operations (LDS-DMA included)

@@ -92,6 +92,11 @@ struct tz_ctx {
     size_t cap_payload = 0, payload_len = 0;
     unsigned* d_scan_status = nullptr;      // inverse scan: one word per resident block, tagged with the launch's epoch
     unsigned scan_epoch = 0;
+    unsigned scan_dbg_skew = 0, scan_dbg_limit = 0;   // tz_scan_fault_inject: poll for another epoch / give up sooner
+    // fault word: one pinned, device-visible host word that a kernel with a hand-built wait sets when the wait expires
+    // (k_scan2p's bounded poll); the host reads it behind every stream synchronisation (tz_stream_sync)
+    volatile unsigned* h_fault = nullptr;
+    unsigned* d_fault = nullptr;
     int decode_unfused = 0;                 // TEZIP_DECODE_UNFUSED=1: tz_decode as scan + reconstruct launches (cross-check)
     uint8_t* d_out = nullptr;               // resident decoded frames of a tz_decode(frames_out = NULL)
     size_t cap_out = 0;
@@ -108,6 +113,9 @@ struct tz_ctx {
 };
 
 int tz_fail(tz_ctx* ctx, int status, const char* fmt, ...);
+static constexpr unsigned TZ_FAULT_SCAN_POLL = 1u;   // k_scan2p: a status word never showed the launch's epoch
+int tz_fault_word(tz_ctx* ctx);      // makes the fault word on first use
+int tz_stream_sync(tz_ctx* ctx);     // hipStreamSynchronize(ctx->stream) + TZ_ERR_HIP if a kernel reported a fault
 
 #define TZ_HIP(ctx, expr)                                                                      \
     do {                                                                                       \

@@ -43,24 +43,41 @@ def sweep(ctx, frames, warm_up, windows, mode, bound, entropy=True, keep_best=Tr
     return rows, (best[0]["window"], best[1], best[2])
 
 
-def sweep_sharded(ctx, frames, warm_up, windows, mode, bound, entropy=True):
+def sweep_sharded(ctx, frames, warm_up, windows, mode, bound, entropy=True, ctx_error=None):
     """The same over the ranks of a torch.distributed job: rank r takes windows[r::world]; the
     sizes are all-gathered; returns (rows of every candidate sorted by window, best_window,
-    (key bytes, entropy bytes) on the rank that holds the best candidate else None)."""
+    (key bytes, entropy bytes) on the rank that holds the best candidate else None).
+    `ctx_error`: the exception this rank met while making its context (ctx is then None); it is
+    reported to the other ranks through the all_gather like a failure of the sweep itself."""
     job = tzdist.active()
     if job is None:
+        if ctx_error is not None:
+            raise ctx_error
         rows, (bw, kb, eb) = sweep(ctx, frames, warm_up, windows, mode, bound, entropy)
         return rows, bw, (kb, eb)
     import torch.distributed as dist
     rank, world = job
     mine = list(windows)[rank::world]
-    rows, best = (sweep(ctx, frames, warm_up, mine, mode, bound, entropy) if mine else ([], (None, None, None)))
+    # a rank whose candidates fail (out of memory, a TezipError, a bad window size) still enters the all_gather and
+    # says so in its first element: the others raise a RuntimeError instead of waiting for the watchdog (dist.py)
+    rows, best, err = [], (None, None, None), ctx_error
+    try:
+        if mine and err is None:
+            rows, best = sweep(ctx, frames, warm_up, mine, mode, bound, entropy)
+    except Exception as e:
+        rows, err = [], e
     per = max(1, (len(windows) + world - 1) // world)
-    flat = np.full(per * 4, -1, np.int64)
+    flat = np.full(1 + per * 4, -1, np.int64)
+    flat[0] = 1 if err is None else 0
     for i, r in enumerate(rows):
-        flat[4 * i: 4 * i + 4] = [r["window"], r["key_frames"], r["key_bytes"], r["entropy_bytes"]]
+        flat[1 + 4 * i: 5 + 4 * i] = [r["window"], r["key_frames"], r["key_bytes"], r["entropy_bytes"]]
+    gathered = tzdist._all_gather_i64(flat.tolist(), dist)
+    if err is not None:
+        raise err
+    tzdist._raise_if_any_failed([int(v[0]) for v in gathered], "window sweep")
     allrows = []
-    for v in tzdist._all_gather_i64(flat.tolist(), dist):
+    for v in gathered:
+        v = v[1:]
         for i in range(per):
             wv, kf, kbytes, ebytes = (int(x) for x in v[4 * i: 4 * i + 4])
             if wv > 0:
@@ -92,17 +109,36 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOWS, MODE, BOUND_VALU
     job = tzdist.active()
     if job:
         device = tzdist.init_from_env()
-    ctx = make_context(cfg, wts, hp, wp, 1, device)
+    ctx, ctx_error = None, None
     try:
-        rows, bw, blobs = sweep_sharded(ctx, frames, PREPROCESS, list(WINDOWS or DEFAULT_WINDOWS), MODE, BOUND_VALUE, ENTROPY_RUN)
+        ctx = make_context(cfg, wts, hp, wp, 1, device)
+    except Exception as e:  # the other ranks are on their way into a collective: tell them there
+        ctx_error = e
+    try:
+        rows, bw, blobs = sweep_sharded(ctx, frames, PREPROCESS, list(WINDOWS or DEFAULT_WINDOWS), MODE, BOUND_VALUE,
+                                        ENTROPY_RUN, ctx_error=ctx_error)
     finally:
-        ctx.close()
+        if ctx is not None:
+            ctx.close()
     rank0 = job is None or job[0] == 0
+    mk_error = None
     if rank0 and not os.path.exists(OUTPUT_DIR):
-        os.mkdir(OUTPUT_DIR)
+        try:
+            os.mkdir(OUTPUT_DIR)
+        except OSError as e:
+            mk_error = e
     if job:
         import torch.distributed as dist
-        dist.barrier()  # the directory exists before the owner of the best candidate writes into it
+        # the directory exists before the owner of the best candidate writes into it (and if it could not be made
+        # every rank stops here)
+        try:
+            tzdist._all_ok(mk_error is None, dist, "creating the output directory")
+        except RuntimeError:
+            if mk_error is not None:
+                raise mk_error
+            raise
+    elif mk_error is not None:
+        raise mk_error
     if blobs is not None:
         with open(os.path.join(OUTPUT_DIR, "key_frame.dat"), "wb") as f:
             f.write(blobs[0])
