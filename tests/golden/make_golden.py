@@ -15,7 +15,10 @@ What it does:
     predictor itself is unpinned) and `zstd` replaced by the identity, so
     the recorded `entropy.dat` / `key_frame.dat` are the PRE-zstd byte streams.
 
-Run:  /opt/conda/bin/python3.9 tests/golden/make_golden.py
+  * (round 4) runs the reference's train_data_create.process_data and data_utils.SequenceGenerator on a small PNG
+    tree (hickle.dump captured, keras' Iterator replaced by a sequential stand-in) -> ref_train.npz.
+
+Run:  /opt/conda/bin/python3.9 tests/golden/make_golden.py      (--train-only: just ref_train.npz)
 (python3.9 + numpy 1.26 because the reference calls ndarray.tostring(), removed in numpy 2.)
 Nothing from the reference's source text is written to the fixtures: only arrays.
 """
@@ -412,8 +415,119 @@ def _runs(compress, decompress, out, runs=None, seed=777, make_frames=None):
             shutil.rmtree(tmp, ignore_errors=True)
 
 
+# ---- round 4: the training-data side -----------------------------------------------------
+class _SeqIterator:
+    """Stand-in for keras.preprocessing.image.Iterator (Keras 2.2.4, absent here) with the behaviour
+    data_utils.SequenceGenerator relies on: n, batch_size, a lock, batch_index and an index generator that walks
+    arange(n) (a permutation when shuffle) in batches, wrapping around."""
+
+    def __init__(self, n, batch_size, shuffle, seed):
+        import threading
+        self.n, self.batch_size, self.shuffle, self.seed = n, batch_size, shuffle, seed
+        self.batch_index, self.total_batches_seen, self.lock = 0, 0, threading.Lock()
+        self.index_generator = self._flow_index()
+
+    def _flow_index(self):
+        self.batch_index = 0
+        while True:
+            if self.batch_index == 0:
+                self.index_array = np.random.permutation(self.n) if self.shuffle else np.arange(self.n)
+            cur = (self.batch_index * self.batch_size) % self.n
+            self.batch_index = self.batch_index + 1 if self.n > cur + self.batch_size else 0
+            self.total_batches_seen += 1
+            yield self.index_array[cur: cur + self.batch_size]
+
+
+TRAIN_TREE = [
+    # folder, number of images, H, W, grayscale
+    ("seq_a", 6, 13, 19, False),
+    ("seq_b", 5, 16, 24, False),
+    ("seq_c", 7, 11, 22, True),
+    ("seq_d", 4, 16, 17, False),
+    ("seq_e", 5, 9, 24, False),
+]
+
+
+def _train_fixture(out):
+    """train_data_create.process_data (train_data_create.py:11-95) and data_utils.SequenceGenerator
+    (data_utils.py:8-71) of the REFERENCE on a small PNG tree: hickle.dump is captured, hickle.load answers from
+    the capture, keras' Iterator is the stand-in above.  Recorded: the images of the tree, what the reference
+    stacked per split (explicit validation folders; the random split under random.seed(5)), possible_starts in
+    both start modes / with N_seq, and two batches."""
+    import random
+    from PIL import Image
+    store = {}
+    sys.modules["hickle"].dump = lambda obj, path, **k: store.__setitem__(path, obj)
+    sys.modules["hickle"].load = lambda path: store[path]
+    sys.modules["keras.preprocessing.image"].Iterator = _SeqIterator
+    for m in ("train_data_create", "data_utils"):
+        sys.modules.pop(m, None)
+    import train_data_create
+    import data_utils
+    rng = np.random.default_rng(20261006)
+    tmp = tempfile.mkdtemp(prefix="tztrain_")
+    stdout = sys.stdout
+    try:
+        ddir = os.path.join(tmp, "data")
+        os.mkdir(ddir)
+        out["tr_folders"] = np.array([t[0] for t in TRAIN_TREE])
+        for folder, n, h, w, gray in TRAIN_TREE:
+            os.mkdir(os.path.join(ddir, folder))
+            imgs = rng.integers(0, 256, size=(n, h, w) if gray else (n, h, w, 3)).astype(np.uint8)
+            out["tr_img_" + folder] = imgs
+            for i in range(n):
+                Image.fromarray(imgs[i], mode="L" if gray else "RGB").save(os.path.join(ddir, folder, "im_%02d.png" % i))
+        sys.stdout = io.StringIO()
+        # (1) explicit validation folders (-v): train = set(folders) ^ set(val), in whatever order set() iterates
+        o1 = os.path.join(tmp, "o1")
+        os.mkdir(o1)
+        train_data_create.args = types.SimpleNamespace(val_dir_path=[os.path.join(ddir, "seq_b"), os.path.join(ddir, "seq_e")])
+        train_data_create.process_data(ddir, o1)
+        # (2) the random split (train_data_create.py:26-35)
+        o2 = os.path.join(tmp, "o2")
+        os.mkdir(o2)
+        train_data_create.args = types.SimpleNamespace(val_dir_path=None)
+        random.seed(5)
+        train_data_create.process_data(ddir, o2)
+        log = sys.stdout.getvalue()
+        sys.stdout = stdout
+        for tag, od in (("v", o1), ("r", o2)):
+            for split in ("train", "val"):
+                out["tr_%s_X_%s" % (tag, split)] = store[os.path.join(od, "X_%s.hkl" % split)]
+                out["tr_%s_src_%s" % (tag, split)] = np.array(store[os.path.join(od, "sources_%s.hkl" % split)])
+        out["tr_log"] = np.array(log)
+        # (3) SequenceGenerator on (1)'s training files
+        xf, sf = os.path.join(o1, "X_train.hkl"), os.path.join(o1, "sources_train.hkl")
+        for nt in (2, 3, 5):
+            g = data_utils.SequenceGenerator(xf, sf, nt, batch_size=2, shuffle=False, data_format="channels_last")
+            out["sg_all_nt%d" % nt] = np.asarray(g.possible_starts, dtype=np.int64)
+            gu = data_utils.SequenceGenerator(xf, sf, nt, batch_size=2, shuffle=False, sequence_start_mode="unique",
+                                              data_format="channels_last")
+            out["sg_unique_nt%d" % nt] = np.asarray(gu.possible_starts, dtype=np.int64)
+        g = data_utils.SequenceGenerator(xf, sf, 2, batch_size=1, N_seq=2, data_format="channels_last")   # train.py:90
+        out["sg_nseq2"] = np.asarray(g.possible_starts, dtype=np.int64)
+        assert g.N_sequences == 2
+        g = data_utils.SequenceGenerator(xf, sf, 3, batch_size=2, shuffle=False, data_format="channels_last")
+        bx, by = g.next()
+        out["sg_batch0_x"], out["sg_batch0_y"] = bx, by
+        bx, by = g[None]
+        out["sg_batch1_x"] = bx
+        out["sg_im_shape"] = np.array(g.im_shape)
+        print("train fixture: train sources", list(dict.fromkeys(out["tr_v_src_train"].tolist())), "| random val",
+              list(dict.fromkeys(out["tr_r_src_val"].tolist())), "| starts nt=3:", out["sg_all_nt3"].tolist())
+    finally:
+        sys.stdout = stdout
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     _install_stubs()
+    if "--train-only" in sys.argv:
+        tr = {}
+        _train_fixture(tr)
+        np.savez_compressed(os.path.join(HERE, "ref_train.npz"), **tr)
+        print("ref_train.npz:", len(tr), "arrays")
+        return
     import compress
     import decompress
     import data_utils
@@ -442,6 +556,10 @@ def main():
     _runs(compress, decompress, runs3, RUNS_3, seed=779)
     np.savez_compressed(os.path.join(HERE, "ref_runs3.npz"), **runs3)
     print("ref_runs3.npz:", len(runs3), "arrays")
+    tr = {}
+    _train_fixture(tr)
+    np.savez_compressed(os.path.join(HERE, "ref_train.npz"), **tr)
+    print("ref_train.npz:", len(tr), "arrays")
 
 
 if __name__ == "__main__":

@@ -163,8 +163,8 @@ def test_sweep_under_torchrun_writes_the_files_of_one_process(tmp_path):
     s.close()
     env = dict(os.environ, TEZIP_DIST_BACKEND="gloo", TEZIP_SINGLE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), "-m", "tezip_amd.tezip", "-c", mdir, ddir, two, "--sweep", "5", "10",
-           "20", "40", "-m", "abs", "-b", "0"]
+           "127.0.0.1", "--master-port", str(port), "-m", "tezip_amd.tezip", "-c", mdir, ddir, two, "-p", "0", "--sweep", "5",
+           "10", "20", "40", "-m", "abs", "-b", "0"]
     r = subprocess.run(cmd, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

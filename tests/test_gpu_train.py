@@ -62,6 +62,29 @@ def test_learn_then_compress_then_uncompress_on_the_gpu(tmp_path):
     _cli(["-u", mdir, cdir, udir])
     got = np.stack([np.array(Image.open(os.path.join(udir, "f%03d.png" % t))) for t in range(12)])
     assert np.array_equal(got, test)                            # lossless
+    # ... and with the weights `-l` just trained the files hold exactly the ORACLE's streams (trained weights are not the
+    # near-constant glorot predictions the other parity tests see: the whole predictor + codec chain on a real model)
+    from oracle import coracle
+    from oracle import oracle as O
+
+    class P:
+        net = coracle.CPredNet(trained, cfg.stack_sizes, cfg.R_stack_sizes, 64, 96)
+
+        def c0(self, a, b):
+            return self.net.c0()
+
+        def next(self, f):
+            return self.net.next(np.asarray(f, np.float32))
+
+    for mode, bound, sub in (("abs", [0.0], cdir), ("abs", [2.0], str(tmp_path / "comp_abs2"))):
+        if sub != cdir:
+            _cli(["-c", mdir, ddir, sub, "-p", "0", "-w", "6", "-m", mode, "-b", "2"])
+        ref = O.compress_oracle(test, 0, 6, None, mode, bound, P(), True)
+        stream = np.frombuffer(zstd.decompress(open(os.path.join(sub, "entropy.dat"), "rb").read()), "<i2")
+        keyb = np.frombuffer(zstd.decompress(open(os.path.join(sub, "key_frame.dat"), "rb").read()), np.uint8)
+        np.testing.assert_array_equal(stream, ref["stream"], err_msg="pre-zstd entropy stream, %s %r" % (mode, bound))
+        np.testing.assert_array_equal(keyb, ref["key_frame"])
+    assert int(np.abs(np.diff(P.net.next(coracle.u8_to_f32_frame(test[0], 64, 96)), axis=1)).max() * 255) > 3  # not a constant image
     # the same frames with untrained weights of the same architecture compress worse
     rdir = str(tmp_path / "random_model")
     weights.save_model(rdir, cfg, cfg.init_weights(seed=123), 64, 96)

@@ -97,9 +97,32 @@ def build_model(cfg, weight_list=None, seed=123):
     return PredNetTorch()
 
 
-def possible_starts(sources, nt):
-    """data_utils.py:29-30 (sequence_start_mode='all')."""
-    return np.array([i for i in range(len(sources) - nt) if sources[i] == sources[i + nt - 1]], dtype=np.int64)
+def possible_starts(sources, nt, mode="all", N_seq=None):
+    """data_utils.py:28-45.  'all' (what train.py uses): every start whose nt frames come from one source -- the
+    reference iterates range(N - nt), so the last valid start is never offered (kept); 'unique': each frame in at most one
+    sequence; N_seq keeps the first N_seq of them (the validation generator of train.py:90).  Pinned to the reference's own
+    SequenceGenerator by tests/golden/ref_train.npz."""
+    n = len(sources)
+    if mode == "all":
+        starts = [i for i in range(n - nt) if sources[i] == sources[i + nt - 1]]
+    elif mode == "unique":
+        starts, cur = [], 0
+        while cur < n - nt + 1:
+            if sources[cur] == sources[cur + nt - 1]:
+                starts.append(cur)
+                cur += nt
+            else:
+                cur += 1
+    else:
+        raise ValueError("sequence_start_mode must be in {all, unique}")
+    if N_seq is not None and len(starts) > N_seq:
+        starts = starts[:N_seq]
+    return np.array(starts, dtype=np.int64)
+
+
+def sample(X, start, nt):
+    """One training sample (data_utils.py:58-61,70-71): nt consecutive frames as float32 / 255, channels last."""
+    return np.asarray(X[start:start + nt]).astype(np.float32) / 255
 
 
 def l0_loss(errors, nt):
@@ -135,14 +158,13 @@ def run(WEIGHTS_DIR, DATA_DIR, VERBOSE, nb_epoch=100, samples_per_epoch=5, N_seq
     model = build_model(cfg, seed=seed).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-7)
     starts = rng.permutation(possible_starts(src, nt))
-    vstarts = possible_starts(srcv, nt)[:N_seq_val]
+    vstarts = possible_starts(srcv, nt, N_seq=N_seq_val)
     if len(starts) == 0 or len(vstarts) == 0:
         print("ERROR: not enough consecutive frames per folder for nt =", nt)
         exit()
 
     def batch(arr, i):
-        x = torch.from_numpy(np.ascontiguousarray(arr[i:i + nt])).to(dev).float().div_(255)
-        return x.permute(0, 3, 1, 2)[None]
+        return torch.from_numpy(sample(arr, i, nt)).to(dev).permute(0, 3, 1, 2)[None]
 
     os.makedirs(WEIGHTS_DIR, exist_ok=True)
     best, cursor, history = float("inf"), 0, []
