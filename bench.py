@@ -509,6 +509,23 @@ def main():
             except Exception as e:
                 extras["sharded_path"] = {"error": repr(e)}
 
+        # ------------------------------------------------------------ the other BASELINE.json configurations (seconds each)
+        if world == 1:
+            try:
+                extras["configs"] = configs_leg(job, ctx, cfg, frames, dev)
+            except Exception as e:
+                extras["configs"] = {"error": repr(e)}
+            ctx.prepare(H, W, max_batch=nwin)
+        try:   # configs[4] as a search, every N: one candidate window size per rank and turn
+            f3 = turbulence_cuda(NT, 0, NT, H, W, 3, dev).cpu().numpy()
+            extras["cfg5_sweep"] = cfg5_sweep(job, ctx, f3, world)
+            del f3
+        except Exception as e:
+            extras["cfg5_sweep"] = {"error": repr(e)}
+            if dist:
+                raise
+        ctx.prepare(H, W, max_batch=nwin)
+
         # ------------------------------------------------------------ the compression-ratio half of the metric, with a TRAINED model
         if world == 1 and not args.no_trained_ratio:
             try:
@@ -560,6 +577,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "value_definition": "device-resident: frames already in HBM when the clock starts, payload left in HBM, table on the "
+                                "host (the task contract's definition of `value`); SURVEY.md 8d / BASELINE.md 4 define frames/s "
+                                "host to host -- that rate is value_host_to_host (pinned buffers) and the host_to_host object",
+            "value_host_to_host": (extras.get("host_to_host") or {}).get("pinned_frames_per_s"),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -690,12 +711,119 @@ def sharded_path_n1(job, ctx, engine, frames, own_state, fused_value, args, dev)
         same = bool(torch.equal(pl, own_state["payload"])) and bool((state["table"] == own_state["table"]).all()) \
             and bool((state["key"] == own_state["key"]).all())
         rate = nt * steps / el
-        return {"frames_per_s": rate, "ms_per_step": el / steps * 1e3, "steps": steps, "backend": backend,
-                "fraction_of_fused": rate / fused_value,
-                "check": "byte-identical to tz_rollout + tz_encode" if same else "MISMATCH vs tz_rollout + tz_encode",
-                "note": "one-rank process group on this GPU: every collective of the N > 1 protocol is issued"}
+        res = {"frames_per_s": rate, "ms_per_step": el / steps * 1e3, "steps": steps, "backend": backend,
+               "fraction_of_fused": rate / fused_value,
+               "check": "byte-identical to tz_rollout + tz_encode" if same else "MISMATCH vs tz_rollout + tz_encode",
+               "note": "one-rank process group on this GPU: every collective of the N > 1 protocol is issued"}
+        # the point-to-point gather itself: with one rank its op list is empty, so the payload shard (126 MB, int16 seen
+        # as uint8 device views) is sent by rank 0 to ITSELF through the same grouped isend / irecv that peers use,
+        # wait=False overlap included -- the only way the RCCL send/recv path can run on a one-GPU box
+        try:
+            state.clear()
+
+            def step_p2p():
+                nxt = tzdist.compress_sharded(engine, lambda a, b: frames, WARM_UP, WINDOW, MODE, BOUND, True, nt=nt,
+                                              to_host=False, wait=False, self_p2p=True)
+                drain()
+                state["pending"] = nxt
+            el2 = job.timed(step_p2p, steps, 1, drain=drain)
+            pl = state["payload"]
+            if isinstance(pl, np.ndarray):
+                pl = torch.from_numpy(pl).to(dev)
+            same2 = bool(torch.equal(pl, own_state["payload"])) and bool((state["table"] == own_state["table"]).all())
+            # the transfer alone: one grouped self send/recv of the payload bytes
+            src = own_state["payload"].view(torch.uint8)
+            dst = torch.empty_like(src)
+            torch.cuda.synchronize()
+            for _ in range(2):
+                for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, dst, 0), dist.P2POp(dist.isend, src, 0)]):
+                    q.wait()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, dst, 0), dist.P2POp(dist.isend, src, 0)]):
+                    q.wait()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            res["self_p2p"] = {"frames_per_s": nt * steps / el2, "fraction_of_fused": nt * steps / el2 / fused_value,
+                               "check": "byte-identical to tz_rollout + tz_encode" if same2 else "MISMATCH",
+                               "transfer_GBps": src.numel() / dt / 1e9, "transfer_ms": dt * 1e3, "bytes": int(src.numel()),
+                               "transfer_check": "byte-identical" if bool(torch.equal(src, dst)) else "MISMATCH",
+                               "note": "rank 0's own shard through dist.batch_isend_irecv to itself (grouped RCCL send/recv, "
+                                       "device uint8 views of the int16 payload) instead of the device copy"}
+        except Exception as e:   # RCCL may refuse a self send/recv: recorded, not fatal
+            res["self_p2p"] = {"error": repr(e)[:500]}
+        return res
     finally:
         dist.destroy_process_group()
+
+
+def configs_leg(job, ctx, cfg, frames3, dev):
+    """Driver-run numbers for the BASELINE.json configurations the headline does not cover, each a few seconds, device
+    resident (frames in HBM, payload into HBM, table on the host), every result decoded again and checked:
+      cfg1  64x64 moving blobs, 40 frames, -w 20, lossless          (configs[0])
+      cfg2  128x160 KITTI-like, 40 frames, -w 10, lossless          (configs[1])
+      cfg5_dwp  512x512 turbulence, 80 frames, DWP (-t inside the observed window-MSE range), lossless   (configs[4])"""
+    from tezip_amd import synth
+    out = {}
+
+    def run(name, frames, window, thr, max_batch, steps):
+        nt, h, w = frames.shape[:3]
+        hp, wp = (h + 7) // 8 * 8, (w + 7) // 8 * 8
+        ctx.prepare(hp, wp, max_batch)
+        payload = torch.empty(nt * h * w * 3, dtype=torch.int16, device=dev)
+        st = {}
+
+        def step():
+            st["key"], _ = ctx.rollout(frames, 0, window, thr)
+            _, st["table"], _ = ctx.encode("abs", [0.0], True, payload=payload)
+        el = job.timed(step, steps, 2)
+        key = st["key"]
+        kidx = torch.from_numpy(key).to(dev)
+        keys = torch.zeros_like(frames)
+        keys[kidx] = frames[kidx]
+        dec = torch.empty_like(frames)
+        torch.cuda.synchronize()
+
+        def dstep():
+            ctx.rollout_decode(keys, 0)
+            ctx.decode(payload, st["table"], out=dec)
+        eld = job.timed(dstep, steps, 1)
+        lens = np.diff(np.concatenate([key.nonzero()[0], [nt]])).tolist()
+        out[name] = {"frames": nt, "size": "%dx%d" % (h, w), "key_frames": int(key.sum()), "window_lengths": lens,
+                     "frames_per_s": nt * steps / el, "ms_per_step": el / steps * 1e3,
+                     "decode_frames_per_s": nt * steps / eld, "steps": steps,
+                     "round_trip": "bit-exact" if bool(torch.equal(dec, frames)) else "MISMATCH"}
+
+    run("cfg1", torch.from_numpy(synth.moving_blobs(40, 64, 64)).to(dev), 20, None, 2, 20)
+    run("cfg2", torch.from_numpy(synth.translating_scene(40, 128, 160)).to(dev), 10, None, 4, 20)
+    ctx.prepare(H, W, 1)
+    _, mse = ctx.rollout(frames3[:41], 0, None, 1e9, want_mse=True)
+    thr = float(mse[16])           # the window MSE of compress.py:246 reaches it after about 16 frames
+    run("cfg5_dwp", frames3, None, thr, 1, 3)
+    out["cfg5_dwp"]["threshold"] = thr
+    return out
+
+
+def cfg5_sweep(job, ctx, frames3_host, world):
+    """BASELINE.json configs[4] read as a search: the SWP sweep -w in {5, 10, ..., 40} of tezip_amd/sweep.py (`tezip.py
+    --sweep`), one candidate per rank and turn under N > 1 (sweep.sweep_sharded: nothing exchanged but the sizes), all
+    eight on this GPU at N = 1; lossless; each candidate is rollout + encode + the two zstd-9 frames, as `-w <value>`
+    would write them (the sizes ARE the result of the search, so zstd is inside the timed region here)."""
+    from tezip_amd import sweep
+    st = {}
+
+    def step():
+        st["rows"], st["best"], _ = sweep.sweep_sharded(ctx, frames3_host, 0, sweep.DEFAULT_WINDOWS, "abs", [0.0])
+    el = job.timed(step, 1, 0)
+    nt = frames3_host.shape[0]
+    raw = float(frames3_host.nbytes)
+    return {"workload": "512x512x3 turbulence, %d frames, lossless, SWP candidates -w %s, %d rank(s)"
+                        % (nt, list(sweep.DEFAULT_WINDOWS), world),
+            "seconds": el, "candidates_per_s": len(sweep.DEFAULT_WINDOWS) / el,
+            "frames_per_s": nt * len(sweep.DEFAULT_WINDOWS) / el, "best_window": int(st["best"]),
+            "ratio_by_window": {str(r["window"]): raw / r["total_bytes"] for r in st["rows"]},
+            "note": "random glorot weights: the ratios only order the candidates"}
 
 
 def _ratio_of(ctx, frames, mode, bound):

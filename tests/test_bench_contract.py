@@ -70,3 +70,12 @@ def test_flop_accounting_matches_the_design_numbers(bench):
     cfg = PredNetConfig()
     assert bench.live_flops_per_px0(cfg) == 416754      # executed live work per level-0 pixel and frame
     assert bench.conv16_flops_per_px0(cfg) == 405504    # ... of which k_conv16 (levels >= 1)
+
+
+def test_the_line_says_which_frames_per_second_value_is(bench):
+    """BASELINE.md 4 / SURVEY.md 8d define frames/s host to host; the task contract defines `value` device resident.
+    The line carries both and says which is which (checked on the source: the line itself needs a GPU)."""
+    import inspect
+    src = inspect.getsource(bench.main)
+    assert '"value_definition": "device-resident' in src and '"value_host_to_host":' in src
+    assert '"configs"' in src and '"cfg5_sweep"' in src      # every BASELINE.json config has a driver-run number

@@ -224,10 +224,12 @@ class PendingGather:
         return self.full
 
 
-def _gather_shards_begin(engine, buf, nbytes, dist, dst=0):
+def _gather_shards_begin(engine, buf, nbytes, dist, dst=0, self_p2p=False):
     """Point-to-point gather of the per-rank byte shards (sizes `nbytes`, known to everyone from
     the shard plan) into one buffer on `dst`: peers send, `dst` receives each shard straight into
-    its slice.  Returns a PendingGather: the transfers run behind whatever the caller does next."""
+    its slice.  Returns a PendingGather: the transfers run behind whatever the caller does next.
+    self_p2p (diagnostic, bench.py's one-GPU `sharded_path` leg): `dst` moves its OWN shard through the same
+    grouped isend / irecv instead of a device copy, so that the point-to-point machinery runs on a box with one GPU."""
     import torch
     rank, dev = dist.get_rank(), _device(dist)
     mine = _comm_tensor(engine, buf, dev) if nbytes[rank] else None
@@ -237,10 +239,13 @@ def _gather_shards_begin(engine, buf, nbytes, dist, dst=0):
     offs = np.concatenate([[0], np.cumsum(nbytes)]).astype(np.int64)
     full = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)
     # ONE group of receives: the shards arrive concurrently over their own xGMI links
+    own_by_p2p = bool(self_p2p and nbytes[rank])
     ops = [dist.P2POp(dist.irecv, full[int(offs[r]): int(offs[r + 1])], r)
-           for r in range(dist.get_world_size()) if r != dst and nbytes[r]]
+           for r in range(dist.get_world_size()) if (r != dst or own_by_p2p) and nbytes[r]]
+    if own_by_p2p:
+        ops.append(dist.P2POp(dist.isend, mine, dst))
     reqs = dist.batch_isend_irecv(ops) if ops else []
-    if nbytes[rank]:
+    if nbytes[rank] and not own_by_p2p:
         full[int(offs[rank]): int(offs[rank + 1])].copy_(mine)
     return PendingGather(reqs, full, mine)
 
@@ -293,7 +298,8 @@ def _all_ok(ok, dist, what):
         raise RuntimeError("%s failed on %d rank(s) (see their logs)" % (what, int(t.item())))
 
 
-def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True, nt=None, to_host=True, wait=True):
+def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True, nt=None, to_host=True, wait=True,
+                     self_p2p=False):
     """Every rank passes the same arguments.  `frames` is the full (nt,H,W,3) stack (anything whose
     [f0:f1] slice yields frames) or, with `nt` given, a callable (f0, f1) -> this rank's frames
     (a rank then never sees the others' frames).  Returns (payload, table|None, key_mask) on rank
@@ -370,7 +376,7 @@ def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True,
         if err is not None:
             raise err
         raise
-    gather = _gather_shards_begin(engine, y, [(b - a) * fe * 2 for a, b in shards], dist)
+    gather = _gather_shards_begin(engine, y, [(b - a) * fe * 2 for a, b in shards], dist, self_p2p=self_p2p)
     keys = np.concatenate([np.asarray(i[4: 4 + (b - a)]) for i, (a, b) in zip(infos, shards)]).astype(bool)
     pending = PendingCompress(gather, rank, table, keys, to_host)
     return pending.wait() if wait else pending
