@@ -90,6 +90,16 @@ int tz_predict_tap(tz_ctx* ctx, int kind, int level, float* out);
  * model expects it to be faster (default; env TEZIP_LAT=0|1|2 sets a context's start value),
  * 1 (value 2) = never, 2 (value 4) = wherever a convolution is eligible. */
 int tz_set_conv_impl(tz_ctx* ctx, int lds_dma);
+/* The arithmetic contract of the predictor.  The reference leaves the float32 summation order of its
+ * convolutions (prednet.py:254-277) to Keras / TensorFlow / cuDNN; this library fixes it, because a lossless decoder must
+ * regenerate the encoder's predictions bit for bit (decompress.py:252-253).  1 = TZ-PA1: every convolution one direct fmaf
+ * chain (rounds 1-3; what files written by earlier builds need).  2 = TZ-PA2: the per-frame convolutions of levels >= 1
+ * evaluate their same-resolution source as Winograd F(2x2, 3x3) chains (2.25x fewer multiplies; oracle/tz_oracle.c
+ * conv3x3_wino), everything else as in TZ-PA1.  Encoder and decoder must use the same contract: the on-disk format of the
+ * reference has no place to record it.  A context starts with the value of the environment variable TEZIP_PA (default:
+ * see DESIGN.md); switching re-prepares nothing. */
+int tz_set_contract(tz_ctx* ctx, int contract);
+int tz_get_contract(tz_ctx* ctx);
 /* Diagnostic: the inverse scan of decompress.py:22-29 (k_scan2p) lets a workgroup wait for the block sums of the workgroups
  * in front of it; that wait is bounded, and an expiry surfaces as TZ_ERR_HIP at the context's next stream synchronisation
  * (tz_ctx_synchronize, or any call that delivers host results).  This entry makes the next scans wait for the status words

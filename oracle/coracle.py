@@ -33,6 +33,8 @@ def lib():
             getattr(L, f).restype = None
         L.tzo_model_c0.argtypes = [C.c_void_p, C.c_void_p]
         L.tzo_model_next.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tzo_model_set_contract.argtypes = [C.c_void_p, C.c_int]
+        L.tzo_model_set_contract.restype = None
         L.tzo_predict2_literal.argtypes = [C.c_void_p] * 4
         L.tzo_sse_frame.restype = C.c_double
         L.tzo_sse_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -74,6 +76,12 @@ class CPredNet:
         if getattr(self, "h", None):
             lib().tzo_model_destroy(self.h)
             self.h = None
+
+    def set_contract(self, contract):
+        """1 = TZ-PA1 (direct chains everywhere), 2 = TZ-PA2 (tz_oracle.c conv3x3_wino for the per-frame convolutions of
+        levels >= 1)."""
+        lib().tzo_model_set_contract(self.h, int(contract))
+        return self
 
     def c0(self, hp=None, wp=None):
         out = np.empty((self.hp, self.wp, self.stack[0]), np.float32)

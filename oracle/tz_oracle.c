@@ -191,6 +191,7 @@ typedef struct {
     /* t=0 state after the top-down pass (input independent), and Ahat at t=0 */
     float *r0[TZO_MAXL], *c0[TZO_MAXL], *ahat0[TZO_MAXL];
     int prepared;
+    int contract; /* 1 = TZ-PA1 (every convolution a direct chain), 2 = TZ-PA2 (see conv3x3_wino), tzo_model_set_contract */
 } tzo_model;
 
 static int lvl_h(const tzo_model* m, int l) { return m->Hp >> l; }
@@ -320,10 +321,13 @@ tzo_model* tzo_model_create(int L, const int* stack, const int* rstack, int Hp, 
 }
 
 /* ------------------------------------------------------------------------------------------------------
- * A SECOND statement of the same convolution, NOT used by the predictor yet: Winograd F(2x2, 3x3) on the
- * same-resolution sources ("TZ-PA2", profiles/r03/winograd_skeleton.md: 2.25x fewer multiplies, still one
- * fmaf chain along the input channels per transformed position, i.e. what an MFMA k-loop computes).  Stated
- * here first so that a device kernel has something to be bit-exact with.
+ * A SECOND statement of the same convolution, arithmetic contract "TZ-PA2": Winograd F(2x2, 3x3) on the
+ * per-frame same-resolution sources (2.25x fewer multiplies, still one fmaf chain along the input channels per
+ * transformed position, i.e. what an MFMA k-loop computes).  tzo_model_set_contract(m, 2) makes the predictor use
+ * it for the per-frame convolutions of levels >= 1 (wino_gate_ok / wino_a_ok); the device kernel k_wino
+ * (tezip_amd/csrc/tz_wino_kernels.hip.h) is bit-exact with it.
+ *   sources marked in `direct_mask` (the constant r_{t-1} of a gate convolution) come FIRST and the direct way:
+ *   init[y][x] = the TZ-PA1 chain from the bias over them (conv3x3; the device keeps it as G0 per model);
  *   tile (ty, tx) = outputs (2ty+a, 2tx+b), a, b in {0,1}; its input patch d[r][c] = x[2ty-1+r][2tx-1+c], zero outside
  *   input transform V = B^T d B, columns first:  t[r][0] = d[r][0]-d[r][2]  t[r][1] = d[r][1]+d[r][2]
  *                                                t[r][2] = d[r][2]-d[r][1]  t[r][3] = d[r][1]-d[r][3]
@@ -333,9 +337,10 @@ tzo_model* tzo_model_create(int L, const int* stack, const int* rstack, int Hp, 
  *   products: D[i][j] = chain over sources in concat order, channels ascending, from 0:  D = fmaf(V[i][j](ci), U[i][j](ci, co), D)
  *   outputs, transform row i = 0..3 in turn (one pass over the channels each):
  *       Z[i][0] = (D[i][0]+D[i][1])+D[i][2]     Z[i][1] = (D[i][1]-D[i][2])-D[i][3]
- *       y[0][b] = ((bias + Z[0][b]) + Z[1][b]) + Z[2][b]     y[1][b] = ((bias + Z[1][b]) - Z[2][b]) - Z[3][b]
- *   an upsampled source then continues each output's chain with its 4 collapsed taps exactly as in conv3x3 (the four
- *   outputs of a tile are the four parity classes over the same 2x2 half-resolution pixels). */
+ *       y[0][b] = ((init + Z[0][b]) + Z[1][b]) + Z[2][b]     y[1][b] = ((init + Z[1][b]) - Z[2][b]) - Z[3][b]
+ *   an upsampled source then continues each output's chain with the collapsed taps and weights of conv3x3 (the four
+ *   outputs of a tile are the four parity classes over the same 2x2 half-resolution pixels), in the order: channel
+ *   quads ascending, the 4 taps of a quad, the 4 channels of a tap (conv3x3: blocks of 16, taps, 16 channels). */
 static void wino_u(const float* Wt, int Cin, int Cout, int ci, int co, float U[4][4]) {
     float g[3][3], w[4][3];
     for (int r = 0; r < 3; ++r)
@@ -356,9 +361,25 @@ static void wino_u(const float* Wt, int Cin, int Cout, int ci, int co, float U[4
     }
 }
 
-static void conv3x3_wino(const tzo_src* src, int nsrc, int H, int W, const float* Wt, const float* bias, int Cout, float* out) {
+static void conv3x3_wino(const tzo_src* src, int nsrc, int direct_mask, int H, int W, const float* Wt, const float* bias, int Cout,
+                         float* out) {
     int Cin = 0, Csame = 0;
     for (int s = 0; s < nsrc; ++s) Cin += src[s].C;
+    /* the direct part first: init = bias + the TZ-PA1 chains over the sources of direct_mask */
+    float* init = NULL;
+    tzo_src wsrc[4];
+    for (int s = 0; s < nsrc; ++s) wsrc[s] = src[s];
+    if (direct_mask) {
+        tzo_src dsrc[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int s = 0; s < nsrc; ++s) {
+            dsrc[s] = src[s];
+            if (!((direct_mask >> s) & 1)) dsrc[s].p = NULL;   /* conv3x3 leaves the chains alone for a NULL source */
+            else wsrc[s].p = NULL;
+        }
+        init = (float*)malloc(sizeof(float) * (size_t)H * W * Cout);
+        conv3x3(dsrc, nsrc, H, W, Wt, bias, Cout, init);
+    }
+    src = wsrc;
     /* transformed weights of the same-resolution sources: Us[pos][c][co], c counting the live same-resolution channels in
        concat order; collapsed weights of upsampled sources as in conv3x3 */
     int coff = 0;
@@ -412,8 +433,11 @@ static void conv3x3_wino(const tzo_src* src, int nsrc, int H, int W, const float
         float* Y = (float*)malloc(sizeof(float) * 4 * (size_t)Cout);
         float* V = (float*)malloc(sizeof(float) * 4 * (size_t)(Csame ? Csame : 1));
         for (int tx = 0; tx < TX; ++tx) {
-            for (int q = 0; q < 4; ++q)
-                for (int co = 0; co < Cout; ++co) Y[q * Cout + co] = bias[co];
+            for (int q = 0; q < 4; ++q) {
+                const int yy = 2 * ty + (q >> 1), xx = 2 * tx + (q & 1);
+                const float* ip = (init && yy < H && xx < W) ? init + ((size_t)yy * W + xx) * Cout : bias;
+                for (int co = 0; co < Cout; ++co) Y[q * Cout + co] = ip[co];
+            }
             for (int i = 0; i < 4 && Csame; ++i) {   /* one pass over the channels per transform row */
                 int c = 0;
                 for (int s = 0; s < nsrc; ++s) {
@@ -485,13 +509,13 @@ static void conv3x3_wino(const tzo_src* src, int nsrc, int H, int W, const float
                     for (int s = 0; s < nsrc; ++s) {
                         if (!(src[s].p && src[s].up)) continue;
                         int C = src[s].C, H2 = H >> 1, W2 = W >> 1, cls = (a << 1) | b;
-                        for (int c0 = 0; c0 < C; c0 += 16)
+                        for (int c0 = 0; c0 < C; c0 += 4)   /* channel quads; taps inside */
                             for (int tp = 0; tp < 4; ++tp) {
                                 int ly = (y >> 1) - 1 + (y & 1) + (tp >> 1), lx = (x >> 1) - 1 + (x & 1) + (tp & 1);
                                 int inside = ly >= 0 && ly < H2 && lx >= 0 && lx < W2;
                                 const float* ip = inside ? src[s].p + ((size_t)ly * W2 + lx) * C : NULL;
                                 const float* wp = Wc[s] + ((size_t)cls * 4 + tp) * C * Cout;
-                                int c1 = c0 + 16 < C ? c0 + 16 : C;
+                                int c1 = c0 + 4 < C ? c0 + 4 : C;
                                 for (int ci = c0; ci < c1; ++ci) {
                                     float xv = inside ? ip[ci] : 0.0f;
                                     const float* wr = wp + (size_t)ci * Cout;
@@ -507,8 +531,20 @@ static void conv3x3_wino(const tzo_src* src, int nsrc, int H, int W, const float
         free(V);
     }
     free(Us);
+    free(init);
     for (int s = 0; s < 4; ++s) free(Wc[s]);
 }
+
+/* Which per-frame convolutions TZ-PA2 evaluates this way: the same predicate as pack_wino (tz_prednet.hip) -- level >= 1,
+ * every source a multiple of 16 channels, columns in blocks of 64 (gates: 4 x 16) or 48 / 64 (A convolutions). */
+static int wino_gate_ok(const tzo_model* m, int l) {
+    return m->contract == 2 && l >= 1 && (2 * m->stack[l]) % 16 == 0 && m->rstack[l] % 16 == 0 &&
+           (l == m->L - 1 || m->rstack[l + 1] % 16 == 0);
+}
+static int wino_a_ok(const tzo_model* m, int l) {
+    return m->contract == 2 && l >= 1 && (2 * m->stack[l]) % 16 == 0 && (m->stack[l + 1] % 64 == 0 || m->stack[l + 1] % 48 == 0);
+}
+void tzo_model_set_contract(tzo_model* m, int contract) { m->contract = contract == 2 ? 2 : 1; }
 
 /* probe for tests: one convolution in either statement.  x: [H][W][C] same-resolution source (or NULL), xu: [H/2][W/2][Cu]
  * upsampled source (or NULL), Wt: HWIO (3,3,C+Cu,Cout) */
@@ -518,7 +554,7 @@ void tzo_conv_probe(int winograd, const float* x, int C, const float* xu, int Cu
     int ns = 0;
     if (C > 0) { src[ns].p = x; src[ns].C = C; src[ns].up = 0; ++ns; }
     if (Cu > 0) { src[ns].p = xu; src[ns].C = Cu; src[ns].up = 1; ++ns; }
-    if (winograd) conv3x3_wino(src, ns, H, W, Wt, bias, Cout, out);
+    if (winograd) conv3x3_wino(src, ns, 0, H, W, Wt, bias, Cout, out);
     else conv3x3(src, ns, H, W, Wt, bias, Cout, out);
 }
 
@@ -529,8 +565,8 @@ void tzo_model_destroy(tzo_model* m) {
 }
 
 /* One ConvLSTM update at level l (prednet.py:249-261).  r_prev/c_prev/e_prev may be NULL (zeros). */
-static void lstm_level(const tzo_model* m, int l, const float* r_prev, const float* c_prev, const float* e_prev,
-                       const float* r_up_half, float* r_out, float* c_out) {
+static void lstm_level_c(const tzo_model* m, int l, const float* r_prev, const float* c_prev, const float* e_prev,
+                         const float* r_up_half, float* r_out, float* c_out, int pa2) {
     int H = lvl_h(m, l), W = lvl_w(m, l), R = m->rstack[l];
     tzo_src src[3];
     int ns = 0;
@@ -541,7 +577,9 @@ static void lstm_level(const tzo_model* m, int l, const float* r_prev, const flo
     float* g[4];
     for (int k = 0; k < 4; ++k) {
         g[k] = (float*)malloc(sizeof(float) * n);
-        conv3x3(src, ns, H, W, m->g_k[k][l], m->g_b[k][l], R, g[k]);
+        /* TZ-PA2, per-frame call: the constant r_{t-1} (source 0) directly, e_{t-1} as Winograd chains, then the taps of up(r) */
+        if (pa2) conv3x3_wino(src, ns, 1, H, W, m->g_k[k][l], m->g_b[k][l], R, g[k]);
+        else conv3x3(src, ns, H, W, m->g_k[k][l], m->g_b[k][l], R, g[k]);
     }
     for (size_t j = 0; j < n; ++j) {
         float i_ = tzo_hard_sigmoid(g[0][j]), f_ = tzo_hard_sigmoid(g[1][j]), o_ = tzo_hard_sigmoid(g[3][j]);
@@ -553,6 +591,11 @@ static void lstm_level(const tzo_model* m, int l, const float* r_prev, const flo
         r_out[j] = o_ * tzo_tanh(c);
     }
     for (int k = 0; k < 4; ++k) free(g[k]);
+}
+
+static void lstm_level(const tzo_model* m, int l, const float* r_prev, const float* c_prev, const float* e_prev,
+                       const float* r_up_half, float* r_out, float* c_out) {
+    lstm_level_c(m, l, r_prev, c_prev, e_prev, r_up_half, r_out, c_out, 0);
 }
 
 /* ahat_l = relu(conv(r_l)) (+ min(.,1) at l=0)   prednet.py:268-271 */
@@ -582,11 +625,12 @@ static void err_level(const tzo_model* m, int l, const float* ahat, const float*
 }
 
 /* a_{l+1} = maxpool2x2(relu(conv(e_l)))   prednet.py:289-291 */
-static void a_level(const tzo_model* m, int l, const float* e, float* a_next) {
+static void a_level(const tzo_model* m, int l, const float* e, float* a_next, int pa2) {
     int H = lvl_h(m, l), W = lvl_w(m, l), C = m->stack[l + 1];
     float* full = (float*)malloc(sizeof(float) * (size_t)H * W * C);
     tzo_src s = {e, 2 * m->stack[l], 0};
-    conv3x3(&s, 1, H, W, m->a_k[l], m->a_b[l], C, full);
+    if (pa2) conv3x3_wino(&s, 1, 0, H, W, m->a_k[l], m->a_b[l], C, full);
+    else conv3x3(&s, 1, H, W, m->a_k[l], m->a_b[l], C, full);
     int H2 = H / 2, W2 = W / 2;
     for (int y = 0; y < H2; ++y)
         for (int x = 0; x < W2; ++x)
@@ -641,7 +685,7 @@ void tzo_model_next(tzo_model* m, const float* frame, float* pred, float** dbg) 
         err_level(m, l, m->ahat0[l], a, e[l]);
         if (l < L - 1) {
             float* an = falloc((npx / 4) * m->stack[l + 1]);
-            a_level(m, l, e[l], an);
+            a_level(m, l, e[l], an, wino_a_ok(m, l));
             free(a_own);
             a_own = an;
             a = an;
@@ -652,7 +696,7 @@ void tzo_model_next(tzo_model* m, const float* frame, float* pred, float** dbg) 
         size_t n = (size_t)lvl_h(m, l) * lvl_w(m, l) * m->rstack[l];
         r1[l] = falloc(n);
         c1[l] = falloc(n);
-        lstm_level(m, l, m->r0[l], m->c0[l], e[l], l < L - 1 ? r1[l + 1] : NULL, r1[l], c1[l]);
+        lstm_level_c(m, l, m->r0[l], m->c0[l], e[l], l < L - 1 ? r1[l + 1] : NULL, r1[l], c1[l], wino_gate_ok(m, l));
     }
     ahat_level(m, 0, r1[0], pred);
     for (int l = 0; l < L; ++l) {
@@ -700,7 +744,7 @@ void tzo_predict2_literal(tzo_model* m, const float* frame, float* out0, float* 
             free(ah);
             if (l < L - 1) {
                 float* an = falloc((npx / 4) * m->stack[l + 1]);
-                a_level(m, l, e[l], an);
+                a_level(m, l, e[l], an, 0);   /* (the literal form is the TZ-PA1 cross-check) */
                 free(a_own);
                 a_own = an;
                 a = an;

@@ -1,15 +1,14 @@
-// Winograd F(2x2, 3x3) K loop with ALL 16 transform positions live (round 4).  Round 3's skeletons kept 4 positions live
-// (one pass over the channels per transform row: the patch staged 4 times, 6x the direct kernel's stream bytes per MFMA,
-// 2 waves per SIMD) because 16 accumulator sets "do not fit".  They do: gfx950 gives ONE wave per SIMD 512 registers,
-// 256 of them accumulation registers -- exactly 16 positions x 4 column tiles x 4 (one 16-row tile = 16 tiles of 2x2
-// outputs x 64 columns).  Then the channel quad is the outermost loop, the patch is staged ONCE, the output transform
-// A^T D A happens once per workgroup, and a k-step (4 channels) is 64 independent MFMAs per wave behind 16 patch reads,
-// 32 vector adds (B^T d B) and 16 ds_read_b128 of transformed weights.
-//   workgroup = 4 waves = 16x16 output pixels (wave w: the 8x8 quadrant (w>>1, w&1) = 4x4 tiles) x 64 columns, 1 per CU
-//   stage     = one k-step: 16 KB of transformed weights [pos][lane][4 column tiles] + one quad plane of the 18x18 halo
-//               patch (324 x 16 B), DMA'd into a ring of NS slots LEAD stages ahead; one vmcnt wait + barrier per stage
-// Checks the result bit for bit against the oracle's statement of the same chains (oracle/tz_oracle.c conv3x3_wino).
-//   hipcc --offload-arch=gfx950 -O3 wino16.hip -o wino16.bin && ./wino16.bin
+// Winograd F(2x2, 3x3) K loop, 8 waves per workgroup = TWO waves per SIMD (round 4, second form; wino16.hip is the first).
+// wino16 keeps all 16 transform positions of a 16-row tile in ONE wave (256 accumulation registers, one wave per SIMD):
+// 92 TFLOP/s executed, and its ablations say a lone wave per SIMD pays for every instruction between its MFMAs.  Here
+// the 16 positions of a tile are split over a PAIR of waves on the same SIMD: wave (mt, ph) owns the 16 tiles of
+// quadrant mt of the 16x16-pixel region and the transform rows i = 2 ph, 2 ph + 1 (8 positions x 4 column tiles = 128
+// accumulation registers, 256 registers per wave).  Nothing is duplicated but a third of the patch reads: a wave reads
+// only its 8 positions' weights, needs 3 of the 4 patch rows and 20 of the 32 transform adds; the output transform needs
+// one small exchange between the partners at the very end (two of the four row sums each).
+//   stage = one k-step (4 channels): 16 KB of transformed weights + one quad plane of the 18x18 halo patch, columns
+//   stored evens first so that the 16 tiles of a wave sit on consecutive slots (2-way instead of 4-way bank conflicts).
+//   hipcc --offload-arch=gfx950 -O3 wino8.hip -o wino8.bin && ./wino8.bin
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -82,10 +81,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+template <int K>
+__device__ __forceinline__ void read_rows(unsigned ad, f32x2 (&d)[3][2]) {   // row k of the wave's three patch rows: (d0, d2), (d1, d3)
+    d[K][0] = lds_read2<72 * K, 72 * K + 4>(ad);
+    d[K][1] = lds_read2<72 * K + 36, 72 * K + 40>(ad);
+}
+
+// MODE bits (ablation builds, wrong results): 1 no barrier in the loop; 2 no patch reads / transform; 4 no weight reads
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_wino(const Args a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wino(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = wv & 3, ph = wv >> 2;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int cb = bid % a.ncb;
     bid /= a.ncb;
@@ -96,31 +103,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned sbase = lds_addr(smem);
     const int S = a.C >> 2;   // stages
 
-    // ---- patch DMA geometry, once: pieces wv and wv + 4, lane = slot inside the piece
-    unsigned poff[2];
-    unsigned long long pmask[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int slot = (wv + 4 * j) * PP + lane;
-        const int py = slot / PW, px = slot - py * PW;
+    // ---- patch DMA geometry, once: piece wv, lane = slot inside the piece; slot = row * 18 + (column, evens first)
+    unsigned poff;
+    unsigned long long pmask;
+    {
+        const int slot = wv * PP + lane;
+        const int py = slot / PW, xs = slot - py * PW;
+        const int px = xs < PW / 2 ? 2 * xs : 2 * (xs - PW / 2) + 1;
         const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
         const bool ok = lane < PP && slot < PW * PW && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-        poff[j] = ok ? 4u * (unsigned)((yy * a.W + xx) * a.C) : 0u;
-        pmask[j] = __ballot(ok);
+        poff = ok ? 4u * (unsigned)((yy * a.W + xx) * a.C) : 0u;
+        pmask = __ballot(ok);
     }
     const float* xn = a.x + (long long)n * a.H * a.W * a.C;
     const unsigned lane16 = lane * 16;
-    auto issue = [&](int s) {   // stage s into its ring slot: 4 KB of weights + two patch pieces per wave
+    auto issue = [&](int s) {   // stage s into its ring slot: 2 KB of weights + one patch piece per wave
         const unsigned slot = sbase + (unsigned)(s % NS) * SLOT;
-        const float* w = a.wimg + (((long long)s * a.ncb + cb) * 16 + 4 * wv) * 256;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) dma_lanes(w + p * 256, lane16, slot + (4 * wv + p) * 1024);
-        const float* xs = xn + 4 * s;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dma_gather(xs, poff[j], pmask[j], slot + WBYTES + (wv + 4 * j) * PP * 16);
+        const float* w = a.wimg + (((long long)s * a.ncb + cb) * 16 + 2 * wv) * 256;
+        dma_lanes(w, lane16, slot + (2 * wv) * 1024);
+        dma_lanes(w + 256, lane16, slot + (2 * wv + 1) * 1024);
+        dma_gather(xn + 4 * s, poff, pmask, slot + WBYTES + wv * PP * 16);
     };
     // zero the patch areas once: out-of-image slots are never written by the DMA
-    for (int i = tid; i < NS * (PBYTES / 16); i += 256) {
+    for (int i = tid; i < NS * (PBYTES / 16); i += 512) {
         const int sl = i / (PBYTES / 16), o = i - sl * (PBYTES / 16);
         *(f32x4*)(smem + sl * SLOT + WBYTES + o * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -128,81 +133,78 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int nlead = LEAD < S ? LEAD : S;
     for (int s = 0; s < nlead; ++s) issue(s);
 
-    f32x4 D[16][4];
+    f32x4 D[8][4];
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int t = 0; t < 4; ++t) D[p][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // A address of this lane: tile r of the wave's quadrant, channel g of the quad
+    // A address of this lane: tile r = (tyl, txl) of quadrant mt, channel g of the quad, first of the wave's three rows
     const int tyl = r >> 2, txl = r & 3;
-    const unsigned abase = WBYTES + (unsigned)(((8 * (wv >> 1) + 2 * tyl) * PW + 8 * (wv & 1) + 2 * txl) * 16 + 4 * g);
-    auto read_d_slot = [&](int slot_, f32x2 (&d)[4][2]) {
+    const unsigned abase = WBYTES + (unsigned)(((8 * (mt >> 1) + 2 * tyl + ph) * PW + 4 * (mt & 1) + txl) * 16 + 4 * g);
+    const unsigned bbase = (unsigned)(8 * ph) * 1024 + lane16;
+    auto read_d = [&](int slot_, f32x2 (&d)[3][2]) {
         const unsigned ad = sbase + (unsigned)slot_ * SLOT + abase;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            // (template arguments must be constants: spelled out)
-            if (rr == 0) { d[0][0] = lds_read2<0, 4>(ad); d[0][1] = lds_read2<8, 12>(ad); }
-            if (rr == 1) { d[1][0] = lds_read2<PW * 4, PW * 4 + 4>(ad); d[1][1] = lds_read2<PW * 4 + 8, PW * 4 + 12>(ad); }
-            if (rr == 2) { d[2][0] = lds_read2<2 * PW * 4, 2 * PW * 4 + 4>(ad); d[2][1] = lds_read2<2 * PW * 4 + 8, 2 * PW * 4 + 12>(ad); }
-            if (rr == 3) { d[3][0] = lds_read2<3 * PW * 4, 3 * PW * 4 + 4>(ad); d[3][1] = lds_read2<3 * PW * 4 + 8, 3 * PW * 4 + 12>(ad); }
-        }
+        read_rows<0>(ad, d);
+        read_rows<1>(ad, d);
+        read_rows<2>(ad, d);
     };
-    auto read_d = [&](int s_, f32x2 (&d)[4][2]) { read_d_slot(s_ % NS, d); };
-    auto transform = [&](const f32x2 (&d)[4][2], float (&V)[16]) {
-        float t[4][4];
+    // B^T d B for the wave's two transform rows (oracle/tz_oracle.c, same association): columns first, then rows
+    auto transform = [&](const f32x2 (&d)[3][2], float (&V)[8]) {
+        float t[3][4];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const float d0 = d[rr][0][0], d1 = d[rr][0][1], d2 = d[rr][1][0], d3 = d[rr][1][1];
-            t[rr][0] = d0 - d2;
-            t[rr][1] = d1 + d2;
-            t[rr][2] = d2 - d1;
-            t[rr][3] = d1 - d3;
+        for (int k = 0; k < 3; ++k) {
+            const float d0 = d[k][0][0], d2 = d[k][0][1], d1 = d[k][1][0], d3 = d[k][1][1];
+            t[k][0] = d0 - d2;
+            t[k][1] = d1 + d2;
+            t[k][2] = d2 - d1;
+            t[k][3] = d1 - d3;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            V[0 * 4 + j] = t[0][j] - t[2][j];
-            V[1 * 4 + j] = t[1][j] + t[2][j];
-            V[2 * 4 + j] = t[2][j] - t[1][j];
-            V[3 * 4 + j] = t[1][j] - t[3][j];
+            if (ph == 0) {   // rows 0, 1, 2 of the patch: V[0] = t0 - t2, V[1] = t1 + t2
+                V[j] = t[0][j] - t[2][j];
+                V[4 + j] = t[1][j] + t[2][j];
+            } else {         // rows 1, 2, 3: V[2] = t2 - t1, V[3] = t1 - t3
+                V[j] = t[1][j] - t[0][j];
+                V[4 + j] = t[0][j] - t[2][j];
+            }
         }
     };
+#define TIE8(X) asm volatile("" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]))
+#define TIED(d) asm volatile("" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]))
 
     // stages 0 and 1 landed for everyone
-    if (S >= 2 && nlead > 2) {
-        if (nlead == 5) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nlead == LEAD) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // MODE bits (ablation builds, wrong results): 1 no barrier in the loop; 2 no patch reads / transform; 4 no weight reads
-    float V0[16], V1[16];
+    float V0[8], V1[8];
     {
-        f32x2 d[4][2];
+        f32x2 d[3][2];
         read_d(0, d);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]), "+v"(d[3][0]), "+v"(d[3][1]) : : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]) : : "memory");
         transform(d, V0);
-        asm volatile("" : "+v"(V0[0]), "+v"(V0[1]), "+v"(V0[2]), "+v"(V0[3]), "+v"(V0[4]), "+v"(V0[5]), "+v"(V0[6]), "+v"(V0[7]),
-                     "+v"(V0[8]), "+v"(V0[9]), "+v"(V0[10]), "+v"(V0[11]), "+v"(V0[12]), "+v"(V0[13]), "+v"(V0[14]), "+v"(V0[15]));
+        TIE8(V0);
     }
-    f32x4 B[16];
+    f32x4 B[8];
     {   // the weight reads run as one continuous stream, four positions ahead, across the stage boundaries
-        const unsigned wb = sbase + lane16;
+        const unsigned wb = sbase + bbase;
         B[0] = lds_read16<0>(wb);
         B[1] = lds_read16<1024>(wb);
         B[2] = lds_read16<2048>(wb);
         B[3] = lds_read16<3072>(wb);
     }
     int slot = 0;   // ring slot of the current stage
-    // One stage: 16 positions x 4 column tiles.  In-order LDS queue, so every wait is a count:
-    //   pos 0-3   wait 3 (the three younger weight reads)            then issue B[p + 4]; behind pos 3 the 8 patch reads of stage s + 1
-    //   pos 4-7   wait 11 (3 weight reads + the 8 patch reads)
-    //   pos 8     wait 3: the patch reads are in front of B[8], i.e. done -> transform for stage s + 1 (32 vector adds)
-    //   pos 12-15 issue B[0..3] of stage s + 1 from the next slot
+    // One stage of a wave: 8 positions x 4 column tiles.  The LDS queue is in order, so every wait is a count:
+    //   pos 0, 1  wait 3 (the three younger weight reads); behind pos 1 the six patch reads of stage s + 1
+    //   pos 2-5   wait 9 (3 weight reads + 6 patch reads)
+    //   pos 6     wait 3: the patch reads sit in front of B[6]'s successors, i.e. are done -> transform for stage s + 1
+    //   pos 4-7   issue B[0..3] of stage s + 1 from the next slot
 #define WPOS(VC, P, WAITN, NEXT)                                                                                            \
     {                                                                                                                       \
         if (!(MODE & 4)) {                                                                                                  \
             if (WAITN == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(B[P]) : : "memory");                                 \
-            else asm volatile("s_waitcnt lgkmcnt(11)" : "+v"(B[P]) : : "memory");                                           \
+            else asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(B[P]) : : "memory");                                            \
         }                                                                                                                   \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) mfma_acc(D[P][t], VC[P], B[P][t]);                                    \
         if (!(MODE & 4)) { NEXT; }                                                                                          \
@@ -210,37 +212,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define WSTAGE(VC, VN)                                                                                                      \
     {                                                                                                                       \
         if (a.streams && s + LEAD < S) issue(s + LEAD);                                                                     \
-        const unsigned wb = sbase + (unsigned)slot * SLOT + lane16;                                                         \
+        const unsigned wb = sbase + (unsigned)slot * SLOT + bbase;                                                          \
         const int nslot = slot + 1 == NS ? 0 : slot + 1;                                                                    \
-        const unsigned wn = sbase + (unsigned)nslot * SLOT + lane16;                                                        \
-        f32x2 d[4][2];                                                                                                      \
-        const bool pr = MODE & 2 ? (MODE & 4) != 0 : true;                                                                  \
+        const unsigned wn = sbase + (unsigned)nslot * SLOT + bbase;                                                         \
+        f32x2 d[3][2];                                                                                                      \
         WPOS(VC, 0, 3, B[4] = lds_read16<4 * 1024>(wb))                                                                     \
-        WPOS(VC, 1, 3, B[5] = lds_read16<5 * 1024>(wb))                                                                     \
-        WPOS(VC, 2, 3, B[6] = lds_read16<6 * 1024>(wb))                                                                     \
-        WPOS(VC, 3, 3, B[7] = lds_read16<7 * 1024>(wb); if (!(MODE & 2)) read_d_slot(nslot, d))                             \
-        WPOS(VC, 4, (MODE & 2 ? 3 : 11), B[8] = lds_read16<8 * 1024>(wb))                                                   \
-        WPOS(VC, 5, (MODE & 2 ? 3 : 11), B[9] = lds_read16<9 * 1024>(wb))                                                   \
-        WPOS(VC, 6, (MODE & 2 ? 3 : 11), B[10] = lds_read16<10 * 1024>(wb))                                                 \
-        WPOS(VC, 7, (MODE & 2 ? 3 : 11), B[11] = lds_read16<11 * 1024>(wb))                                                 \
-        WPOS(VC, 8, 3, B[12] = lds_read16<12 * 1024>(wb))                                                                   \
-        /* the patch reads were in front of B[8] in the queue: arrived.  (Empty asm: the compiler may not compute with d before here.) */ \
-        if (!(MODE & 2)) asm volatile("" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]), "+v"(d[3][0]), "+v"(d[3][1])); \
-        if (!(MODE & 2)) { transform(d, VN); }                                                                              \
-        else { _Pragma("unroll") for (int q = 0; q < 16; ++q) VN[q] = VC[q]; }                                              \
-        /* ... and must have the transform done HERE: sunk to its first use it would sit right in front of an asm MFMA, */  \
-        /* behind which nobody inserts the wait states a VALU result needs before the matrix pipe reads it              */  \
-        asm volatile("" : "+v"(VN[0]), "+v"(VN[1]), "+v"(VN[2]), "+v"(VN[3]), "+v"(VN[4]), "+v"(VN[5]), "+v"(VN[6]), "+v"(VN[7]),   \
-                     "+v"(VN[8]), "+v"(VN[9]), "+v"(VN[10]), "+v"(VN[11]), "+v"(VN[12]), "+v"(VN[13]), "+v"(VN[14]), "+v"(VN[15])); \
-        WPOS(VC, 9, 3, B[13] = lds_read16<13 * 1024>(wb))                                                                   \
-        WPOS(VC, 10, 3, B[14] = lds_read16<14 * 1024>(wb))                                                                  \
-        WPOS(VC, 11, 3, B[15] = lds_read16<15 * 1024>(wb))                                                                  \
-        WPOS(VC, 12, 3, B[0] = lds_read16<0>(wn))                                                                           \
-        WPOS(VC, 13, 3, B[1] = lds_read16<1024>(wn))                                                                        \
-        WPOS(VC, 14, 3, B[2] = lds_read16<2048>(wn))                                                                        \
-        WPOS(VC, 15, 3, B[3] = lds_read16<3072>(wn))                                                                        \
-        (void)pr;                                                                                                           \
-        if (a.streams && s + LEAD < S) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");                                    \
+        WPOS(VC, 1, 3, B[5] = lds_read16<5 * 1024>(wb); if (!(MODE & 2)) read_d(nslot, d))                                  \
+        WPOS(VC, 2, (MODE & 2 ? 3 : 9), B[6] = lds_read16<6 * 1024>(wb))                                                    \
+        WPOS(VC, 3, (MODE & 2 ? 3 : 9), B[7] = lds_read16<7 * 1024>(wb))                                                    \
+        WPOS(VC, 4, (MODE & 2 ? 3 : 9), B[0] = lds_read16<0>(wn))                                                           \
+        WPOS(VC, 5, (MODE & 2 ? 3 : 9), B[1] = lds_read16<1024>(wn))                                                        \
+        WPOS(VC, 6, 3, B[2] = lds_read16<2048>(wn))                                                                         \
+        /* the patch reads have arrived (empty asm: the compiler may not compute with d before here) ...               */  \
+        if (!(MODE & 2)) { TIED(d); transform(d, VN); }                                                                     \
+        else { _Pragma("unroll") for (int q = 0; q < 8; ++q) VN[q] = VC[q]; }                                               \
+        /* ... and the transform is done HERE, not sunk to its first use right in front of an asm MFMA                  */  \
+        TIE8(VN);                                                                                                           \
+        WPOS(VC, 7, 3, B[3] = lds_read16<3072>(wn))                                                                         \
+        if (a.streams && s + LEAD < S) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                     \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
         if (!(MODE & 1)) __builtin_amdgcn_s_barrier();                                                                      \
         slot = nslot;                                                                                                       \
@@ -255,33 +244,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef WSTAGE
 #undef WPOS
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the reads issued for a stage past the end; the last MFMAs
-    // ---- output transform, oracle order, then store
-    const float* init = a.init + cb * 64 + r;
-    f32x4 Y[4][4];
+    // ---- output transform, oracle order.  Row sums of the wave's two transform rows:
+    f32x4 z0[2][4], z1[2][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float b = init[16 * t];
-        f32x4 z0[4], z1[4];
+    for (int li = 0; li < 2; ++li)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            z0[i] = (D[4 * i + 0][t] + D[4 * i + 1][t]) + D[4 * i + 2][t];
-            z1[i] = (D[4 * i + 1][t] - D[4 * i + 2][t]) - D[4 * i + 3][t];
+        for (int t = 0; t < 4; ++t) {
+            z0[li][t] = (D[4 * li + 0][t] + D[4 * li + 1][t]) + D[4 * li + 2][t];
+            z1[li][t] = (D[4 * li + 1][t] - D[4 * li + 2][t]) - D[4 * li + 3][t];
         }
-        const f32x4 bb = (f32x4){b, b, b, b};
-        Y[0][t] = ((bb + z0[0]) + z0[1]) + z0[2];
-        Y[1][t] = ((bb + z1[0]) + z1[1]) + z1[2];
-        Y[2][t] = ((bb + z0[1]) - z0[2]) - z0[3];
-        Y[3][t] = ((bb + z1[1]) - z1[2]) - z1[3];
+    // y[0][b] = ((init + Z[0][b]) + Z[1][b]) + Z[2][b] belongs to the wave with rows 0, 1 and needs Z[2] of its partner;
+    // y[1][b] = ((init + Z[1][b]) - Z[2][b]) - Z[3][b] belongs to the wave with rows 2, 3 and needs Z[1]: one exchange in LDS
+    __syncthreads();   // everybody is done with the ring
+    {
+        f32x4* xo = (f32x4*)smem + (wv * 8) * 64 + lane;
+        const int give = ph == 0 ? 1 : 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            xo[t * 64] = z0[give][t];
+            xo[(4 + t) * 64] = z1[give][t];
+        }
+    }
+    __syncthreads();
+    f32x4 Y[2][4];
+    {
+        const f32x4* xi = (const f32x4*)smem + ((wv ^ 4) * 8) * 64 + lane;
+        const float* init = a.init + cb * 64 + r;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float b = init[16 * t];
+            const f32x4 bb = (f32x4){b, b, b, b};
+            const f32x4 p0 = xi[t * 64], p1 = xi[(4 + t) * 64];   // partner's Z[2] (for ph 0) or Z[1] (for ph 1)
+            if (ph == 0) {
+                Y[0][t] = ((bb + z0[0][t]) + z0[1][t]) + p0;
+                Y[1][t] = ((bb + z1[0][t]) + z1[1][t]) + p1;
+            } else {
+                Y[0][t] = ((bb + p0) - z0[0][t]) - z0[1][t];
+                Y[1][t] = ((bb + p1) - z1[0][t]) - z1[1][t];
+            }
+        }
     }
     float* on = a.out + (long long)n * a.H * a.W * a.ncols + cb * 64 + r;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {   // accumulator row 4 g + e = tile (tyl = g, txl = e)
-            const int y = ty0 + 8 * (wv >> 1) + 2 * g + (q >> 1), x = tx0 + 8 * (wv & 1) + 2 * e + (q & 1);
+        for (int e = 0; e < 4; ++e) {   // accumulator row 4 g + e = tile (tyl = g, txl = e); this wave's outputs: row a = ph
+            const int y = ty0 + 8 * (mt >> 1) + 2 * g + ph, x = tx0 + 8 * (mt & 1) + 2 * e + b;
             if (y < a.H && x < a.W) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) on[((long long)y * a.W + x) * a.ncols + 16 * t] = Y[q][t][e];
+                for (int t = 0; t < 4; ++t) on[((long long)y * a.W + x) * a.ncols + 16 * t] = Y[b][t][e];
             }
         }
 }
@@ -355,7 +366,7 @@ static int run(const char* name, int N, int H, int W, int C, int ncols, int reps
         a.streams = streams;
         for (int it = 0; it < reps + 1; ++it) {
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(k_wino<MODE>, dim3(grid), dim3(256), lds, 0, a);
+            hipLaunchKernelGGL(k_wino<MODE>, dim3(grid), dim3(512), lds, 0, a);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms;

@@ -1,7 +1,7 @@
 """The oracle's SECOND statement of the 3x3 convolution -- Winograd F(2x2, 3x3) on the same-resolution sources, still one
 fmaf chain along the input channels per transformed position (oracle/tz_oracle.c: conv3x3_wino; profiles/r03/
-winograd_skeleton.md) -- is not used by the predictor yet.  It is stated in the oracle first, so that a device kernel has
-something to be bit-exact with; here it is held against the direct statement and a float64 convolution."""
+winograd_skeleton.md) -- arithmetic contract TZ-PA2 since round 4 (tzo_model_set_contract; the device kernel k_wino is bit-exact
+with it: tests/test_gpu_wino.py).  Here it is held against the direct statement and a float64 convolution."""
 import itertools
 
 import numpy as np
@@ -35,8 +35,8 @@ def test_winograd_statement_agrees_with_direct_and_float64(H, W, C, Cu, Co):
     wino = coracle.conv_probe(x, xu, w, b, True)
     ref = _ref64(x, xu, w, b)
     assert np.abs(direct - ref).max() < 1e-5 and np.abs(wino - ref).max() < 1e-5
-    if C == 0:   # nothing to transform: the two statements are the same chains
-        np.testing.assert_array_equal(direct, wino)
+    # (C == 0, nothing to transform: still not the same bits -- TZ-PA2 walks an upsampled source quad by quad, taps inside,
+    # TZ-PA1 in blocks of 16 channels: round 4, when the statement met its kernel)
     np.testing.assert_array_equal(wino, coracle.conv_probe(x, xu, w, b, True))   # deterministic (OpenMP over tile rows)
 
 

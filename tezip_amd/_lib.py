@@ -40,6 +40,8 @@ _SIGS = {
     "tz_predict_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "tz_set_conv_impl": (C.c_int, [C.c_void_p, C.c_int]),
     "tz_scan_fault_inject": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint]),
+    "tz_set_contract": (C.c_int, [C.c_void_p, C.c_int]),
+    "tz_get_contract": (C.c_int, [C.c_void_p]),
     "tz_act_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tz_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                              C.c_void_p, C.c_void_p]),
@@ -303,6 +305,14 @@ class Context:
         lat: None = k_convlat where the cost model picks it (default), "never", "always"."""
         code = {None: 0, "never": 1, "always": 2}[lat]
         self._ck(self.lib.tz_set_conv_impl(self.h, int(bool(lds_dma)) | (code << 1)))
+
+    def set_contract(self, contract):
+        """Arithmetic contract of the predictor: 1 = TZ-PA1 (direct fmaf chains), 2 = TZ-PA2 (Winograd chains on the
+        same-resolution sources of levels >= 1).  Encoder and decoder must agree."""
+        self._ck(self.lib.tz_set_contract(self.h, int(contract)))
+
+    def get_contract(self):
+        return int(self.lib.tz_get_contract(self.h))
 
     def scan_fault_inject(self, epoch_skew=0, poll_limit=0):
         """Diagnostic: make the inverse scan's bounded wait expire (see tz_scan_fault_inject); (0, 0) = normal."""

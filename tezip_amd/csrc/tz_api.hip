@@ -92,6 +92,8 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
         if (e && e[0] == '0') ctx->conv_impl = 0;
         e = getenv("TEZIP_LAT");                 // k_convlat: 0 never, 1 cost model (default), 2 wherever eligible
         if (e) ctx->lat_mode = atoi(e);
+        e = getenv("TEZIP_PA");                  // arithmetic contract a context starts with (tz_set_contract): 1 or 2
+        if (e && (e[0] == '1' || e[0] == '2') && !e[1]) ctx->contract = e[0] - '0';
     }
     ctx->device = device;
     if (hip_stream) {
@@ -447,7 +449,7 @@ tz_prof_scope::~tz_prof_scope() {
 static const char* kProfNames[TZP_COUNT] = {"conv3x3_mfma", "err0", "delta", "quant", "spatial_delta_hist",
                                             "lut_remap", "undelta_scan", "reconstruct", "sse",
                                             "conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general",
-                                            "convlat_small_grid", "table_create", "quant_serial_chains"};
+                                            "convlat_small_grid", "wino_pa2", "table_create", "quant_serial_chains"};
 
 extern "C" int tz_prof_enable(tz_ctx* ctx, int on) {
     if (!ctx) return TZ_ERR_INVALID;

@@ -28,6 +28,7 @@ enum tz_prof_class {
     TZP_CONV_SMALL, // k_conv_small: direct VALU 3 -> 3 convolution
     TZP_CONV_GEN,   // k_conv3x3: general kernel
     TZP_CONVLAT,    // k_convlat: one accumulator tile per wave, for grids that cannot fill the chip
+    TZP_WINO,       // k_wino: TZ-PA2 form (Winograd F(2x2, 3x3) on the same-resolution source) of the k_conv16 convolutions
     TZP_TABLE,      // HOST time: rank table + LUT from the downloaded histogram (compress.py:356-361)
     TZP_QSERIAL,    // not a time: `launches` counts the chains the quantiser sent through its serial fallback (k_q_serial)
     TZP_COUNT
@@ -54,6 +55,7 @@ struct tz_ctx {
     tz_model* model = nullptr;
     int conv_impl = 1;                // tz_set_conv_impl: 1 = LDS-DMA kernels where they apply
     int lat_mode = 1;                 // k_convlat: 0 never, 1 where the cost model says so, 2 wherever eligible (TEZIP_LAT)
+    int contract = 1;                 // arithmetic contract of the predictor: 1 = TZ-PA1, 2 = TZ-PA2 (tz_set_contract, TEZIP_PA)
     // rollout-resident data
     int nt = 0, H = 0, W = 0, Hp = 0, Wp = 0, warm_up = 0;
     uint8_t* d_frames = nullptr;      // nt*H*W*3 (encoder: originals; decoder: key stack)

@@ -23,6 +23,7 @@
 #include <algorithm>
 
 #include "tz_conv_kernels.hip.h"
+#include "tz_wino_kernels.hip.h"
 
 // ------------------------------------------------------------------------------- host side
 struct Seg {
@@ -34,6 +35,7 @@ struct PackedConv {
     float* d_Wimg = nullptr;  // LDS image order for k_conv16 (every source a multiple of 16 channels), else null
     float* d_Wblk = nullptr;  // block-step image for k_conv16b (first source <= 8 channels at stride 8), else null
     float* d_Wlat = nullptr;  // per-wave fragment image for k_convlat (same condition as d_Wimg), else null
+    float* d_Wwino = nullptr; // TZ-PA2 stage image for k_wino (pack_wino), else null
     const float* d_zero = nullptr;
     float* d_bias = nullptr;
     int nslots = 0, ncols = 0, NT = 1, ncb = 1;
@@ -216,6 +218,69 @@ static int pack_conv(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, con
     return TZ_OK;
 }
 
+// TZ-PA2 weights of a per-frame convolution for k_wino (tz_wino_kernels.hip.h; oracle/tz_oracle.c::conv3x3_wino states the
+// same numbers): stage s < C0/4 = channel quad s of the same-resolution source segs[0], its 16 sets = the transformed
+// weights U[i][j] = (G g G^T)[i][j] of the quad's 4 channels, position 4 i + j, evaluated in float32 rows first:
+//   s = g[0][c] + g[2][c]; w[1][c] = 0.5 (s + g[1][c]); w[2][c] = 0.5 (s - g[1][c]); w[0][c] = g[0][c]; w[3][c] = g[2][c];
+//   then the same along c.
+// Stages behind those = the channel quads of the upsampled source segs[1]: 16 sets = (parity class (a, b), collapsed tap tp)
+// at index 8 a + 2 tp + b (the order in which wave (.., ph = a) of k_wino consumes them), values = pack_conv's collapsed sums.
+// Image: [stage][column block][set][lane = (channel of the quad) * 16 + column][column tile (4, zero beyond NT)].
+static int pack_wino(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, const std::vector<ColSrc>& cols, int NT, PackedConv* pc) {
+    if (segs.empty() || segs[0].up || segs[0].C % 16 || (NT != 3 && NT != 4) || segs.size() > 2 ||
+        (segs.size() == 2 && (!segs[1].up || segs[1].C % 16)))
+        return TZ_OK;   // not a k_wino convolution
+    const int ncols = (int)cols.size(), ncb = ncols / (16 * NT);
+    const int S1 = segs[0].C / 4, S2 = segs.size() == 2 ? segs[1].C / 4 : 0;
+    std::vector<float> I((size_t)(S1 + S2) * ncb * 16 * 256, 0.0f);
+    auto at = [&](int st, int cb, int set, int lane, int nt) -> float& {
+        return I[((((size_t)st * ncb + cb) * 16 + set) * 64 + lane) * 4 + nt];
+    };
+    for (int col = 0; col < ncols; ++col) {
+        const ColSrc& cs = cols[col];
+        if (cs.ch < 0) continue;
+        const int cb = col / (16 * NT), nt = (col % (16 * NT)) / 16, j = col % 16;
+        for (int c = 0; c < segs[0].C; ++c) {
+            float g[3][3], w[4][3], U[4][4];
+            for (int r = 0; r < 3; ++r)
+                for (int q = 0; q < 3; ++q) g[r][q] = cs.kernel[((size_t)(r * 3 + q) * cs.Cin + segs[0].row_off + c) * cs.Cout + cs.ch];
+            for (int q = 0; q < 3; ++q) {
+                const float s_ = g[0][q] + g[2][q];
+                w[0][q] = g[0][q];
+                w[1][q] = 0.5f * (s_ + g[1][q]);
+                w[2][q] = 0.5f * (s_ - g[1][q]);
+                w[3][q] = g[2][q];
+            }
+            for (int i = 0; i < 4; ++i) {
+                const float s_ = w[i][0] + w[i][2];
+                U[i][0] = w[i][0];
+                U[i][1] = 0.5f * (s_ + w[i][1]);
+                U[i][2] = 0.5f * (s_ - w[i][1]);
+                U[i][3] = w[i][2];
+            }
+            for (int p = 0; p < 16; ++p) at(c / 4, cb, p, (c % 4) * 16 + j, nt) = U[p >> 2][p & 3];
+        }
+        for (int c = 0; c < (S2 ? segs[1].C : 0); ++c)
+            for (int cls = 0; cls < 4; ++cls)
+                for (int tp = 0; tp < 4; ++tp) {
+                    int kys[2], kxs[2];
+                    const int nky = collapse_set(cls >> 1, tp >> 1, kys), nkx = collapse_set(cls & 1, tp & 1, kxs);
+                    float v = 0.0f;
+                    bool first = true;
+                    for (int iy = 0; iy < nky; ++iy)
+                        for (int ix = 0; ix < nkx; ++ix) {
+                            const float wv_ = cs.kernel[((size_t)(kys[iy] * 3 + kxs[ix]) * cs.Cin + segs[1].row_off + c) * cs.Cout + cs.ch];
+                            v = first ? wv_ : v + wv_;
+                            first = false;
+                        }
+                    at(S1 + c / 4, cb, 8 * (cls >> 1) + 2 * tp + (cls & 1), (c % 4) * 16 + j, nt) = v;
+                }
+    }
+    TZ_TRY(dmalloc(ctx, m, (void**)&pc->d_Wwino, I.size() * 4));
+    TZ_HIP(ctx, hipMemcpy(pc->d_Wwino, I.data(), I.size() * 4, hipMemcpyHostToDevice));
+    return TZ_OK;
+}
+
 static int plain_nt(int Cout) {
     if (Cout % 64 == 0) return 4;
     if (Cout % 48 == 0) return 3;
@@ -262,6 +327,34 @@ static void launch_conv16_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
     int blocks = a.ncb * a.tiles_x * a.tiles_y * nbatch;
     hipLaunchKernelGGL((k_conv16<NT, EPI, UPS>), dim3(blocks), dim3(NTHR), 0, ctx->stream, a);
 }
+
+template <int NT, int EPI, bool UPS>
+static int launch_wino_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
+    static bool attr_set = false;   // (per instantiation; the attribute belongs to the function, not to a context)
+    if (!attr_set) {
+        TZ_HIP(ctx, hipFuncSetAttribute((const void*)k_wino<NT, EPI, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, tzw::LDS_BYTES));
+        attr_set = true;
+    }
+    const int blocks = a.ncb * a.tiles_x * a.tiles_y * nbatch;
+    hipLaunchKernelGGL((k_wino<NT, EPI, UPS>), dim3(blocks), dim3(512), tzw::LDS_BYTES, ctx->stream, a);
+    TZ_HIP(ctx, hipGetLastError());
+    return TZ_OK;
+}
+
+static int launch_wino(tz_ctx* ctx, int NT, int epi, bool ups, const ConvArgs& a, int nbatch) {
+    if (NT == 4 && epi == EPI_LSTM) return ups ? launch_wino_t<4, EPI_LSTM, true>(ctx, a, nbatch) : launch_wino_t<4, EPI_LSTM, false>(ctx, a, nbatch);
+    if (NT == 4 && epi == EPI_RAW) return ups ? launch_wino_t<4, EPI_RAW, true>(ctx, a, nbatch) : launch_wino_t<4, EPI_RAW, false>(ctx, a, nbatch);
+    if (epi == EPI_POOL_ERR && !ups) return NT == 4 ? launch_wino_t<4, EPI_POOL_ERR, false>(ctx, a, nbatch) : launch_wino_t<3, EPI_POOL_ERR, false>(ctx, a, nbatch);
+    return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "no TZ-PA2 kernel for NT=%d epilogue=%d upsampled=%d", NT, epi, (int)ups);
+}
+
+extern "C" int tz_set_contract(tz_ctx* ctx, int contract) {
+    if (!ctx) return TZ_ERR_INVALID;
+    if (contract != 1 && contract != 2) return tz_fail(ctx, TZ_ERR_INVALID, "tz_set_contract: %d is neither 1 (TZ-PA1) nor 2 (TZ-PA2)", contract);
+    ctx->contract = contract;   // nothing is re-prepared: both forms of a convolution are packed, the constants are TZ-PA1 in both
+    return TZ_OK;
+}
+extern "C" int tz_get_contract(tz_ctx* ctx) { return ctx ? ctx->contract : TZ_ERR_INVALID; }
 
 extern "C" int tz_set_conv_impl(tz_ctx* ctx, int lds_dma) {
     if (!ctx) return TZ_ERR_INVALID;
@@ -341,6 +434,12 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
         TZ_CASE16B(1, EPI_POOL_ERR, false) TZ_CASE16B(3, EPI_POOL_ERR, false) TZ_CASE16B(4, EPI_POOL_ERR, false)
 #undef TZ_CASE16B
     }
+    // TZ-PA2: the per-frame convolutions of levels >= 1 go through ONE kernel whatever the batch and the frame size
+    // (the contract fixes the arithmetic per convolution; k_wino_ref is its cross-check, tz_set_conv_impl(0))
+    if (a.Wwino && ctx->contract == 2 && fullk && (epi == EPI_LSTM || epi == EPI_POOL_ERR || epi == EPI_RAW)) {
+        ps.sub = TZP_WINO;
+        return launch_wino(ctx, NT, epi, ups, a, nbatch);
+    }
     {
         const LatPlan lp = lat_plan(ctx, NT, epi, ups, fullk, a, nbatch);
         if (!lp.use) goto no_lat;
@@ -403,6 +502,7 @@ static void fill_srcs(ConvArgs& a, const PackedConv& pc, const float* const* ptr
     a.Wimg = pc.d_Wimg;
     a.Wblk = pc.d_Wblk;
     a.Wlat = pc.d_Wlat;
+    a.Wwino = pc.d_Wwino;
     a.zero = pc.d_zero;
     a.bias = pc.d_bias;
     a.ncols = pc.ncols;
@@ -570,6 +670,7 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         std::vector<Seg> segs = {Seg{m->rstack[l], 2 * m->stack[l], 0}};
         if (l < L - 1) segs.push_back(Seg{m->rstack[l] + 2 * m->stack[l], m->rstack[l + 1], 1});
         TZ_TRY(pack_conv(ctx, m, segs, cols, NT, &m->gate_t1[l]));
+        if (l >= 1) TZ_TRY(pack_wino(ctx, m, segs, cols, NT, &m->gate_t1[l]));   // TZ-PA2 form of the same convolution
         // fragment-order copies for the LDS-DMA kernels' prologue / epilogue (row map of the t=1 launch)
         {
             const int tx = (wl(l) + 15) / 16, ty = (hl(l) + 15) / 16, ncb = pg.ncols / (16 * NT);
@@ -593,6 +694,7 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         int Cout = m->stack[l + 1], NT = plain_nt(Cout);
         TZ_TRY(pack_conv(ctx, m, {Seg{0, 2 * m->stack[l], 0}}, plain_cols(m->a_k(l), m->a_b(l), 2 * m->stack[l], Cout), NT,
                          &m->a_conv[l]));
+        if (l >= 1) TZ_TRY(pack_wino(ctx, m, {Seg{0, 2 * m->stack[l], 0}}, plain_cols(m->a_k(l), m->a_b(l), 2 * m->stack[l], Cout), NT, &m->a_conv[l]));
     }
     TZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     m->prepared = true;
@@ -693,7 +795,8 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         const PackedConv& pc = m->a_conv[l];
         ConvArgs a;
         aconv_args(l, a);
-        if (m->P[l] && m->gate_t1[l].NT == 4 && m->gate_t1[l].segs.size() == 2) {
+        // (not under TZ-PA2 where the gate convolution is a k_wino one: the split halves are TZ-PA1 chains)
+        if (m->P[l] && m->gate_t1[l].NT == 4 && m->gate_t1[l].segs.size() == 2 && !(ctx->contract == 2 && m->gate_t1[l].d_Wwino)) {
             ConvArgs ge;
             gate_args(l, ge);
             ge.nsrc = 1;                      // the chain over E_l only

@@ -1,0 +1,460 @@
+// k_wino: the per-frame convolutions of levels >= 1 under arithmetic contract TZ-PA2 (round 4).
+//
+// What it computes (prednet.py:254-259 gate convolutions over [r_{t-1}, e_{t-1}, up(r_{l+1})] with the LSTM update,
+// prednet.py:289-291 + 274-277 A convolutions with pooling and the next level's error unit): the same convolutions as
+// k_conv16, with the SAME-RESOLUTION source evaluated as Winograd F(2x2, 3x3) -- 16 multiplies per input channel and 2x2
+// outputs instead of 36 -- in the fixed order that oracle/tz_oracle.c::conv3x3_wino states (TZ-PA2):
+//   tile (ty, tx) = outputs (2ty + a, 2tx + b); V = B^T d B of its 4x4 input patch, columns first, in float32;
+//   D[i][j] = ONE fmaf chain from 0 over the input channels in ascending order: D = fmaf(V[i][j](c), U[i][j](c, col), D)
+//             with U = G g G^T evaluated on the host in float32 -- what v_mfma_f32_16x16x4_f32 computes along k;
+//   Z[i][0] = (D[i][0] + D[i][1]) + D[i][2],  Z[i][1] = (D[i][1] - D[i][2]) - D[i][3];
+//   y[0][b] = ((init + Z[0][b]) + Z[1][b]) + Z[2][b],  y[1][b] = ((init + Z[1][b]) - Z[2][b]) - Z[3][b],
+//             init = bias, or G0 = bias + the direct TZ-PA1 chain over the constant r_{t-1} source (tz_model_prepare);
+//   an upsampled source then continues every output's chain with its 4 collapsed taps (the four outputs of a tile are the
+//   four parity classes over the same 2x2 half-resolution pixels), order: 16-channel block, channel quad, tap, channel.
+//
+// How (scripts/microbench/wino8.hip is the measured skeleton):
+//   workgroup = 8 waves = 16x16 output pixels x 64 (48) columns, ONE per CU (156 KB of LDS), two waves per SIMD.
+//   Wave (mt, ph): the 16 tiles of quadrant mt and the transform rows i = 2 ph, 2 ph + 1: 8 positions x NT column tiles
+//   = 128 accumulation registers, held in AGPRs by asm MFMAs with a tied operand.  The channel quad is the outermost loop:
+//   a STAGE = 16 KB of transformed weights [position][lane][4 column tiles] + one quad plane of the 18x18 halo patch
+//   (columns stored evens first: the 16 tiles of a wave sit on consecutive slots, 2-way bank conflicts instead of 4-way),
+//   DMA'd into a ring of 6 slots 5 stages ahead; per stage and wave 32 MFMAs, 8 ds_read_b128 of weights in one
+//   continuous stream 4 positions ahead, 6 ds_read2_b32 of the patch and 20 vector adds for the next stage's B^T d B,
+//   one counted vmcnt wait and one barrier.  After the last channel quad the partners exchange two row sums each through
+//   LDS and form their two outputs per tile; the upsampled source then runs through the same pipeline (stage = one channel
+//   quad: 4 classes x 4 taps of collapsed weights, 6 patch reads, no transform), the epilogue is fused.
+// Invariants nobody checks for us (DESIGN.md section 5 "hand-scheduled kernels" applies here too):
+//   * every wave issues exactly 3 LDS-DMA instructions per stage, so `vmcnt(9)` = "my pieces of stage s + 2 have landed";
+//   * the LDS queue is in order, so the lgkmcnt immediates below are counts of younger reads;
+//   * asm MFMAs get no hazard handling from the compiler: a VALU result is never consumed by the very next MFMA (empty
+//     asm statements pin the transform away from its first use), accumulators are read behind explicit wait states.
+#pragma once
+#include "tz_conv_kernels.hip.h"
+
+namespace tzw {
+static constexpr int NS = 6, LEAD = 5;
+static constexpr int WBYTES = 16 * 1024;             // weights of a stage
+static constexpr int PP = 41, P1BYTES = 8 * PP * 16; // same-resolution patch plane: 8 DMA pieces of 41 slots (>= 18 x 18)
+static constexpr int UP = 13, P2BYTES = 8 * UP * 16; // half-resolution patch plane: 8 pieces of 13 slots (>= 10 x 10)
+static constexpr int SLOT = WBYTES + P1BYTES + P2BYTES;
+static constexpr int XBYTES = 16 * 1024;             // exchange area of the wave pairs
+static constexpr int LDS_BYTES = NS * SLOT + XBYTES; // 156,160
+static constexpr int WPW = 18, WLW = 10;   // halo patch of 18 x 18 pixels, half-resolution patch of 10 x 10
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void dma_lanes(const float* ubase, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(ubase), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void dma_gather(const float* ubase, unsigned voff, unsigned long long mask, unsigned lds) {
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(voff), "s"(ubase), "s"(lds), "s"(mask) : "memory");
+}
+template <int O0, int O1>
+__device__ __forceinline__ f32x2 lds_read2(unsigned addr) {
+    f32x2 v;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// in-place accumulation in an AGPR tuple (see the header: the register allocator must not get a say)
+__device__ __forceinline__ void mfma_acc(f32x4& acc, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+template <int K>
+__device__ __forceinline__ void read_rows(unsigned ad, f32x2 (&d)[3][2]) {   // row k of the wave's three patch rows: (d0, d2), (d1, d3)
+    d[K][0] = lds_read2<72 * K, 72 * K + 4>(ad);
+    d[K][1] = lds_read2<72 * K + 36, 72 * K + 40>(ad);
+}
+}  // namespace tzw
+
+#define TZW_TIE8(X) asm volatile("" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]))
+#define TZW_TIE6(X) asm volatile("" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]))
+#define TZW_TIED(d) asm volatile("" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]))
+#define TZW_TIEU(u) asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]))
+
+// EPI: EPI_LSTM (NT = 4: columns [i | f | g | o] x 16 channels), EPI_POOL_ERR (NT = 3 or 4), EPI_RAW (NT = 4; tests).
+// src[0]: the same-resolution source (multiple of 16 channels); src[1] (UPS): the half-resolution source.
+template <int NT, int EPI, bool UPS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wino(const ConvArgs a) {
+    using namespace tzw;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = wv & 3, ph = wv >> 2;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = bid % a.ncb;
+    bid /= a.ncb;
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int tile = bid % ntiles, n = bid / ntiles;
+    const int ty0 = (tile / a.tiles_x) * 16, tx0 = (tile % a.tiles_x) * 16;
+    const int g = lane >> 4, r = lane & 15;
+    const unsigned sbase = lds_addr(smem);
+    const int S1 = a.src[0].C >> 2;                       // stages of the same-resolution source
+    const int S = S1 + (UPS ? a.src[1].C >> 2 : 0);       // ... and of the upsampled one
+
+    // ---- DMA geometry, once per workgroup.  Same-resolution plane: piece wv = slots 41 wv ..; slot = row * 18 + column
+    // with the columns stored evens first.  Half-resolution plane: piece wv = slots 13 wv .., slot = row * 10 + column.
+    unsigned poff, uoff = 0;
+    unsigned long long pmask, umask = 0;
+    {
+        const int slot = wv * PP + lane;
+        const int py = slot / WPW, xs = slot - py * WPW;
+        const int px = xs < WPW / 2 ? 2 * xs : 2 * (xs - WPW / 2) + 1;
+        const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
+        const bool ok = lane < PP && slot < WPW * WPW && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        poff = ok ? 4u * (unsigned)((yy * a.W + xx) * a.src[0].pstride) : 0u;
+        pmask = __ballot(ok);
+    }
+    if (UPS) {
+        const int slot = wv * UP + lane;
+        const int Y = slot / WLW, X = slot - Y * WLW;
+        const int ly = (ty0 >> 1) - 1 + Y, lx = (tx0 >> 1) - 1 + X;
+        const bool ok = lane < UP && slot < WLW * WLW && ly >= 0 && ly < (a.H >> 1) && lx >= 0 && lx < (a.W >> 1);
+        uoff = ok ? 4u * (unsigned)((ly * (a.W >> 1) + lx) * a.src[1].pstride) : 0u;
+        umask = __ballot(ok);
+    }
+    const float* x0 = a.src[0].p + (long long)n * a.src[0].nstride;
+    const float* x1 = UPS ? a.src[1].p + (long long)n * a.src[1].nstride : nullptr;
+    const unsigned lane16 = lane * 16;
+    auto issue = [&](int s) {   // stage s into its ring slot: 2 KB of weights + one patch piece per wave = 3 DMA instructions
+        const unsigned slot = sbase + (unsigned)(s % NS) * SLOT;
+        const float* w = a.Wwino + (((long long)s * a.ncb + cb) * 16 + 2 * wv) * 256;
+        dma_lanes(w, lane16, slot + (2 * wv) * 1024);
+        dma_lanes(w + 256, lane16, slot + (2 * wv + 1) * 1024);
+        if (!UPS || s < S1) dma_gather(x0 + 4 * s, poff, pmask, slot + WBYTES + wv * PP * 16);
+        else dma_gather(x1 + 4 * (s - S1), uoff, umask, slot + WBYTES + P1BYTES + wv * UP * 16);
+    };
+    // zero the patch areas once: the slots of out-of-image pixels are never written by the DMA
+    for (int i = tid; i < NS * ((P1BYTES + P2BYTES) / 16); i += 512) {
+        const int sl = i / ((P1BYTES + P2BYTES) / 16), o = i - sl * ((P1BYTES + P2BYTES) / 16);
+        *(f32x4*)(smem + sl * SLOT + WBYTES + o * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    const int nlead = LEAD < S ? LEAD : S;
+    for (int s = 0; s < nlead; ++s) issue(s);
+
+    f32x4 D[8][4];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) D[p][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // A address of this lane: tile r = (tyl, txl) of quadrant mt, channel g of the quad, first of the wave's three rows
+    const int tyl = r >> 2, txl = r & 3;
+    const unsigned abase = WBYTES + (unsigned)(((8 * (mt >> 1) + 2 * tyl + ph) * WPW + 4 * (mt & 1) + txl) * 16 + 4 * g);
+    const unsigned ubase = WBYTES + P1BYTES + (unsigned)(((4 * (mt >> 1) + tyl + ph) * WLW + 4 * (mt & 1) + txl) * 16 + 4 * g);
+    const unsigned bbase = (unsigned)(8 * ph) * 1024 + lane16;
+    auto read_d = [&](int slot_, f32x2 (&d)[3][2]) {
+        const unsigned ad = sbase + (unsigned)slot_ * SLOT + abase;
+        read_rows<0>(ad, d);
+        read_rows<1>(ad, d);
+        read_rows<2>(ad, d);
+    };
+    // B^T d B for the wave's two transform rows (same association as the oracle): columns first, then rows
+    auto transform = [&](const f32x2 (&d)[3][2], float (&V)[8]) {
+        float t[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float d0 = d[k][0][0], d2 = d[k][0][1], d1 = d[k][1][0], d3 = d[k][1][1];
+            t[k][0] = d0 - d2;
+            t[k][1] = d1 + d2;
+            t[k][2] = d2 - d1;
+            t[k][3] = d1 - d3;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ph == 0) {   // rows 0, 1, 2 of the patch: V[0] = t0 - t2, V[1] = t1 + t2
+                V[j] = t[0][j] - t[2][j];
+                V[4 + j] = t[1][j] + t[2][j];
+            } else {         // rows 1, 2, 3: V[2] = t2 - t1, V[3] = t1 - t3
+                V[j] = t[1][j] - t[0][j];
+                V[4 + j] = t[0][j] - t[2][j];
+            }
+        }
+    };
+
+    // stages 0 and 1 landed for everyone
+    if (nlead == LEAD) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float V0[8], V1[8];
+    {
+        f32x2 d[3][2];
+        read_d(0, d);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]) : : "memory");
+        transform(d, V0);
+        TZW_TIE8(V0);
+    }
+    f32x4 B[8];
+    {   // the weight reads run as one continuous stream, four positions ahead, across the stage boundaries
+        const unsigned wb = sbase + bbase;
+        B[0] = lds_read16<0>(wb);
+        B[1] = lds_read16<1024>(wb);
+        B[2] = lds_read16<2048>(wb);
+        B[3] = lds_read16<3072>(wb);
+    }
+    int slot = 0;   // ring slot of the current stage
+    int s = 0;
+    // One stage of a wave: 8 positions x NT column tiles.  The LDS queue is in order, so every wait is a count:
+    //   pos 0, 1  wait 3 (the three younger weight reads); behind pos 1 the patch reads of the NEXT stage (NA instructions)
+    //   pos 2-5   wait 3 + NA
+    //   pos 6     wait 3: the patch reads are done -> (phase 1) transform for the next stage
+    //   pos 4-7   issue B[0..3] of the next stage from the next slot
+#define TZW_WAIT(P, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(B[P]) : : "memory")
+#define TZW_STAGE_HEAD                                                                                                      \
+        if (s + LEAD < S) issue(s + LEAD);                                                                                  \
+        const unsigned wb = sbase + (unsigned)slot * SLOT + bbase;                                                          \
+        const int nslot = slot + 1 == NS ? 0 : slot + 1;                                                                    \
+        const unsigned wn = sbase + (unsigned)nslot * SLOT + bbase;
+#define TZW_STAGE_TAIL                                                                                                      \
+        if (s + LEAD < S) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                                  \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
+        __builtin_amdgcn_s_barrier();                                                                                       \
+        slot = nslot;                                                                                                       \
+        ++s;
+#define TZW_MM(ACC, P, AV)                                                                                                  \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) mfma_acc(ACC[t], AV, B[P][t]);
+#define TZW_STAGE1(VC, VN)                                                                                                  \
+    {                                                                                                                       \
+        TZW_STAGE_HEAD                                                                                                      \
+        f32x2 d[3][2];                                                                                                      \
+        TZW_WAIT(0, 3); TZW_MM(D[0], 0, VC[0]) B[4] = lds_read16<4 * 1024>(wb);                                             \
+        TZW_WAIT(1, 3); TZW_MM(D[1], 1, VC[1]) B[5] = lds_read16<5 * 1024>(wb);                                             \
+        read_d(nslot, d);                                                                                                   \
+        TZW_WAIT(2, 9); TZW_MM(D[2], 2, VC[2]) B[6] = lds_read16<6 * 1024>(wb);                                             \
+        TZW_WAIT(3, 9); TZW_MM(D[3], 3, VC[3]) B[7] = lds_read16<7 * 1024>(wb);                                             \
+        TZW_WAIT(4, 9); TZW_MM(D[4], 4, VC[4]) B[0] = lds_read16<0>(wn);                                                    \
+        TZW_WAIT(5, 9); TZW_MM(D[5], 5, VC[5]) B[1] = lds_read16<1024>(wn);                                                 \
+        TZW_WAIT(6, 3); TZW_MM(D[6], 6, VC[6]) B[2] = lds_read16<2048>(wn);                                                 \
+        /* the patch reads have arrived (empty asm: nothing is computed with d before here) and the transform is done */   \
+        /* HERE, not sunk to its first use right in front of an asm MFMA                                              */   \
+        TZW_TIED(d);                                                                                                        \
+        transform(d, VN);                                                                                                   \
+        TZW_TIE8(VN);                                                                                                       \
+        TZW_WAIT(7, 3); TZW_MM(D[7], 7, VC[7]) B[3] = lds_read16<3072>(wn);                                                 \
+        TZW_STAGE_TAIL                                                                                                      \
+    }
+#pragma unroll 1
+    while (s < S1) {   // S1 is even (sources are multiples of 16 channels)
+        TZW_STAGE1(V0, V1)
+        TZW_STAGE1(V1, V0)
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+
+    // ---- output transform, oracle order.  Row sums of the wave's two transform rows:
+    f32x4 Y[2][4];
+    {
+        f32x4 z0[2][NT], z1[2][NT];
+#pragma unroll
+        for (int li = 0; li < 2; ++li)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                z0[li][t] = (D[4 * li + 0][t] + D[4 * li + 1][t]) + D[4 * li + 2][t];
+                z1[li][t] = (D[4 * li + 1][t] - D[4 * li + 2][t]) - D[4 * li + 3][t];
+            }
+        // accumulator start of this wave's outputs: row a = ph of the tiles, columns b = 0, 1; register e <-> tile (g, e)
+        f32x4 in0[NT], in1[NT];
+        {
+            const int y = ty0 + 8 * (mt >> 1) + 2 * g + ph;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = cb * (16 * NT) + 16 * t + r;
+                if (a.init) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int x = tx0 + 8 * (mt & 1) + 2 * e;
+                        const bool ok = y < a.H && x < a.W;   // (W even wherever tiles are cut: x + 1 < W too)
+                        const float* ip = a.init + ((long long)(ok ? y * a.W + x : 0)) * a.ncols + col;
+                        in0[t][e] = ip[0];
+                        in1[t][e] = ip[x + 1 < a.W && ok ? a.ncols : 0];
+                    }
+                } else {
+                    const float b = a.bias[col];
+                    in0[t] = in1[t] = (f32x4){b, b, b, b};
+                }
+            }
+        }
+        // y[0][b] = ((init + Z[0][b]) + Z[1][b]) + Z[2][b] belongs to the wave with rows 0, 1 and needs Z[2] of its partner;
+        // y[1][b] = ((init + Z[1][b]) - Z[2][b]) - Z[3][b] belongs to the wave with rows 2, 3 and needs Z[1]: exchanged
+        // through 16 KB of LDS, one column tile per round
+        f32x4* xo = (f32x4*)(smem + NS * SLOT) + (wv * 2) * 64 + lane;
+        const f32x4* xi = (const f32x4*)(smem + NS * SLOT) + ((wv ^ 4) * 2) * 64 + lane;
+        const int give = ph == 0 ? 1 : 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            xo[0] = z0[give][t];
+            xo[64] = z1[give][t];
+            __syncthreads();
+            const f32x4 p0 = xi[0], p1 = xi[64];
+            if (ph == 0) {
+                Y[0][t] = ((in0[t] + z0[0][t]) + z0[1][t]) + p0;
+                Y[1][t] = ((in1[t] + z1[0][t]) + z1[1][t]) + p1;
+            } else {
+                Y[0][t] = ((in0[t] + p0) - z0[0][t]) - z0[1][t];
+                Y[1][t] = ((in1[t] + p1) - z1[0][t]) - z1[1][t];
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- the upsampled source: every output's chain goes on with its collapsed taps.  Stage = one channel quad; the
+    // wave's classes are (a = ph, b = 0, 1); weight sets in consumption order lp = 2 tap + b; A fragments = the 2 x 3
+    // half-resolution pixels around the tile (rows ph + tpy, columns b + tpx)
+    if (UPS) {
+        auto read_u = [&](int slot_, f32x2 (&u)[3]) {
+            const unsigned ad = sbase + (unsigned)slot_ * SLOT + ubase;
+            u[0] = lds_read2<0, 4>(ad);             // (row 0, columns 0, 1)
+            u[1] = lds_read2<8, WLW * 4>(ad);        // (row 0, column 2), (row 1, column 0)
+            u[2] = lds_read2<WLW * 4 + 4, WLW * 4 + 8>(ad);   // (row 1, columns 1, 2)
+        };
+        float A0[6], A1[6];
+        {
+            f32x2 u[3];
+            read_u(slot, u);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]) : : "memory");
+            A0[0] = u[0][0]; A0[1] = u[0][1]; A0[2] = u[1][0]; A0[3] = u[1][1]; A0[4] = u[2][0]; A0[5] = u[2][1];
+            TZW_TIE6(A0);
+            // (the weight stream was drained by that wait: restart it)
+            const unsigned wb = sbase + (unsigned)slot * SLOT + bbase;
+            B[0] = lds_read16<0>(wb);
+            B[1] = lds_read16<1024>(wb);
+            B[2] = lds_read16<2048>(wb);
+            B[3] = lds_read16<3072>(wb);
+        }
+        // lp = 2 tap + b: tap = (tpy, tpx) -> A[3 tpy + b + tpx]
+#define TZW_STAGE2(AC, AN)                                                                                                  \
+    {                                                                                                                       \
+        TZW_STAGE_HEAD                                                                                                      \
+        f32x2 u[3];                                                                                                         \
+        TZW_WAIT(0, 3); TZW_MM(Y[0], 0, AC[0]) B[4] = lds_read16<4 * 1024>(wb);                                             \
+        TZW_WAIT(1, 3); TZW_MM(Y[1], 1, AC[1]) B[5] = lds_read16<5 * 1024>(wb);                                             \
+        read_u(nslot, u);                                                                                                   \
+        TZW_WAIT(2, 6); TZW_MM(Y[0], 2, AC[1]) B[6] = lds_read16<6 * 1024>(wb);                                             \
+        TZW_WAIT(3, 6); TZW_MM(Y[1], 3, AC[2]) B[7] = lds_read16<7 * 1024>(wb);                                             \
+        TZW_WAIT(4, 6); TZW_MM(Y[0], 4, AC[3]) B[0] = lds_read16<0>(wn);                                                    \
+        TZW_WAIT(5, 6); TZW_MM(Y[1], 5, AC[4]) B[1] = lds_read16<1024>(wn);                                                 \
+        TZW_WAIT(6, 3); TZW_MM(Y[0], 6, AC[4]) B[2] = lds_read16<2048>(wn);                                                 \
+        TZW_TIEU(u);                                                                                                        \
+        AN[0] = u[0][0]; AN[1] = u[0][1]; AN[2] = u[1][0]; AN[3] = u[1][1]; AN[4] = u[2][0]; AN[5] = u[2][1];               \
+        TZW_TIE6(AN);                                                                                                       \
+        TZW_WAIT(7, 3); TZW_MM(Y[1], 7, AC[5]) B[3] = lds_read16<3072>(wn);                                                 \
+        TZW_STAGE_TAIL                                                                                                      \
+    }
+#pragma unroll 1
+        while (s < S) {
+            TZW_STAGE2(A0, A1)
+            TZW_STAGE2(A1, A0)
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads issued for a stage past the end
+#undef TZW_STAGE2
+#undef TZW_STAGE1
+#undef TZW_MM
+#undef TZW_STAGE_TAIL
+#undef TZW_STAGE_HEAD
+#undef TZW_WAIT
+
+    // ---- epilogues.  This wave's outputs: pixel row a = ph of its 16 tiles, columns b = 0, 1: Y[b][column tile][e],
+    // accumulator row 4 g + e = tile (tyl = g, txl = e)
+    const int oy = ty0 + 8 * (mt >> 1) + 2 * g + ph;
+    if (EPI == EPI_RAW) {
+        float* on = a.out0 + (long long)n * a.out0_nstride;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int x = tx0 + 8 * (mt & 1) + 2 * e + b;
+                if (oy < a.H && x < a.W) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) on[((long long)oy * a.W + x) * a.ncols + cb * (16 * NT) + 16 * t + r] = Y[b][t][e];
+                }
+            }
+    } else if (EPI == EPI_LSTM) {
+        // columns of this block: [i | f | g | o] x 16 channels of channel group cb (prednet.py:255-259):
+        // c = f * c_prev + i * g ; r = o * tanh(c)
+        const int ch = cb * 16 + r, R = a.Cout;
+        float* o0 = a.out0 + (long long)n * a.out0_nstride;
+        float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
+        long long pix[2][4];
+        bool ok[2][4];
+        float cp[2][4];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int x = tx0 + 8 * (mt & 1) + 2 * e + b;
+                ok[b][e] = oy < a.H && x < a.W;
+                pix[b][e] = ok[b][e] ? (long long)oy * a.W + x : 0;
+                cp[b][e] = a.aux ? a.aux[pix[b][e] * R + ch] : 0.0f;
+            }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gi = tz_hard_sigmoid(Y[b][0][e]);
+                const float gf = tz_hard_sigmoid(Y[b][1 % NT][e]);
+                const float gg = tz_tanh(Y[b][2 % NT][e]);
+                const float go = tz_hard_sigmoid(Y[b][3 % NT][e]);
+                const float t1 = gf * cp[b][e];
+                const float t2 = gi * gg;
+                const float c = t1 + t2;
+                const float rr = go * tz_tanh(c);
+                if (ok[b][e]) {
+                    o0[pix[b][e] * R + ch] = rr;
+                    if (o1) o1[pix[b][e] * R + ch] = c;
+                }
+            }
+    } else if (EPI == EPI_POOL_ERR) {
+        // prednet.py:289-291 then 274-277 of the next level: A = maxpool2x2(relu(conv)) -- the pooling window IS the tile --,
+        // e = [relu(Ahat0 - A), relu(A - Ahat0)] at the pooled resolution.  The wave holds one row of every window; the
+        // partner the other: wave ph = 0 finishes column tiles 0, 1, wave ph = 1 the rest
+        const int H2 = a.H >> 1, W2 = a.W >> 1, C = a.Cout;
+        float* o = a.out0 + (long long)n * a.out0_nstride;
+        f32x4 m[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = tz_relu(Y[0][t][e]), v1 = tz_relu(Y[1][t][e]);
+                m[t][e] = v1 > v0 ? v1 : v0;
+            }
+        f32x4* xo = (f32x4*)(smem + NS * SLOT) + (wv * 2) * 64 + lane;
+        const f32x4* xi = (const f32x4*)(smem + NS * SLOT) + ((wv ^ 4) * 2) * 64 + lane;
+        // (no run-time indices into m[]: it has to stay in registers)
+        xo[0] = ph == 0 ? m[2] : m[0];                       // the column tiles the partner finishes
+        xo[64] = ph == 0 ? m[NT - 1] : m[1];                 // (NT = 3: the second one of wave 0 is not used)
+        __syncthreads();
+        const f32x4 q0 = xi[0], q1 = xi[64];
+        const int yp = (ty0 >> 1) + 4 * (mt >> 1) + g;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (ph == 1 && 2 + k >= NT) break;               // wave 1 finishes column tiles 2 .. NT - 1, wave 0 tiles 0, 1
+            const int t = (ph == 0 ? 0 : 2) + k;
+            const f32x4 mine = ph == 0 ? m[k] : m[(2 + k) % NT], other = k == 0 ? q0 : q1;
+            const int ch = cb * (16 * NT) + 16 * t + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int xp = (tx0 >> 1) + 4 * (mt & 1) + e;
+                const bool okp = yp < H2 && xp < W2 && ch < C;
+                const long long pp = okp ? (long long)yp * W2 + xp : 0;
+                const float h = a.aux[okp ? pp * C + ch : 0];
+                const float mm = other[e] > mine[e] ? other[e] : mine[e];
+                const float d1 = h - mm, d2 = mm - h;
+                if (okp) {
+                    o[pp * 2 * C + ch] = tz_relu(d1);
+                    o[pp * 2 * C + C + ch] = tz_relu(d2);
+                }
+            }
+        }
+    }
+}
