@@ -96,8 +96,9 @@ int tz_set_conv_impl(tz_ctx* ctx, int lds_dma);
  * chain (rounds 1-3; what files written by earlier builds need).  2 = TZ-PA2: the per-frame convolutions of levels >= 1
  * evaluate their same-resolution source as Winograd F(2x2, 3x3) chains (2.25x fewer multiplies; oracle/tz_oracle.c
  * conv3x3_wino), everything else as in TZ-PA1.  Encoder and decoder must use the same contract: the on-disk format of the
- * reference has no place to record it.  A context starts with the value of the environment variable TEZIP_PA (default:
- * see DESIGN.md); switching re-prepares nothing. */
+ * reference has no place to record it.  0 (the default; or the environment variable TEZIP_PA) = by padded frame size, which
+ * both sides know: TZ-PA2 from 256 x 256 pixels on, TZ-PA1 below.  tz_get_contract returns the contract in force (1 or 2)
+ * for the prepared model.  Switching re-prepares nothing. */
 int tz_set_contract(tz_ctx* ctx, int contract);
 int tz_get_contract(tz_ctx* ctx);
 /* Diagnostic: the inverse scan of decompress.py:22-29 (k_scan2p) lets a workgroup wait for the block sums of the workgroups

@@ -79,7 +79,7 @@ class CPredNet:
 
     def set_contract(self, contract):
         """1 = TZ-PA1 (direct chains everywhere), 2 = TZ-PA2 (tz_oracle.c conv3x3_wino for the per-frame convolutions of
-        levels >= 1)."""
+        levels >= 1), 0 = by padded frame size (the default of a new model: TZ-PA2 from 256 x 256 pixels on)."""
         lib().tzo_model_set_contract(self.h, int(contract))
         return self
 

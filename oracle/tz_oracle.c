@@ -317,6 +317,9 @@ tzo_model* tzo_model_create(int L, const int* stack, const int* rstack, int Hp, 
     const int order[4] = {2, 1, 0, 3}; /* list order c, f, i, o -> our gate slots */
     for (int g = 0; g < 4; ++g)
         for (int l = 0; l < L; ++l) { m->g_k[order[g]][l] = w[k++]; m->g_b[order[g]][l] = w[k++]; }
+    /* the contract in force when nothing else is asked for is a function of the padded frame size, which encoder and decoder
+       both know (tz_prednet.hip effective_contract): TZ-PA2 from 256 x 256 pixels on, TZ-PA1 below */
+    m->contract = (long long)Hp * Wp >= 256LL * 256 ? 2 : 1;
     return m;
 }
 
@@ -544,7 +547,10 @@ static int wino_gate_ok(const tzo_model* m, int l) {
 static int wino_a_ok(const tzo_model* m, int l) {
     return m->contract == 2 && l >= 1 && (2 * m->stack[l]) % 16 == 0 && (m->stack[l + 1] % 64 == 0 || m->stack[l + 1] % 48 == 0);
 }
-void tzo_model_set_contract(tzo_model* m, int contract) { m->contract = contract == 2 ? 2 : 1; }
+void tzo_model_set_contract(tzo_model* m, int contract) {
+    m->contract = contract == 0 ? ((long long)m->Hp * m->Wp >= 256LL * 256 ? 2 : 1) : (contract == 2 ? 2 : 1);
+}
+int tzo_model_get_contract(const tzo_model* m) { return m->contract; }
 
 /* probe for tests: one convolution in either statement.  x: [H][W][C] same-resolution source (or NULL), xu: [H/2][W/2][Cu]
  * upsampled source (or NULL), Wt: HWIO (3,3,C+Cu,Cout) */

@@ -26,6 +26,10 @@ for (h, w, batch, reps) in ((512, 512, 4, 24), (376, 1248, 2, 8), (128, 160, 4, 
     for rep in range(reps * MULT):
         nt = 3 * batch
         frames = synth.turbulence(nt, h, w, seed=1000 + runs)
+        # both arithmetic contracts: TZ-PA1 (k_conv16 / k_conv16b / k_convlat against k_conv3x3) and TZ-PA2 (k_wino --
+        # asm MFMAs in AGPRs, DMA ring with counted waits -- against the plain k_wino_ref), alternating over the repetitions
+        pa = 1 + (rep & 1)
+        ctx.set_contract(pa)
         out = []
         for impl, lat in ((1, None), (0, None), (1, None), (1, "always")):
             ctx.set_conv_impl(impl, lat=lat)
@@ -37,6 +41,7 @@ for (h, w, batch, reps) in ((512, 512, 4, 24), (376, 1248, 2, 8), (128, 160, 4, 
         bad += not ok
         if not ok:
             d = np.argwhere(out[0] != out[1])
-            print("MISMATCH", h, w, batch, rep, len(d), d[:4].tolist(), flush=True)
-print("soak: %d rollouts, %d mismatching, %.1f s" % (runs, bad, time.time() - t0))
+            print("MISMATCH", h, w, batch, rep, "TZ-PA%d" % pa, len(d), d[:4].tolist(), flush=True)
+ctx.set_contract(0)
+print("soak: %d rollouts (both contracts), %d mismatching, %.1f s" % (runs, bad, time.time() - t0))
 sys.exit(1 if bad else 0)

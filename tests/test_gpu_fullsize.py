@@ -264,24 +264,34 @@ def test_soak_lds_dma_kernels_forced_small_grid_kernel_included():
 
 
 def test_the_hot_launches_run_on_the_kernels_the_design_names(ctx):
-    """Dispatch guard: at 512x512 with four windows every convolution of levels >= 1 is k_conv16 (95 launches
-    per 19-step rollout), the level-0 ones k_conv16b / k_conv_small, and nothing falls back to the general
-    k_conv3x3; at 64x64 the levels >= 1 run on k_convlat (split gate launches included).  A silent fallback
-    would keep every parity test green and cost 15 % of the headline."""
+    """Dispatch guard: at 512x512 with four windows every convolution of levels >= 1 is k_wino (TZ-PA2 is the contract in
+    force from 256x256 pixels on; 95 launches per 19-step rollout) -- k_conv16 when TZ-PA1 is asked for --, the level-0
+    ones k_conv16b / k_conv_small, and nothing falls back to the general k_conv3x3; at 64x64 (TZ-PA1 by size) the levels
+    >= 1 run on k_convlat (split gate launches included).  A silent fallback would keep every parity test green and
+    cost a large part of the headline."""
     frames = synth.turbulence(80, 512, 512, seed=9)
     ctx.prepare(512, 512, max_batch=4)
+    assert ctx.get_contract() == 2
     ctx.rollout(frames, 0, 20)
     ctx.prof_enable(True)
     ctx.prof_reset()
     ctx.rollout(frames, 0, 20)
     p = ctx.prof_get()
-    assert p["conv16_lds_dma"][1] == 95 and p["conv16b_level0"][1] == 38 and p["conv_small_valu"][1] == 19
+    assert p["wino_pa2"][1] == 95 and p["conv16_lds_dma"][1] == 0 and p["conv16b_level0"][1] == 38 and p["conv_small_valu"][1] == 19
+    assert p["conv3x3_general"][1] == 0 and p["convlat_small_grid"][1] == 0
+    ctx.set_contract(1)
+    ctx.prof_reset()
+    ctx.rollout(frames, 0, 20)
+    p = ctx.prof_get()
+    ctx.set_contract(0)
+    assert p["conv16_lds_dma"][1] == 95 and p["wino_pa2"][1] == 0 and p["conv16b_level0"][1] == 38 and p["conv_small_valu"][1] == 19
     assert p["conv3x3_general"][1] == 0 and p["convlat_small_grid"][1] == 0
     # the level-0 error unit is launched for the step that starts from the key frames only: every later step finds its
     # error maps written by the prediction kernel of the step before (round 3)
     assert p["err0"][1] == 1
     small = synth.moving_blobs(40, 64, 64)
     ctx.prepare(64, 64, max_batch=2)
+    assert ctx.get_contract() == 1
     ctx.rollout(small, 0, 20)
     ctx.prof_reset()
     ctx.rollout(small, 0, 20)

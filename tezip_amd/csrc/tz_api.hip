@@ -92,8 +92,8 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
         if (e && e[0] == '0') ctx->conv_impl = 0;
         e = getenv("TEZIP_LAT");                 // k_convlat: 0 never, 1 cost model (default), 2 wherever eligible
         if (e) ctx->lat_mode = atoi(e);
-        e = getenv("TEZIP_PA");                  // arithmetic contract a context starts with (tz_set_contract): 1 or 2
-        if (e && (e[0] == '1' || e[0] == '2') && !e[1]) ctx->contract = e[0] - '0';
+        e = getenv("TEZIP_PA");                  // arithmetic contract a context starts with (tz_set_contract): 0 (default), 1 or 2
+        if (e && e[0] >= '0' && e[0] <= '2' && !e[1]) ctx->contract = e[0] - '0';
     }
     ctx->device = device;
     if (hip_stream) {

@@ -55,7 +55,7 @@ struct tz_ctx {
     tz_model* model = nullptr;
     int conv_impl = 1;                // tz_set_conv_impl: 1 = LDS-DMA kernels where they apply
     int lat_mode = 1;                 // k_convlat: 0 never, 1 where the cost model says so, 2 wherever eligible (TEZIP_LAT)
-    int contract = 1;                 // arithmetic contract of the predictor: 1 = TZ-PA1, 2 = TZ-PA2 (tz_set_contract, TEZIP_PA)
+    int contract = 0;                 // arithmetic contract of the predictor: 0 = by frame size, 1 = TZ-PA1, 2 = TZ-PA2 (tz_set_contract, TEZIP_PA)
     // rollout-resident data
     int nt = 0, H = 0, W = 0, Hp = 0, Wp = 0, warm_up = 0;
     uint8_t* d_frames = nullptr;      // nt*H*W*3 (encoder: originals; decoder: key stack)

@@ -341,20 +341,46 @@ static int launch_wino_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
     return TZ_OK;
 }
 
+template <int NT, int EPI, bool UPS>
+static int launch_wino_ref_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
+    const long long nthreads = (long long)((a.W + 1) / 2) * ((a.H + 1) / 2) * a.ncb * (EPI == EPI_LSTM ? 16 : 16 * NT);
+    hipLaunchKernelGGL((k_wino_ref<NT, EPI, UPS>), dim3((unsigned)std::min<long long>((nthreads + 255) / 256, 65535), nbatch), dim3(256), 0,
+                       ctx->stream, a);
+    TZ_HIP(ctx, hipGetLastError());
+    return TZ_OK;
+}
+
 static int launch_wino(tz_ctx* ctx, int NT, int epi, bool ups, const ConvArgs& a, int nbatch) {
+    if (!ctx->conv_impl) {   // tz_set_conv_impl(0): the plain statement of the same chains
+        if (NT == 4 && epi == EPI_LSTM) return ups ? launch_wino_ref_t<4, EPI_LSTM, true>(ctx, a, nbatch) : launch_wino_ref_t<4, EPI_LSTM, false>(ctx, a, nbatch);
+        if (NT == 4 && epi == EPI_RAW) return ups ? launch_wino_ref_t<4, EPI_RAW, true>(ctx, a, nbatch) : launch_wino_ref_t<4, EPI_RAW, false>(ctx, a, nbatch);
+        if (epi == EPI_POOL_ERR && !ups) return NT == 4 ? launch_wino_ref_t<4, EPI_POOL_ERR, false>(ctx, a, nbatch) : launch_wino_ref_t<3, EPI_POOL_ERR, false>(ctx, a, nbatch);
+        return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "no TZ-PA2 reference kernel for NT=%d epilogue=%d upsampled=%d", NT, epi, (int)ups);
+    }
     if (NT == 4 && epi == EPI_LSTM) return ups ? launch_wino_t<4, EPI_LSTM, true>(ctx, a, nbatch) : launch_wino_t<4, EPI_LSTM, false>(ctx, a, nbatch);
     if (NT == 4 && epi == EPI_RAW) return ups ? launch_wino_t<4, EPI_RAW, true>(ctx, a, nbatch) : launch_wino_t<4, EPI_RAW, false>(ctx, a, nbatch);
     if (epi == EPI_POOL_ERR && !ups) return NT == 4 ? launch_wino_t<4, EPI_POOL_ERR, false>(ctx, a, nbatch) : launch_wino_t<3, EPI_POOL_ERR, false>(ctx, a, nbatch);
     return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "no TZ-PA2 kernel for NT=%d epilogue=%d upsampled=%d", NT, epi, (int)ups);
 }
 
+// The contract in force: what tz_set_contract chose, or -- 0, the default -- a function of the padded frame size that
+// encoder and decoder both know: TZ-PA2 from 256 x 256 pixels on, TZ-PA1 below (there the per-frame convolutions are
+// latency chains on a mostly idle chip and run on k_convlat).
+static constexpr long long TZ_PA2_MIN_PIXELS = 256 * 256;
+static int effective_contract(const tz_ctx* ctx) {
+    if (ctx->contract) return ctx->contract;
+    const tz_model* m = ctx->model;
+    return m && (long long)m->Hp * m->Wp >= TZ_PA2_MIN_PIXELS ? 2 : 1;
+}
+
 extern "C" int tz_set_contract(tz_ctx* ctx, int contract) {
     if (!ctx) return TZ_ERR_INVALID;
-    if (contract != 1 && contract != 2) return tz_fail(ctx, TZ_ERR_INVALID, "tz_set_contract: %d is neither 1 (TZ-PA1) nor 2 (TZ-PA2)", contract);
+    if (contract < 0 || contract > 2)
+        return tz_fail(ctx, TZ_ERR_INVALID, "tz_set_contract: %d is not 0 (by frame size), 1 (TZ-PA1) or 2 (TZ-PA2)", contract);
     ctx->contract = contract;   // nothing is re-prepared: both forms of a convolution are packed, the constants are TZ-PA1 in both
     return TZ_OK;
 }
-extern "C" int tz_get_contract(tz_ctx* ctx) { return ctx ? ctx->contract : TZ_ERR_INVALID; }
+extern "C" int tz_get_contract(tz_ctx* ctx) { return ctx ? effective_contract(ctx) : TZ_ERR_INVALID; }
 
 extern "C" int tz_set_conv_impl(tz_ctx* ctx, int lds_dma) {
     if (!ctx) return TZ_ERR_INVALID;
@@ -436,7 +462,7 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
     }
     // TZ-PA2: the per-frame convolutions of levels >= 1 go through ONE kernel whatever the batch and the frame size
     // (the contract fixes the arithmetic per convolution; k_wino_ref is its cross-check, tz_set_conv_impl(0))
-    if (a.Wwino && ctx->contract == 2 && fullk && (epi == EPI_LSTM || epi == EPI_POOL_ERR || epi == EPI_RAW)) {
+    if (a.Wwino && effective_contract(ctx) == 2 && fullk && (epi == EPI_LSTM || epi == EPI_POOL_ERR || epi == EPI_RAW)) {
         ps.sub = TZP_WINO;
         return launch_wino(ctx, NT, epi, ups, a, nbatch);
     }
@@ -796,7 +822,7 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         ConvArgs a;
         aconv_args(l, a);
         // (not under TZ-PA2 where the gate convolution is a k_wino one: the split halves are TZ-PA1 chains)
-        if (m->P[l] && m->gate_t1[l].NT == 4 && m->gate_t1[l].segs.size() == 2 && !(ctx->contract == 2 && m->gate_t1[l].d_Wwino)) {
+        if (m->P[l] && m->gate_t1[l].NT == 4 && m->gate_t1[l].segs.size() == 2 && !(effective_contract(ctx) == 2 && m->gate_t1[l].d_Wwino)) {
             ConvArgs ge;
             gate_args(l, ge);
             ge.nsrc = 1;                      // the chain over E_l only

@@ -70,6 +70,19 @@ __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
 __device__ __forceinline__ void mfma_acc(f32x4& acc, float a, float b) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
+// float32 add / subtract the compiler cannot pair into v_pk_add_f32 (it did: 16 packed adds + 12 moves to line their
+// operands up, 28 instructions where 20 do -- and a packed fp32 instruction takes the SIMD longer than a plain one, all of
+// it time the matrix pipe does not get).  Same IEEE results.
+__device__ __forceinline__ float fsub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fadd(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <int K>
 __device__ __forceinline__ void read_rows(unsigned ad, f32x2 (&d)[3][2]) {   // row k of the wave's three patch rows: (d0, d2), (d1, d3)
     d[K][0] = lds_read2<72 * K, 72 * K + 4>(ad);
@@ -165,19 +178,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float d0 = d[k][0][0], d2 = d[k][0][1], d1 = d[k][1][0], d3 = d[k][1][1];
-            t[k][0] = d0 - d2;
-            t[k][1] = d1 + d2;
-            t[k][2] = d2 - d1;
-            t[k][3] = d1 - d3;
+            t[k][0] = fsub(d0, d2);
+            t[k][1] = fadd(d1, d2);
+            t[k][2] = fsub(d2, d1);
+            t[k][3] = fsub(d1, d3);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (ph == 0) {   // rows 0, 1, 2 of the patch: V[0] = t0 - t2, V[1] = t1 + t2
-                V[j] = t[0][j] - t[2][j];
-                V[4 + j] = t[1][j] + t[2][j];
+                V[j] = fsub(t[0][j], t[2][j]);
+                V[4 + j] = fadd(t[1][j], t[2][j]);
             } else {         // rows 1, 2, 3: V[2] = t2 - t1, V[3] = t1 - t3
-                V[j] = t[1][j] - t[0][j];
-                V[4 + j] = t[0][j] - t[2][j];
+                V[j] = fsub(t[1][j], t[0][j]);
+                V[4 + j] = fsub(t[0][j], t[2][j]);
             }
         }
     };
@@ -454,6 +467,132 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     o[pp * 2 * C + ch] = tz_relu(d1);
                     o[pp * 2 * C + C + ch] = tz_relu(d2);
                 }
+            }
+        }
+    }
+}
+
+// k_wino_ref: the same TZ-PA2 convolutions (and epilogues) as k_wino, written the plain way -- one thread per (tile, column
+// group), every chain a loop of fmaf in the order the contract states -- as the device-side cross-check of the hand-scheduled
+// kernel (tz_set_conv_impl(0), as k_conv3x3 is for k_conv16).  It reads the same packed stage image (pack_wino), so a packing
+// error cannot hide between the two; ~50x slower.
+//   EPI_LSTM: thread = (tile, channel of the column block): its four gate columns one after the other, then the cell update
+//   EPI_POOL_ERR / EPI_RAW: thread = (tile, column)
+template <int NT, int EPI, bool UPS>
+__global__ __launch_bounds__(256) void k_wino_ref(const ConvArgs a) {
+    const int TX = (a.W + 1) / 2, TY = (a.H + 1) / 2;
+    const int gcols = EPI == EPI_LSTM ? 16 : 16 * NT;           // threads per tile and column block
+    const long long nthreads = (long long)TX * TY * a.ncb * gcols;
+    const int n = blockIdx.y;
+    const int S1 = a.src[0].C >> 2, C0 = a.src[0].C;
+    const float* x0 = a.src[0].p + (long long)n * a.src[0].nstride;
+    const float* x1 = UPS ? a.src[1].p + (long long)n * a.src[1].nstride : nullptr;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nthreads; id += (long long)gridDim.x * blockDim.x) {
+        const int jc = (int)(id % gcols);
+        long long q = id / gcols;
+        const int cb = (int)(q % a.ncb);
+        q /= a.ncb;
+        const int tx = (int)(q % TX), ty = (int)(q / TX);
+        float Yg[4][4];   // [gate or 0][output 2 a + b]
+        const int ngate = EPI == EPI_LSTM ? 4 : 1;
+        for (int gt = 0; gt < ngate; ++gt) {
+            const int nt = EPI == EPI_LSTM ? gt : jc >> 4, j = jc & 15;
+            const int col = cb * (16 * NT) + 16 * nt + j;
+            float D[16];
+            for (int p = 0; p < 16; ++p) D[p] = 0.0f;
+            for (int c = 0; c < C0; ++c) {
+                float d[4][4], t[4][4];
+                for (int rr = 0; rr < 4; ++rr)
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int yy = 2 * ty - 1 + rr, xx = 2 * tx - 1 + cc;
+                        d[rr][cc] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? x0[((long long)yy * a.W + xx) * a.src[0].pstride + c] : 0.0f;
+                    }
+                for (int rr = 0; rr < 4; ++rr) {
+                    t[rr][0] = d[rr][0] - d[rr][2];
+                    t[rr][1] = d[rr][1] + d[rr][2];
+                    t[rr][2] = d[rr][2] - d[rr][1];
+                    t[rr][3] = d[rr][1] - d[rr][3];
+                }
+                const float* wq = a.Wwino + ((((long long)(c >> 2) * a.ncb + cb) * 16) * 64 + (c & 3) * 16 + j) * 4 + nt;
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float v0 = t[0][jj] - t[2][jj], v1 = t[1][jj] + t[2][jj], v2 = t[2][jj] - t[1][jj], v3 = t[1][jj] - t[3][jj];
+                    D[0 + jj] = fmaf(v0, wq[(0 + jj) * 256], D[0 + jj]);
+                    D[4 + jj] = fmaf(v1, wq[(4 + jj) * 256], D[4 + jj]);
+                    D[8 + jj] = fmaf(v2, wq[(8 + jj) * 256], D[8 + jj]);
+                    D[12 + jj] = fmaf(v3, wq[(12 + jj) * 256], D[12 + jj]);
+                }
+            }
+            float z0[4], z1[4];
+            for (int i = 0; i < 4; ++i) {
+                z0[i] = (D[4 * i] + D[4 * i + 1]) + D[4 * i + 2];
+                z1[i] = (D[4 * i + 1] - D[4 * i + 2]) - D[4 * i + 3];
+            }
+            float in[4];
+            for (int o = 0; o < 4; ++o) {
+                const int y = 2 * ty + (o >> 1), x = 2 * tx + (o & 1);
+                in[o] = a.init ? a.init[((long long)(y < a.H && x < a.W ? y * a.W + x : 0)) * a.ncols + col] : a.bias[col];
+            }
+            float* Y = Yg[gt];
+            Y[0] = ((in[0] + z0[0]) + z0[1]) + z0[2];
+            Y[1] = ((in[1] + z1[0]) + z1[1]) + z1[2];
+            Y[2] = ((in[2] + z0[1]) - z0[2]) - z0[3];
+            Y[3] = ((in[3] + z1[1]) - z1[2]) - z1[3];
+            if (UPS) {   // channel quads ascending, the 4 taps of a quad, its 4 channels
+                const int H2 = a.H >> 1, W2 = a.W >> 1, C1 = a.src[1].C;
+                for (int o = 0; o < 4; ++o) {
+                    const int ay = o >> 1, bx = o & 1;
+                    float acc = Y[o];
+                    for (int c0 = 0; c0 < C1; c0 += 4)
+                        for (int tp = 0; tp < 4; ++tp) {
+                            const int ly = ty - 1 + ay + (tp >> 1), lx = tx - 1 + bx + (tp & 1);
+                            const bool inside = ly >= 0 && ly < H2 && lx >= 0 && lx < W2;
+                            const float* wq = a.Wwino + ((((long long)(S1 + (c0 >> 2)) * a.ncb + cb) * 16 + 8 * ay + 2 * tp + bx) * 64 + j) * 4 + nt;
+                            for (int k = 0; k < 4; ++k) {
+                                const float xv = inside ? x1[((long long)ly * W2 + lx) * a.src[1].pstride + c0 + k] : 0.0f;
+                                acc = fmaf(xv, wq[k * 64], acc);
+                            }
+                        }
+                    Y[o] = acc;
+                }
+            }
+        }
+        if (EPI == EPI_RAW) {
+            float* on = a.out0 + (long long)n * a.out0_nstride;
+            for (int o = 0; o < 4; ++o) {
+                const int y = 2 * ty + (o >> 1), x = 2 * tx + (o & 1);
+                if (y < a.H && x < a.W) on[((long long)y * a.W + x) * a.ncols + cb * (16 * NT) + jc] = Yg[0][o];
+            }
+        } else if (EPI == EPI_LSTM) {
+            const int ch = cb * 16 + jc, R = a.Cout;
+            float* o0 = a.out0 + (long long)n * a.out0_nstride;
+            float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
+            for (int o = 0; o < 4; ++o) {
+                const int y = 2 * ty + (o >> 1), x = 2 * tx + (o & 1);
+                if (y >= a.H || x >= a.W) continue;
+                const long long pix = (long long)y * a.W + x;
+                const float cp = a.aux ? a.aux[pix * R + ch] : 0.0f;
+                const float gi = tz_hard_sigmoid(Yg[0][o]), gf = tz_hard_sigmoid(Yg[1][o]), gg = tz_tanh(Yg[2][o]), go = tz_hard_sigmoid(Yg[3][o]);
+                const float t1 = gf * cp;
+                const float t2 = gi * gg;
+                const float c = t1 + t2;
+                const float rr = go * tz_tanh(c);
+                o0[pix * R + ch] = rr;
+                if (o1) o1[pix * R + ch] = c;
+            }
+        } else {   // EPI_POOL_ERR: the pooling window is the tile
+            const int H2 = a.H >> 1, W2 = a.W >> 1, C = a.Cout, ch = cb * (16 * NT) + jc;
+            if (ty < H2 && tx < W2 && ch < C) {
+                float m = tz_relu(Yg[0][0]);
+                for (int o = 1; o < 4; ++o) {
+                    const float t = tz_relu(Yg[0][o]);
+                    if (t > m) m = t;
+                }
+                const long long pp = (long long)ty * W2 + tx;
+                const float h = a.aux[pp * C + ch];
+                const float d1 = h - m, d2 = m - h;
+                float* o = a.out0 + (long long)n * a.out0_nstride;
+                o[pp * 2 * C + ch] = tz_relu(d1);
+                o[pp * 2 * C + C + ch] = tz_relu(d2);
             }
         }
     }
