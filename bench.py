@@ -162,6 +162,21 @@ def live_flops_per_px0(cfg):
     return 2 * mac
 
 
+def wino_executed_flops_per_px0(cfg):
+    """FLOPs the TZ-PA2 kernel k_wino EXECUTES for the convolutions conv16_flops_per_px0 counts: the same-resolution source
+    of every one of them through F(2x2, 3x3) -- 16 multiplies per 2x2 outputs and input channel instead of 36, i.e. 1/2.25 of
+    the direct form's --, the upsampled source through its 4 collapsed taps as before."""
+    st, rs, L = cfg.stack_sizes, cfg.R_stack_sizes, cfg.nb_layers
+    mac = 0.0
+    for l in range(L):
+        gate_srcs_ok = (2 * st[l]) % 16 == 0 and (l == L - 1 or rs[l + 1] % 16 == 0) and rs[l] % 16 == 0
+        if gate_srcs_ok:
+            mac += (4 * 2 * st[l] + (4 * rs[l + 1] if l < L - 1 else 0)) * 4 * rs[l] / 4 ** l
+        if l < L - 1 and (2 * st[l]) % 16 == 0 and st[l + 1] % 48 == 0:
+            mac += 4 * 2 * st[l] * st[l + 1] / 4 ** l
+    return 2 * mac
+
+
 def conv16_flops_per_px0(cfg):
     """The part of live_flops_per_px0 that k_conv16 executes: gate convolutions and A convolutions
     whose sources all have a multiple of 16 channels (levels >= 1 of the default model)."""
@@ -401,15 +416,20 @@ def main():
     conv_ms, conv_n = prof["conv3x3_mfma"]
     flops_step = live_flops_per_px0(cfg) * H * W * n_pred
     conv_tflops = flops_step / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    SUB = ("conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general", "convlat_small_grid")  # sub-classes of conv3x3_mfma
+    SUB = ("conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general", "convlat_small_grid", "wino_pa2")  # sub-classes of conv3x3_mfma
     step_dev_ms = sum(v[0] for k, v in prof.items() if k not in SUB)
     c16_ms, c16_n = prof["conv16_lds_dma"]               # the dominant kernel on its own
+    wino_ms, wino_n = prof.get("wino_pa2", (0.0, 0))      # ... under TZ-PA2 (the contract in force at this frame size)
+    contract = ctx.get_contract()
     lat_ms, lat_n = prof.get("convlat_small_grid", (0.0, 0))
     # (with fewer than 4 windows per GPU -- `--frames 40` -- the upper levels run on k_convlat: same convolutions,
     # same FLOPs; counted with the dominant kernel so that the fraction stays FLOPs of these launches / their time)
     c16_ms, c16_n = c16_ms + lat_ms, c16_n + lat_n
     c16_flops = conv16_flops_per_px0(cfg) * H * W * n_pred
     c16_tflops = c16_flops / (c16_ms * 1e-3) / 1e12 if c16_ms > 0 else 0.0
+    wino_flops = wino_executed_flops_per_px0(cfg) * H * W * n_pred
+    wino_tflops = wino_flops / (wino_ms * 1e-3) / 1e12 if wino_ms > 0 else 0.0
+    wino_direct_tflops = c16_flops / (wino_ms * 1e-3) / 1e12 if wino_ms > 0 else 0.0
     # the elementwise delta kernel the north star names (compress.py:292-314).  Since round 3 the STEP forms its deltas inside
     # the fused kernels (k_q_tiles reads pred / orig directly; lossless: k_delta_sd_fused), so the stand-alone kernel is
     # measured through its own C-ABI entry point (tz_delta_encode) on the step's own prediction stack, device resident
@@ -509,6 +529,26 @@ def main():
             except Exception as e:
                 extras["sharded_path"] = {"error": repr(e)}
 
+        # ------------------------------------------------------------ the same step under the other arithmetic contract
+        if world == 1 and contract == 2:
+            try:
+                ctx.set_contract(1)
+                el = job.timed(own_step, max(3, min(args.steps, 10)), 1)
+                ctx.prof_enable(True)
+                ctx.prof_reset()
+                own_step()
+                p1 = ctx.prof_get()
+                ctx.prof_enable(False)
+                k16 = p1["conv16_lds_dma"][0]
+                rate1 = frames.shape[0] * max(3, min(args.steps, 10)) / el
+                extras["tz_pa1"] = {"frames_per_s": rate1, "ms_per_step": el / max(3, min(args.steps, 10)) * 1e3,
+                                    "k_conv16_ms_per_step": k16, "k_conv16_frac_of_mfma_peak": c16_flops / (k16 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                    "tz_pa2_over_tz_pa1": value / rate1,
+                                    "note": "the step of rounds 1-3 (every convolution a direct fmaf chain, k_conv16), same job, same box"}
+            finally:
+                ctx.set_contract(0)
+                own_step()
+
         # ------------------------------------------------------------ the other BASELINE.json configurations (seconds each)
         if world == 1:
             try:
@@ -597,18 +637,37 @@ def main():
                        "backend": backend, "ranks_share_one_gpu": single_dev if world > 1 else False},
             "sharded_check": check,
             "compression_ratio": ratio,
-            "roofline": {"kernel": "k_conv16 (fp32 MFMA implicit GEMM staged by LDS-DMA: every convolution of levels >= 1, "
-                                   "%.0f %% of the step's device time)" % (100.0 * c16_ms / max(step_dev_ms, 1e-9)),
-                         "bound": "mfma", "achieved": c16_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": c16_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic("k_conv16<"),
-                         "launches_per_step": c16_n, "ms_per_launch": c16_ms / max(c16_n, 1), "ms_per_step": c16_ms,
-                         "algorithmic_flops_per_step": c16_flops,
-                         "algorithmic_flops_per_launch": c16_flops / max(c16_n, 1)},
-            "roofline_all_convolutions": {"kernel": "k_conv16 + k_conv16b + k_conv_small (+ k_conv3x3): all PredNet convolutions",
-                                          "bound": "mfma", "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS,
-                                          "unit": "TFLOP/s", "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS,
-                                          "traffic": measured_traffic("k_conv"), "launches_per_step": conv_n,
-                                          "ms_per_step": conv_ms, "algorithmic_flops_per_step": flops_step},
+            "arithmetic_contract": "TZ-PA%d" % contract,
+            "roofline": ({"kernel": "k_wino (TZ-PA2: every convolution of levels >= 1, the same-resolution source as Winograd F(2x2,3x3) "
+                                    "chains on fp32 MFMA, staged by LDS-DMA; %.0f %% of the step's device time)"
+                                    % (100.0 * wino_ms / max(step_dev_ms, 1e-9)),
+                          "bound": "mfma", "achieved": wino_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                          "frac": wino_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic("k_wino<"),
+                          "launches_per_step": wino_n, "ms_per_launch": wino_ms / max(wino_n, 1), "ms_per_step": wino_ms,
+                          "algorithmic_flops_per_step": wino_flops, "algorithmic_flops_per_launch": wino_flops / max(wino_n, 1),
+                          "flop_accounting": "EXECUTED: 16 multiplies per 2x2 outputs and input channel of a same-resolution source "
+                                             "(the direct form has 36), 4 collapsed taps on an upsampled source",
+                          "direct_equivalent": {"achieved": wino_direct_tflops, "frac": wino_direct_tflops / PEAK_FP32_MFMA_TFLOPS,
+                                                "flops_per_step": c16_flops,
+                                                "note": "the same launches priced with the FLOPs of the direct form (what k_conv16 "
+                                                        "executes under TZ-PA1): a speed-up figure, not a utilisation"}}
+                         if wino_n else
+                         {"kernel": "k_conv16 (fp32 MFMA implicit GEMM staged by LDS-DMA: every convolution of levels >= 1, "
+                                    "%.0f %% of the step's device time)" % (100.0 * c16_ms / max(step_dev_ms, 1e-9)),
+                          "bound": "mfma", "achieved": c16_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                          "frac": c16_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic("k_conv16<"),
+                          "launches_per_step": c16_n, "ms_per_launch": c16_ms / max(c16_n, 1), "ms_per_step": c16_ms,
+                          "algorithmic_flops_per_step": c16_flops,
+                          "algorithmic_flops_per_launch": c16_flops / max(c16_n, 1)}),
+            "roofline_all_convolutions": {"kernel": "all PredNet convolutions of a step: k_wino / k_conv16 + k_conv16b + k_conv_small",
+                                          "bound": "mfma",
+                                          "achieved": (flops_step - c16_flops + wino_flops) / (conv_ms * 1e-3) / 1e12 if wino_n else conv_tflops,
+                                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": ((flops_step - c16_flops + wino_flops) / (conv_ms * 1e-3) / 1e12 if wino_n else conv_tflops) / PEAK_FP32_MFMA_TFLOPS,
+                                          "direct_equivalent_tflops": conv_tflops,
+                                          "traffic": measured_traffic("k_wino<" if wino_n else "k_conv"), "launches_per_step": conv_n,
+                                          "ms_per_step": conv_ms,
+                                          "algorithmic_flops_per_step": flops_step - c16_flops + wino_flops if wino_n else flops_step},
             "roofline_delta": {"kernel": "k_delta_flat (stand-alone tz_delta_encode on the step's prediction stack; the step itself forms "
                                          "its deltas inside the fused quantiser / spatial-delta kernels)", "bound": "hbm", "achieved": delta_gbs, "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": delta_gbs / PEAK_HBM_GBS, "traffic": measured_traffic("k_delta_flat"),

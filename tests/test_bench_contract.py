@@ -70,6 +70,8 @@ def test_flop_accounting_matches_the_design_numbers(bench):
     cfg = PredNetConfig()
     assert bench.live_flops_per_px0(cfg) == 416754      # executed live work per level-0 pixel and frame
     assert bench.conv16_flops_per_px0(cfg) == 405504    # ... of which k_conv16 (levels >= 1)
+    # TZ-PA2: the same convolutions as k_wino executes them: 165,888 same-resolution MACs / 2.25 + 36,864 collapsed-tap MACs
+    assert bench.wino_executed_flops_per_px0(cfg) == 2 * (165888 // 9 * 4 + 36864) == 221184
 
 
 def test_the_line_says_which_frames_per_second_value_is(bench):

@@ -35,6 +35,10 @@ FLAG_TABLE = (
     # not in the reference: byte-shuffled payload (flagged in the trailer; the reference cannot read such a file)
     (None, "--shuffle", dict(action="store_true")),
     (None, "--sweep", dict(type=int, nargs="*", metavar="window_size", dest="sweep", default=None)),
+    # not in the reference: the predictor's arithmetic contract.  0 / absent = by frame size (TZ-PA2 from
+    # 256x256 pixels on), 1 = TZ-PA1 (what files compressed by builds before round 4 need for -u), 2 = TZ-PA2.  The same
+    # value must be given to -c and -u: the reference's file format has no field for it.
+    (None, "--pa", dict(type=int, choices=(0, 1, 2), default=None, dest="pa")),
 )
 
 TEXT = {
@@ -107,6 +111,8 @@ def main(arg):
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # launched by torch.distributed.run: one rank per GPU
         from . import dist as tzdist
         tzdist.init_from_env()
+    if getattr(arg, "pa", None) is not None:
+        os.environ["TEZIP_PA"] = str(arg.pa)   # every context of this process starts with it (tz_ctx_create)
     gpu = probe_gpu(arg.force)
     print("GPU MODE" if gpu else "CPU MODE")
     chosen = [name for name in ("learn", "compress", "uncompress") if getattr(arg, name) is not None]
