@@ -223,8 +223,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     //   pos 6     wait 3: the patch reads are done -> (phase 1) transform for the next stage
     //   pos 4-7   issue B[0..3] of the next stage from the next slot
 #define TZW_WAIT(P, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(B[P]) : : "memory")
-#define TZW_ISSUE if (s + LEAD < S) issue(s + LEAD);
 #define TZW_STAGE_HEAD                                                                                                      \
+        if (s + LEAD < S) issue(s + LEAD);                                                                                  \
         const unsigned wb = sbase + (unsigned)slot * SLOT + bbase;                                                          \
         const int nslot = slot + 1 == NS ? 0 : slot + 1;                                                                    \
         const unsigned wn = sbase + (unsigned)nslot * SLOT + bbase;
@@ -238,7 +238,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         _Pragma("unroll") for (int t = 0; t < NT; ++t) mfma_acc(ACC[t], AV, B[P][t]);
 #define TZW_STAGE1(VC, VN)                                                                                                  \
     {                                                                                                                       \
-        TZW_ISSUE                                                                                                           \
         TZW_STAGE_HEAD                                                                                                      \
         f32x2 d[3][2];                                                                                                      \
         TZW_WAIT(0, 3); TZW_MM(D[0], 0, VC[0]) B[4] = lds_read16<4 * 1024>(wb);                                             \
@@ -257,42 +256,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         TZW_WAIT(7, 3); TZW_MM(D[7], 7, VC[7]) B[3] = lds_read16<3072>(wn);                                                 \
         TZW_STAGE_TAIL                                                                                                      \
     }
-    // The two waves of a SIMD are the partners (mt, 0) and (mt, 1), and the barrier starts them into every stage together.
-    // The wave with ph = 1 therefore runs the SAME stage in a shifted order -- DMA issue behind position 2, patch reads
-    // behind position 4, transform at the end -- so that the non-MFMA blocks of the two do not coincide.
-#define TZW_STAGE1_B(VC, VN)                                                                                                \
-    {                                                                                                                       \
-        TZW_STAGE_HEAD                                                                                                      \
-        f32x2 d[3][2];                                                                                                      \
-        TZW_WAIT(0, 3); TZW_MM(D[0], 0, VC[0]) B[4] = lds_read16<4 * 1024>(wb);                                             \
-        TZW_WAIT(1, 3); TZW_MM(D[1], 1, VC[1]) B[5] = lds_read16<5 * 1024>(wb);                                             \
-        TZW_WAIT(2, 3); TZW_MM(D[2], 2, VC[2]) B[6] = lds_read16<6 * 1024>(wb);                                             \
-        TZW_ISSUE                                                                                                           \
-        TZW_WAIT(3, 3); TZW_MM(D[3], 3, VC[3]) B[7] = lds_read16<7 * 1024>(wb);                                             \
-        TZW_WAIT(4, 3); TZW_MM(D[4], 4, VC[4]) B[0] = lds_read16<0>(wn);                                                    \
-        read_d(nslot, d);                                                                                                   \
-        TZW_WAIT(5, 9); TZW_MM(D[5], 5, VC[5]) B[1] = lds_read16<1024>(wn);                                                 \
-        TZW_WAIT(6, 9); TZW_MM(D[6], 6, VC[6]) B[2] = lds_read16<2048>(wn);                                                 \
-        TZW_WAIT(7, 9); TZW_MM(D[7], 7, VC[7]) B[3] = lds_read16<3072>(wn);                                                 \
-        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]) : : "memory"); \
-        transform(d, VN);                                                                                                   \
-        TZW_TIE8(VN);                                                                                                       \
-        TZW_STAGE_TAIL                                                                                                      \
-    }
-    if (ph == 0) {
 #pragma unroll 1
-        while (s < S1) {   // S1 is even (sources are multiples of 16 channels)
-            TZW_STAGE1(V0, V1)
-            TZW_STAGE1(V1, V0)
-        }
-    } else {
-#pragma unroll 1
-        while (s < S1) {
-            TZW_STAGE1_B(V0, V1)
-            TZW_STAGE1_B(V1, V0)
-        }
+    while (s < S1) {   // S1 is even (sources are multiples of 16 channels)
+        TZW_STAGE1(V0, V1)
+        TZW_STAGE1(V1, V0)
     }
-#undef TZW_STAGE1_B
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
 
     // ---- output transform, oracle order.  Row sums of the wave's two transform rows:
@@ -378,7 +346,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // lp = 2 tap + b: tap = (tpy, tpx) -> A[3 tpy + b + tpx]
 #define TZW_STAGE2(AC, AN)                                                                                                  \
     {                                                                                                                       \
-        TZW_ISSUE                                                                                                           \
         TZW_STAGE_HEAD                                                                                                      \
         f32x2 u[3];                                                                                                         \
         TZW_WAIT(0, 3); TZW_MM(Y[0], 0, AC[0]) B[4] = lds_read16<4 * 1024>(wb);                                             \
@@ -395,39 +362,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         TZW_WAIT(7, 3); TZW_MM(Y[1], 7, AC[5]) B[3] = lds_read16<3072>(wn);                                                 \
         TZW_STAGE_TAIL                                                                                                      \
     }
-#define TZW_STAGE2_B(AC, AN)                                                                                                \
-    {                                                                                                                       \
-        TZW_STAGE_HEAD                                                                                                      \
-        f32x2 u[3];                                                                                                         \
-        TZW_WAIT(0, 3); TZW_MM(Y[0], 0, AC[0]) B[4] = lds_read16<4 * 1024>(wb);                                             \
-        TZW_WAIT(1, 3); TZW_MM(Y[1], 1, AC[1]) B[5] = lds_read16<5 * 1024>(wb);                                             \
-        TZW_WAIT(2, 3); TZW_MM(Y[0], 2, AC[1]) B[6] = lds_read16<6 * 1024>(wb);                                             \
-        TZW_ISSUE                                                                                                           \
-        TZW_WAIT(3, 3); TZW_MM(Y[1], 3, AC[2]) B[7] = lds_read16<7 * 1024>(wb);                                             \
-        TZW_WAIT(4, 3); TZW_MM(Y[0], 4, AC[3]) B[0] = lds_read16<0>(wn);                                                    \
-        read_u(nslot, u);                                                                                                   \
-        TZW_WAIT(5, 6); TZW_MM(Y[1], 5, AC[4]) B[1] = lds_read16<1024>(wn);                                                 \
-        TZW_WAIT(6, 6); TZW_MM(Y[0], 6, AC[4]) B[2] = lds_read16<2048>(wn);                                                 \
-        TZW_WAIT(7, 6); TZW_MM(Y[1], 7, AC[5]) B[3] = lds_read16<3072>(wn);                                                 \
-        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]) : : "memory");                             \
-        AN[0] = u[0][0]; AN[1] = u[0][1]; AN[2] = u[1][0]; AN[3] = u[1][1]; AN[4] = u[2][0]; AN[5] = u[2][1];               \
-        TZW_TIE6(AN);                                                                                                       \
-        TZW_STAGE_TAIL                                                                                                      \
-    }
-        if (ph == 0) {
 #pragma unroll 1
-            while (s < S) {
-                TZW_STAGE2(A0, A1)
-                TZW_STAGE2(A1, A0)
-            }
-        } else {
-#pragma unroll 1
-            while (s < S) {
-                TZW_STAGE2_B(A0, A1)
-                TZW_STAGE2_B(A1, A0)
-            }
+        while (s < S) {
+            TZW_STAGE2(A0, A1)
+            TZW_STAGE2(A1, A0)
         }
-#undef TZW_STAGE2_B
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads issued for a stage past the end
@@ -436,7 +375,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef TZW_MM
 #undef TZW_STAGE_TAIL
 #undef TZW_STAGE_HEAD
-#undef TZW_ISSUE
 #undef TZW_WAIT
 
     // ---- epilogues.  This wave's outputs: pixel row a = ph of its 16 tiles, columns b = 0, 1: Y[b][column tile][e],
