@@ -33,13 +33,28 @@
 #include "tz_conv_kernels.hip.h"
 
 namespace tzw {
-static constexpr int NS = 6, LEAD = 5;
+#ifndef TZW_LEAD
+#define TZW_LEAD 3
+#endif
+#ifndef TZW_NS
+#define TZW_NS 4
+#endif
+#ifndef TZW_XKB
+#define TZW_XKB 16
+#endif
+// ring slots; stages in flight ahead of the one being multiplied (<= NS - 1).  Measured on one box (scripts/gpu_wino_ab.sh,
+// ms of k_wino per cfg3 step): LEAD 5: 43.64, 4: 43.62, 3: 43.21, 2: 43.34 -- three stages (3.5 us) cover the memory latency,
+// more only fills the queues.  (The LDS a shorter ring frees could hold the whole exchange of the output transform at once,
+// TZW_XKB = 64: measured 6 % SLOWER, 46.0 against 43.3 ms, for reasons not pursued; the exchange stays one column tile a round.)
+static constexpr int NS = TZW_NS, LEAD = TZW_LEAD;
+static_assert(LEAD >= 2 && LEAD <= NS - 1, "the slot a stage is DMA'd into must be one nobody reads any more");
 static constexpr int WBYTES = 16 * 1024;             // weights of a stage
 static constexpr int PP = 41, P1BYTES = 8 * PP * 16; // same-resolution patch plane: 8 DMA pieces of 41 slots (>= 18 x 18)
 static constexpr int UP = 13, P2BYTES = 8 * UP * 16; // half-resolution patch plane: 8 pieces of 13 slots (>= 10 x 10)
 static constexpr int SLOT = WBYTES + P1BYTES + P2BYTES;
-static constexpr int XBYTES = 16 * 1024;             // exchange area of the wave pairs
-static constexpr int LDS_BYTES = NS * SLOT + XBYTES; // 156,160
+static constexpr int XBYTES = TZW_XKB * 1024;        // exchange area of the wave pairs
+static constexpr int LDS_BYTES = NS * SLOT + XBYTES; // 109,568: one workgroup per CU all the same (256 registers per wave)
+static_assert(LDS_BYTES <= 160 * 1024, "LDS of a CU");
 static constexpr int WPW = 18, WLW = 10;   // halo patch of 18 x 18 pixels, half-resolution patch of 10 x 10
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -82,6 +97,15 @@ __device__ __forceinline__ float fadd(float a, float b) {
     float r;
     asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+}
+// every wave issues 3 LDS-DMA instructions per stage: "my pieces of all but the N youngest stages have landed"
+template <int N>
+__device__ __forceinline__ void wait_vm_stages() {
+    static_assert(N >= 0 && N <= 3, "immediate of s_waitcnt");
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (N == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
 }
 template <int K>
 __device__ __forceinline__ void read_rows(unsigned ad, f32x2 (&d)[3][2]) {   // row k of the wave's three patch rows: (d0, d2), (d1, d3)
@@ -146,7 +170,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (!UPS || s < S1) dma_gather(x0 + 4 * s, poff, pmask, slot + WBYTES + wv * PP * 16);
         else dma_gather(x1 + 4 * (s - S1), uoff, umask, slot + WBYTES + P1BYTES + wv * UP * 16);
     };
-    // zero the patch areas once: the slots of out-of-image pixels are never written by the DMA
+    // zero the patch areas once: the slots of out-of-image pixels are never written by the DMA (a tile whose halo lies
+    // inside the image has none)
+    const bool interior = ty0 >= 2 && tx0 >= 2 && ty0 + 18 <= a.H && tx0 + 18 <= a.W;
+    if (!interior)
     for (int i = tid; i < NS * ((P1BYTES + P2BYTES) / 16); i += 512) {
         const int sl = i / ((P1BYTES + P2BYTES) / 16), o = i - sl * ((P1BYTES + P2BYTES) / 16);
         *(f32x4*)(smem + sl * SLOT + WBYTES + o * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -196,7 +223,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
 
     // stages 0 and 1 landed for everyone
-    if (nlead == LEAD) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    if (nlead == LEAD) wait_vm_stages<LEAD - 2>();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float V0[8], V1[8];
@@ -229,7 +256,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int nslot = slot + 1 == NS ? 0 : slot + 1;                                                                    \
         const unsigned wn = sbase + (unsigned)nslot * SLOT + bbase;
 #define TZW_STAGE_TAIL                                                                                                      \
-        if (s + LEAD < S) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                                  \
+        if (s + LEAD < S) wait_vm_stages<LEAD - 2>();                                                                       \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
         __builtin_amdgcn_s_barrier();                                                                                       \
         slot = nslot;                                                                                                       \
@@ -299,23 +326,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // y[0][b] = ((init + Z[0][b]) + Z[1][b]) + Z[2][b] belongs to the wave with rows 0, 1 and needs Z[2] of its partner;
         // y[1][b] = ((init + Z[1][b]) - Z[2][b]) - Z[3][b] belongs to the wave with rows 2, 3 and needs Z[1]: exchanged
         // through 16 KB of LDS, one column tile per round
-        f32x4* xo = (f32x4*)(smem + NS * SLOT) + (wv * 2) * 64 + lane;
-        const f32x4* xi = (const f32x4*)(smem + NS * SLOT) + ((wv ^ 4) * 2) * 64 + lane;
         const int give = ph == 0 ? 1 : 0;
+        if (XBYTES >= 64 * 1024) {   // everything in one round: 8 waves x 8 x 1 KB
+            f32x4* xo = (f32x4*)(smem + NS * SLOT) + (wv * 8) * 64 + lane;
+            const f32x4* xi = (const f32x4*)(smem + NS * SLOT) + ((wv ^ 4) * 8) * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            xo[0] = z0[give][t];
-            xo[64] = z1[give][t];
-            __syncthreads();
-            const f32x4 p0 = xi[0], p1 = xi[64];
-            if (ph == 0) {
-                Y[0][t] = ((in0[t] + z0[0][t]) + z0[1][t]) + p0;
-                Y[1][t] = ((in1[t] + z1[0][t]) + z1[1][t]) + p1;
-            } else {
-                Y[0][t] = ((in0[t] + p0) - z0[0][t]) - z0[1][t];
-                Y[1][t] = ((in1[t] + p1) - z1[0][t]) - z1[1][t];
+            for (int t = 0; t < NT; ++t) {
+                xo[(2 * t) * 64] = z0[give][t];
+                xo[(2 * t + 1) * 64] = z1[give][t];
             }
             __syncthreads();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 p0 = xi[(2 * t) * 64], p1 = xi[(2 * t + 1) * 64];
+                if (ph == 0) {
+                    Y[0][t] = ((in0[t] + z0[0][t]) + z0[1][t]) + p0;
+                    Y[1][t] = ((in1[t] + z1[0][t]) + z1[1][t]) + p1;
+                } else {
+                    Y[0][t] = ((in0[t] + p0) - z0[0][t]) - z0[1][t];
+                    Y[1][t] = ((in1[t] + p1) - z1[0][t]) - z1[1][t];
+                }
+            }
+            __syncthreads();   // (the pooling epilogue and the next use of the area come behind it)
+        } else {
+            f32x4* xo = (f32x4*)(smem + NS * SLOT) + (wv * 2) * 64 + lane;
+            const f32x4* xi = (const f32x4*)(smem + NS * SLOT) + ((wv ^ 4) * 2) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                xo[0] = z0[give][t];
+                xo[64] = z1[give][t];
+                __syncthreads();
+                const f32x4 p0 = xi[0], p1 = xi[64];
+                if (ph == 0) {
+                    Y[0][t] = ((in0[t] + z0[0][t]) + z0[1][t]) + p0;
+                    Y[1][t] = ((in1[t] + z1[0][t]) + z1[1][t]) + p1;
+                } else {
+                    Y[0][t] = ((in0[t] + p0) - z0[0][t]) - z0[1][t];
+                    Y[1][t] = ((in1[t] + p1) - z1[0][t]) - z1[1][t];
+                }
+                __syncthreads();
+            }
         }
     }
 
