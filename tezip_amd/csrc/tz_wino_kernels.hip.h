@@ -78,6 +78,11 @@ __device__ __forceinline__ f32x2 lds_read2(unsigned addr) {
 template <int OFF>
 __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
     f32x4 v;
+#if defined(TZW_ABL) && (TZW_ABL & 4)
+    v = (f32x4){1.f, 2.f, 3.f, 4.f};
+    asm volatile("" : "+v"(v), "+v"(addr));
+    return v;
+#endif
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
@@ -249,16 +254,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     //   pos 2-5   wait 3 + NA
     //   pos 6     wait 3: the patch reads are done -> (phase 1) transform for the next stage
     //   pos 4-7   issue B[0..3] of the next stage from the next slot
-#define TZW_WAIT(P, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(B[P]) : : "memory")
+// TZW_ABL (diagnostic builds, WRONG results, scripts/gpu_wino_ab.sh): 1 no barrier in the loops; 2 no patch reads / transform;
+// 4 no weight reads; 8 no DMA in the loops; 16 (with 8) every stage loop twice
+#ifndef TZW_ABL
+#define TZW_ABL 0
+#endif
+#define TZW_WAIT(P, N) if (!(TZW_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(B[P]) : : "memory")
 #define TZW_STAGE_HEAD                                                                                                      \
-        if (s + LEAD < S) issue(s + LEAD);                                                                                  \
+        if (!(TZW_ABL & 8) && s + LEAD < S) issue(s + LEAD);                                                                \
         const unsigned wb = sbase + (unsigned)slot * SLOT + bbase;                                                          \
         const int nslot = slot + 1 == NS ? 0 : slot + 1;                                                                    \
         const unsigned wn = sbase + (unsigned)nslot * SLOT + bbase;
 #define TZW_STAGE_TAIL                                                                                                      \
         if (s + LEAD < S) wait_vm_stages<LEAD - 2>();                                                                       \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
-        __builtin_amdgcn_s_barrier();                                                                                       \
+        if (!(TZW_ABL & 1)) __builtin_amdgcn_s_barrier();                                                                   \
         slot = nslot;                                                                                                       \
         ++s;
 #define TZW_MM(ACC, P, AV)                                                                                                  \
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         f32x2 d[3][2];                                                                                                      \
         TZW_WAIT(0, 3); TZW_MM(D[0], 0, VC[0]) B[4] = lds_read16<4 * 1024>(wb);                                             \
         TZW_WAIT(1, 3); TZW_MM(D[1], 1, VC[1]) B[5] = lds_read16<5 * 1024>(wb);                                             \
-        read_d(nslot, d);                                                                                                   \
+        if (!(TZW_ABL & 2)) read_d(nslot, d);                                                                               \
         TZW_WAIT(2, 9); TZW_MM(D[2], 2, VC[2]) B[6] = lds_read16<6 * 1024>(wb);                                             \
         TZW_WAIT(3, 9); TZW_MM(D[3], 3, VC[3]) B[7] = lds_read16<7 * 1024>(wb);                                             \
         TZW_WAIT(4, 9); TZW_MM(D[4], 4, VC[4]) B[0] = lds_read16<0>(wn);                                                    \
@@ -277,16 +287,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         TZW_WAIT(6, 3); TZW_MM(D[6], 6, VC[6]) B[2] = lds_read16<2048>(wn);                                                 \
         /* the patch reads have arrived (empty asm: nothing is computed with d before here) and the transform is done */   \
         /* HERE, not sunk to its first use right in front of an asm MFMA                                              */   \
-        TZW_TIED(d);                                                                                                        \
-        transform(d, VN);                                                                                                   \
+        if (!(TZW_ABL & 2)) { TZW_TIED(d); transform(d, VN); }                                                              \
+        else { _Pragma("unroll") for (int q = 0; q < 8; ++q) VN[q] = VC[q]; }                                               \
         TZW_TIE8(VN);                                                                                                       \
         TZW_WAIT(7, 3); TZW_MM(D[7], 7, VC[7]) B[3] = lds_read16<3072>(wn);                                                 \
         TZW_STAGE_TAIL                                                                                                      \
     }
 #pragma unroll 1
+    for (int rep = 0; rep < ((TZW_ABL & 16) ? 2 : 1); ++rep) {   // (ablation 16, with 8: every loop twice -> time per stage)
+    if (TZW_ABL & 16) s = 0;
+#pragma unroll 1
     while (s < S1) {   // S1 is even (sources are multiples of 16 channels)
         TZW_STAGE1(V0, V1)
         TZW_STAGE1(V1, V0)
+    }
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
 
@@ -400,22 +414,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         f32x2 u[3];                                                                                                         \
         TZW_WAIT(0, 3); TZW_MM(Y[0], 0, AC[0]) B[4] = lds_read16<4 * 1024>(wb);                                             \
         TZW_WAIT(1, 3); TZW_MM(Y[1], 1, AC[1]) B[5] = lds_read16<5 * 1024>(wb);                                             \
-        read_u(nslot, u);                                                                                                   \
+        if (!(TZW_ABL & 2)) read_u(nslot, u);                                                                               \
         TZW_WAIT(2, 6); TZW_MM(Y[0], 2, AC[1]) B[6] = lds_read16<6 * 1024>(wb);                                             \
         TZW_WAIT(3, 6); TZW_MM(Y[1], 3, AC[2]) B[7] = lds_read16<7 * 1024>(wb);                                             \
         TZW_WAIT(4, 6); TZW_MM(Y[0], 4, AC[3]) B[0] = lds_read16<0>(wn);                                                    \
         TZW_WAIT(5, 6); TZW_MM(Y[1], 5, AC[4]) B[1] = lds_read16<1024>(wn);                                                 \
         TZW_WAIT(6, 3); TZW_MM(Y[0], 6, AC[4]) B[2] = lds_read16<2048>(wn);                                                 \
-        TZW_TIEU(u);                                                                                                        \
-        AN[0] = u[0][0]; AN[1] = u[0][1]; AN[2] = u[1][0]; AN[3] = u[1][1]; AN[4] = u[2][0]; AN[5] = u[2][1];               \
+        if (!(TZW_ABL & 2)) { TZW_TIEU(u); AN[0] = u[0][0]; AN[1] = u[0][1]; AN[2] = u[1][0]; AN[3] = u[1][1]; AN[4] = u[2][0]; AN[5] = u[2][1]; } \
+        else { _Pragma("unroll") for (int q = 0; q < 6; ++q) AN[q] = AC[q]; }                                               \
         TZW_TIE6(AN);                                                                                                       \
         TZW_WAIT(7, 3); TZW_MM(Y[1], 7, AC[5]) B[3] = lds_read16<3072>(wn);                                                 \
         TZW_STAGE_TAIL                                                                                                      \
     }
 #pragma unroll 1
+        for (int rep = 0; rep < ((TZW_ABL & 16) ? 2 : 1); ++rep) {
+        if (TZW_ABL & 16) s = S1;
+#pragma unroll 1
         while (s < S) {
             TZW_STAGE2(A0, A1)
             TZW_STAGE2(A1, A0)
+        }
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
