@@ -63,3 +63,43 @@ def test_compiler_is_the_one_the_waitcnt_immediates_were_validated_with():
     assert any(tag in out for tag in KNOWN_GOOD_COMPILERS), (
         "hipcc changed:\n%s\nre-run the bit-exact GPU tests (pytest -m gpu tests/test_gpu_fullsize.py) and scripts/soak_conv.py "
         "with this compiler, then add its tag to KNOWN_GOOD_COMPILERS" % out)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="no ROCm LLVM tools")
+def test_k_wino_stage_bodies_move_no_register_behind_an_asm_read(tmp_path):
+    """k_wino (TZ-PA2, tz_wino_kernels.hip.h) reads LDS through asm the compiler does not see as loads and multiplies with asm
+    MFMAs on a tied AGPR accumulator.  What nobody checks for us: between an asm read and the counted wait in front of its use
+    the compiler may copy or reuse the destination register -- the data then lands in a register that means something else
+    (round 4 met exactly that with asm GLOBAL loads hoisted over the output transform: a late write into an address register,
+    a memory fault; that code is gone).  The static half of the guard: in the code object just built, the straight-line stage
+    bodies (the blocks with 16 or more MFMAs) of every k_wino instantiation contain no register move, no AGPR <-> VGPR
+    traffic, no lane spill and no scratch access at all.  The dynamic half: tests/test_gpu_wino.py and scripts/soak_conv.py
+    (bit for bit against the oracle and against the plain k_wino_ref)."""
+    if not os.path.exists(OBJ):
+        from tezip_amd import build
+        build.build()
+    work = tmp_path / "co"
+    work.mkdir()
+    shutil.copy(OBJ, work / "k.o")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objdump"), "--offloading", "k.o"], cwd=work, stdout=subprocess.DEVNULL)
+    co = [f for f in os.listdir(work) if "amdgcn" in f]
+    text = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co[0]], cwd=work, text=True)
+    seen = 0
+    for fn in re.split(r"\n(?=[0-9a-f]+ <)", text):
+        m = re.match(r"[0-9a-f]+ <([^>]+)>:", fn)
+        if not m or "k_wino" not in m.group(1) or "k_wino_ref" in m.group(1):
+            continue
+        seen += 1
+        blocks = [[]]
+        for line in fn.splitlines()[1:]:
+            ins = line.split("//")[0].strip()
+            blocks[-1].append(ins)
+            if ins.startswith(("s_cbranch", "s_branch", "s_endpgm")):
+                blocks.append([])
+        hot = [b for b in blocks if sum(i.startswith("v_mfma") for i in b) >= 16]
+        assert len(hot) >= 2, (m.group(1), len(hot))
+        for b in hot:
+            bad = [i for i in b if i.startswith(("v_mov_b32", "v_pk_mov", "v_accvgpr", "scratch_", "buffer_", "v_readlane", "v_writelane"))]
+            assert not bad, (m.group(1), bad[:8])
+            assert all("a[" in i.split(",")[0] for i in b if i.startswith("v_mfma")), m.group(1)   # accumulators in AGPRs, in place
+    assert seen >= 6   # LSTM / RAW with and without an upsampled source, pool + error with 3 and 4 column tiles

@@ -476,6 +476,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int x = tx0 + 8 * (mt & 1) + 2 * e + b;
                 ok[b][e] = oy < a.H && x < a.W;
                 pix[b][e] = ok[b][e] ? (long long)oy * a.W + x : 0;
+                // (Asking for these ahead of the output transform through asm loads -- to hide their round trip -- is NOT
+                // safe: the compiler is free to reuse an asm load's destination register before the data lands, and did:
+                // the late write then hit an address register, a memory fault in the bench.  Plain loads, at their use.)
                 cp[b][e] = a.aux ? a.aux[pix[b][e] * R + ch] : 0.0f;
             }
 #pragma unroll
