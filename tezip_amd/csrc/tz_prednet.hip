@@ -373,6 +373,12 @@ static int effective_contract(const tz_ctx* ctx) {
     return m && (long long)m->Hp * m->Wp >= TZ_PA2_MIN_PIXELS ? 2 : 1;
 }
 
+#ifdef TZW_STAMPS
+// diagnostic build only (not in tezip_hip.h): the stamps of the last k_wino launches, [8 shape slots][4096 workgroups][8]
+extern "C" int tz_debug_wino_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tzw_stamps), sizeof(unsigned long long) * 8 * 4096 * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 extern "C" int tz_set_contract(tz_ctx* ctx, int contract) {
     if (!ctx) return TZ_ERR_INVALID;
     if (contract < 0 || contract > 2)

@@ -124,6 +124,13 @@ __device__ __forceinline__ void read_rows(unsigned ad, f32x2 (&d)[3][2]) {   // 
 #define TZW_TIED(d) asm volatile("" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]))
 #define TZW_TIEU(u) asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]))
 
+#ifdef TZW_STAMPS
+// diagnostic build: s_memrealtime (100 MHz) at six points of a workgroup's life, wave 0, per (kernel shape slot, workgroup)
+__device__ unsigned long long tzw_stamps[8][4096][8];
+#define TZW_STAMP(K) if (tid == 0 && blockIdx.x < 4096) tzw_stamps[(a.ncb & 3) | (EPI == EPI_LSTM ? 4 : 0)][blockIdx.x][K] = __builtin_amdgcn_s_memrealtime();
+#else
+#define TZW_STAMP(K)
+#endif
 // EPI: EPI_LSTM (NT = 4: columns [i | f | g | o] x 16 channels), EPI_POOL_ERR (NT = 3 or 4), EPI_RAW (NT = 4; tests).
 // src[0]: the same-resolution source (multiple of 16 channels); src[1] (UPS): the half-resolution source.
 template <int NT, int EPI, bool UPS>
@@ -139,6 +146,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tile = bid % ntiles, n = bid / ntiles;
     const int ty0 = (tile / a.tiles_x) * 16, tx0 = (tile % a.tiles_x) * 16;
     const int g = lane >> 4, r = lane & 15;
+    TZW_STAMP(0)
     const unsigned sbase = lds_addr(smem);
     const int S1 = a.src[0].C >> 2;                       // stages of the same-resolution source
     const int S = S1 + (UPS ? a.src[1].C >> 2 : 0);       // ... and of the upsampled one
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (nlead == LEAD) wait_vm_stages<LEAD - 2>();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    TZW_STAMP(1)
     float V0[8], V1[8];
     {
         f32x2 d[3][2];
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+    TZW_STAMP(2)
 
     // ---- output transform, oracle order.  Row sums of the wave's two transform rows:
     f32x4 Y[2][4];
@@ -383,6 +393,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
 
+    TZW_STAMP(3)
     // ---- the upsampled source: every output's chain goes on with its collapsed taps.  Stage = one channel quad; the
     // wave's classes are (a = ph, b = 0, 1); weight sets in consumption order lp = 2 tap + b; A fragments = the 2 x 3
     // half-resolution pixels around the tile (rows ph + tpy, columns b + tpx)
@@ -438,6 +449,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads issued for a stage past the end
+    TZW_STAMP(4)
 #undef TZW_STAGE2
 #undef TZW_STAGE1
 #undef TZW_MM
@@ -541,6 +553,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
+#ifdef TZW_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TZW_STAMP(5)
+#endif
 }
 
 // k_wino_ref: the same TZ-PA2 convolutions (and epilogues) as k_wino, written the plain way -- one thread per (tile, column
