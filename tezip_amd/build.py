@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["tz_api.hip", "tz_codec.hip", "tz_prednet.hip"]
-HEADERS = ["tz_internal.h", "tz_math.hip.h", "tz_conv_kernels.hip.h", os.path.join("..", "..", "include", "tezip_hip.h")]
+HEADERS = ["tz_internal.h", "tz_math.hip.h", "tz_conv_kernels.hip.h", "tz_wino_kernels.hip.h", os.path.join("..", "..", "include", "tezip_hip.h")]
 LIB = os.path.join(CSRC, "libtezip_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = (["-D" + d for d in os.environ.get("TEZIP_DEFINES", "").split()] if os.environ.get("TEZIP_DEFINES") else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

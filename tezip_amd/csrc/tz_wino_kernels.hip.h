@@ -112,10 +112,36 @@ __device__ __forceinline__ void wait_vm_stages() {
     else if (N == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
 }
+#ifndef TZW_PK
+#define TZW_PK 1
+#endif
 template <int K>
-__device__ __forceinline__ void read_rows(unsigned ad, f32x2 (&d)[3][2]) {   // row k of the wave's three patch rows: (d0, d2), (d1, d3)
-    d[K][0] = lds_read2<72 * K, 72 * K + 4>(ad);
-    d[K][1] = lds_read2<72 * K + 36, 72 * K + 40>(ad);
+__device__ __forceinline__ void read_rows(unsigned ad, f32x2 (&d)[3][2]) {   // row k of the wave's three patch rows
+#if TZW_PK
+    d[K][0] = lds_read2<72 * K, 72 * K + 36>(ad);       // (d0, d1): columns 0 and 1 (evens first: column 1 sits 9 slots on)
+    d[K][1] = lds_read2<72 * K + 4, 72 * K + 40>(ad);   // (d2, d3)
+#else
+    d[K][0] = lds_read2<72 * K, 72 * K + 4>(ad);        // (d0, d2)
+    d[K][1] = lds_read2<72 * K + 36, 72 * K + 40>(ad);  // (d1, d3)
+#endif
+}
+// packed float32 add / subtract with the operand halves chosen per instruction (same IEEE results as two scalar ones):
+//   pk_sub(a, b)  = (a.lo - b.lo, a.hi - b.hi);  pk_add likewise
+//   pk_cross(a, b) = (a.hi + b.lo, b.lo - a.hi)   -- the two middle columns of B^T d: (d1 + d2, d2 - d1) from (d0, d1), (d2, d3)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_cross(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 }  // namespace tzw
 
@@ -214,10 +240,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     // B^T d B for the wave's two transform rows (same association as the oracle): columns first, then rows
     auto transform = [&](const f32x2 (&d)[3][2], float (&V)[8]) {
+#if TZW_PK
+        // 10 packed instructions instead of 20: per row T1 = (t0, t3) = (d0, d1) - (d2, d3), T2 = (t1, t2) = (d1 + d2, d2 - d1);
+        // then the rows the same way on the pairs
+        f32x2 T1[3], T2[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            T1[k] = pk_sub(d[k][0], d[k][1]);
+            T2[k] = pk_cross(d[k][0], d[k][1]);
+        }
+        f32x2 a03, a12, b03, b12;   // (V[.][0], V[.][3]), (V[.][1], V[.][2]) of the wave's two transform rows
+        if (ph == 0) {   // rows 0, 1, 2 of the patch: V[0] = t0 - t2, V[1] = t1 + t2
+            a03 = pk_sub(T1[0], T1[2]);
+            a12 = pk_sub(T2[0], T2[2]);
+            b03 = pk_add(T1[1], T1[2]);
+            b12 = pk_add(T2[1], T2[2]);
+        } else {         // rows 1, 2, 3: V[2] = t2 - t1, V[3] = t1 - t3
+            a03 = pk_sub(T1[1], T1[0]);
+            a12 = pk_sub(T2[1], T2[0]);
+            b03 = pk_sub(T1[0], T1[2]);
+            b12 = pk_sub(T2[0], T2[2]);
+        }
+        V[0] = a03[0]; V[3] = a03[1]; V[1] = a12[0]; V[2] = a12[1];
+        V[4] = b03[0]; V[7] = b03[1]; V[5] = b12[0]; V[6] = b12[1];
+        return;
+#endif
         float t[3][4];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float d0 = d[k][0][0], d2 = d[k][0][1], d1 = d[k][1][0], d3 = d[k][1][1];
+            const float d0 = d[k][0][0], d2 = TZW_PK ? d[k][1][0] : d[k][0][1], d1 = TZW_PK ? d[k][0][1] : d[k][1][0], d3 = d[k][1][1];
             t[k][0] = fsub(d0, d2);
             t[k][1] = fadd(d1, d2);
             t[k][2] = fsub(d2, d1);
