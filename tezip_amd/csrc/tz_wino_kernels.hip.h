@@ -48,6 +48,7 @@ namespace tzw {
 // TZW_XKB = 64: measured 6 % SLOWER, 46.0 against 43.3 ms, for reasons not pursued; the exchange stays one column tile a round.)
 static constexpr int NS = TZW_NS, LEAD = TZW_LEAD;
 static_assert(LEAD >= 2 && LEAD <= NS - 1, "the slot a stage is DMA'd into must be one nobody reads any more");
+static_assert(NS == 4, "the stage loops are unrolled once per ring slot (every LDS address a constant), 4 stages = one 16-channel block");
 static constexpr int WBYTES = 16 * 1024;             // weights of a stage
 static constexpr int PP = 41, P1BYTES = 8 * PP * 16; // same-resolution patch plane: 8 DMA pieces of 41 slots (>= 18 x 18)
 static constexpr int UP = 13, P2BYTES = 8 * UP * 16; // half-resolution patch plane: 8 pieces of 13 slots (>= 10 x 10)
@@ -60,12 +61,18 @@ static constexpr int WPW = 18, WLW = 10;   // halo patch of 18 x 18 pixels, half
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
 }
+// (TZW_ABL 32, diagnostic: everything around a DMA stays, the DMA instruction itself is left out)
+#if defined(TZW_ABL) && (TZW_ABL & 32)
+#define TZW_DMA_INS "; "
+#else
+#define TZW_DMA_INS "global_load_lds_dwordx4 "
+#endif
 __device__ __forceinline__ void dma_lanes(const float* ubase, unsigned voff, unsigned lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(ubase), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t" TZW_DMA_INS "%0, %1" : : "v"(voff), "s"(ubase), "s"(lds) : "memory");
 }
 __device__ __forceinline__ void dma_gather(const float* ubase, unsigned voff, unsigned long long mask, unsigned lds) {
     unsigned long long saved;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" TZW_DMA_INS "%1, %2\n\t"
                  "s_mov_b64 exec, %0"
                  : "=&s"(saved) : "v"(voff), "s"(ubase), "s"(lds), "s"(mask) : "memory");
 }
@@ -198,17 +205,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         uoff = ok ? 4u * (unsigned)((ly * (a.W >> 1) + lx) * a.src[1].pstride) : 0u;
         umask = __ballot(ok);
     }
-    const float* x0 = a.src[0].p + (long long)n * a.src[0].nstride;
-    const float* x1 = UPS ? a.src[1].p + (long long)n * a.src[1].nstride : nullptr;
     const unsigned lane16 = lane * 16;
-    auto issue = [&](int s) {   // stage s into its ring slot: 2 KB of weights + one patch piece per wave = 3 DMA instructions
-        const unsigned slot = sbase + (unsigned)(s % NS) * SLOT;
-        const float* w = a.Wwino + (((long long)s * a.ncb + cb) * 16 + 2 * wv) * 256;
-        dma_lanes(w, lane16, slot + (2 * wv) * 1024);
-        dma_lanes(w + 256, lane16, slot + (2 * wv + 1) * 1024);
-        if (!UPS || s < S1) dma_gather(x0 + 4 * s, poff, pmask, slot + WBYTES + wv * PP * 16);
-        else dma_gather(x1 + 4 * (s - S1), uoff, umask, slot + WBYTES + P1BYTES + wv * UP * 16);
-    };
+    // ---- the DMA stream.  Stage si goes into ring slot si mod 4: 2 KB of weights + one patch piece per wave = 3 DMA
+    // instructions.  The stage loops are unrolled once per ring slot, so every LDS address below is a constant; the global
+    // addresses are running scalar pointers (the first form recomputed them from the stage number: ~40 scalar instructions
+    // per stage and wave, 3.4 % of the kernel -- TZW_ABL 32 against 8).
+    const float* wp = a.Wwino + ((long long)cb * 16 + 2 * wv) * 256;                      // weights of the next stage to issue
+    const long long wstride = (long long)a.ncb * (16 * 256);
+    const float* xp0 = a.src[0].p + (long long)n * a.src[0].nstride;                       // ... its quad of the same-resolution source
+    const float* xp1 = UPS ? a.src[1].p + (long long)n * a.src[1].nstride : nullptr;       // ... of the upsampled one
+    int si = 0;                                                                            // ... its number
+    const unsigned wvw = (unsigned)(2 * wv) * 1024, wvp = WBYTES + (unsigned)wv * (PP * 16), wvu = WBYTES + P1BYTES + (unsigned)wv * (UP * 16);
+#define TZW_ISSUE_TO(KI)                                                                                                    \
+    {                                                                                                                       \
+        const unsigned so = sbase + (unsigned)(KI) * SLOT;                                                                  \
+        dma_lanes(wp, lane16, so + wvw);                                                                                    \
+        dma_lanes(wp + 256, lane16, so + wvw + 1024);                                                                       \
+        if (!UPS || si < S1) {                                                                                              \
+            dma_gather(xp0, poff, pmask, so + wvp);                                                                         \
+            xp0 += 4;                                                                                                       \
+        } else {                                                                                                            \
+            dma_gather(xp1, uoff, umask, so + wvu);                                                                         \
+            xp1 += 4;                                                                                                       \
+        }                                                                                                                   \
+        wp += wstride;                                                                                                      \
+        ++si;                                                                                                               \
+    }
     // zero the patch areas once: the slots of out-of-image pixels are never written by the DMA (a tile whose halo lies
     // inside the image has none)
     const bool interior = ty0 >= 2 && tx0 >= 2 && ty0 + 18 <= a.H && tx0 + 18 <= a.W;
@@ -218,8 +240,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *(f32x4*)(smem + sl * SLOT + WBYTES + o * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
-    const int nlead = LEAD < S ? LEAD : S;
-    for (int s = 0; s < nlead; ++s) issue(s);
+    const int nlead = LEAD;   // (S >= 4: sources are multiples of 16 channels)
+    TZW_ISSUE_TO(0)
+    TZW_ISSUE_TO(1)
+    if (LEAD > 2) TZW_ISSUE_TO(2)
 
     f32x4 D[8][4];
 #pragma unroll
@@ -232,8 +256,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned abase = WBYTES + (unsigned)(((8 * (mt >> 1) + 2 * tyl + ph) * WPW + 4 * (mt & 1) + txl) * 16 + 4 * g);
     const unsigned ubase = WBYTES + P1BYTES + (unsigned)(((4 * (mt >> 1) + tyl + ph) * WLW + 4 * (mt & 1) + txl) * 16 + 4 * g);
     const unsigned bbase = (unsigned)(8 * ph) * 1024 + lane16;
-    auto read_d = [&](int slot_, f32x2 (&d)[3][2]) {
-        const unsigned ad = sbase + (unsigned)slot_ * SLOT + abase;
+    // LDS read addresses, one register set for the whole kernel: weights of slots 0, 1 from wbL and of slots 2, 3 from wbH (the
+    // 16-bit immediate of ds_read_b128 covers a slot and a half), patch planes per slot (ds_read2 immediates are 8 bits)
+    const unsigned wbL = sbase + bbase, wbH = wbL + 2 * SLOT;
+    unsigned adA[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) adA[k] = sbase + (unsigned)k * SLOT + abase;
+    auto read_d = [&](unsigned ad, f32x2 (&d)[3][2]) {
         read_rows<0>(ad, d);
         read_rows<1>(ad, d);
         read_rows<2>(ad, d);
@@ -294,21 +323,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float V0[8], V1[8];
     {
         f32x2 d[3][2];
-        read_d(0, d);
+        read_d(adA[0], d);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]) : : "memory");
         transform(d, V0);
         TZW_TIE8(V0);
     }
     f32x4 B[8];
     {   // the weight reads run as one continuous stream, four positions ahead, across the stage boundaries
-        const unsigned wb = sbase + bbase;
-        B[0] = lds_read16<0>(wb);
-        B[1] = lds_read16<1024>(wb);
-        B[2] = lds_read16<2048>(wb);
-        B[3] = lds_read16<3072>(wb);
+        B[0] = lds_read16<0>(wbL);
+        B[1] = lds_read16<1024>(wbL);
+        B[2] = lds_read16<2048>(wbL);
+        B[3] = lds_read16<3072>(wbL);
     }
-    int slot = 0;   // ring slot of the current stage
-    int s = 0;
+    int s = 0;   // (its ring slot is s mod 4 = the position in the unrolled loop body)
     // One stage of a wave: 8 positions x NT column tiles.  The LDS queue is in order, so every wait is a count:
     //   pos 0, 1  wait 3 (the three younger weight reads); behind pos 1 the patch reads of the NEXT stage (NA instructions)
     //   pos 2-5   wait 3 + NA
@@ -320,46 +347,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define TZW_ABL 0
 #endif
 #define TZW_WAIT(P, N) if (!(TZW_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(B[P]) : : "memory")
-#define TZW_STAGE_HEAD                                                                                                      \
-        if (!(TZW_ABL & 8) && s + LEAD < S) issue(s + LEAD);                                                                \
-        const unsigned wb = sbase + (unsigned)slot * SLOT + bbase;                                                          \
-        const int nslot = slot + 1 == NS ? 0 : slot + 1;                                                                    \
-        const unsigned wn = sbase + (unsigned)nslot * SLOT + bbase;
+#define TZW_STAGE_HEAD(K)                                                                                                   \
+        if (!(TZW_ABL & 8) && s + LEAD < S) TZW_ISSUE_TO(((K) + LEAD) % NS)                                                 \
+        constexpr int KN = ((K) + 1) % NS;                                    /* the next stage's slot */                   \
+        const unsigned wb = ((K) & 2) ? wbH : wbL, wn = (KN & 2) ? wbH : wbL;                                               \
+        constexpr int WO = ((K) & 1) * SLOT, WN = (KN & 1) * SLOT;            /* ... folded into the read immediates */
 #define TZW_STAGE_TAIL                                                                                                      \
         if (s + LEAD < S) wait_vm_stages<LEAD - 2>();                                                                       \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
         if (!(TZW_ABL & 1)) __builtin_amdgcn_s_barrier();                                                                   \
-        slot = nslot;                                                                                                       \
         ++s;
 #define TZW_MM(ACC, P, AV)                                                                                                  \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) mfma_acc(ACC[t], AV, B[P][t]);
-#define TZW_STAGE1(VC, VN)                                                                                                  \
+#define TZW_STAGE1(K, VC, VN)                                                                                               \
     {                                                                                                                       \
-        TZW_STAGE_HEAD                                                                                                      \
+        TZW_STAGE_HEAD(K)                                                                                                   \
         f32x2 d[3][2];                                                                                                      \
-        TZW_WAIT(0, 3); TZW_MM(D[0], 0, VC[0]) B[4] = lds_read16<4 * 1024>(wb);                                             \
-        TZW_WAIT(1, 3); TZW_MM(D[1], 1, VC[1]) B[5] = lds_read16<5 * 1024>(wb);                                             \
-        if (!(TZW_ABL & 2)) read_d(nslot, d);                                                                               \
-        TZW_WAIT(2, 9); TZW_MM(D[2], 2, VC[2]) B[6] = lds_read16<6 * 1024>(wb);                                             \
-        TZW_WAIT(3, 9); TZW_MM(D[3], 3, VC[3]) B[7] = lds_read16<7 * 1024>(wb);                                             \
-        TZW_WAIT(4, 9); TZW_MM(D[4], 4, VC[4]) B[0] = lds_read16<0>(wn);                                                    \
-        TZW_WAIT(5, 9); TZW_MM(D[5], 5, VC[5]) B[1] = lds_read16<1024>(wn);                                                 \
-        TZW_WAIT(6, 3); TZW_MM(D[6], 6, VC[6]) B[2] = lds_read16<2048>(wn);                                                 \
+        TZW_WAIT(0, 3); TZW_MM(D[0], 0, VC[0]) B[4] = lds_read16<WO + 4 * 1024>(wb);                                        \
+        TZW_WAIT(1, 3); TZW_MM(D[1], 1, VC[1]) B[5] = lds_read16<WO + 5 * 1024>(wb);                                        \
+        if (!(TZW_ABL & 2)) read_d(adA[KN], d);                                                                             \
+        TZW_WAIT(2, 9); TZW_MM(D[2], 2, VC[2]) B[6] = lds_read16<WO + 6 * 1024>(wb);                                        \
+        TZW_WAIT(3, 9); TZW_MM(D[3], 3, VC[3]) B[7] = lds_read16<WO + 7 * 1024>(wb);                                        \
+        TZW_WAIT(4, 9); TZW_MM(D[4], 4, VC[4]) B[0] = lds_read16<WN>(wn);                                                   \
+        TZW_WAIT(5, 9); TZW_MM(D[5], 5, VC[5]) B[1] = lds_read16<WN + 1024>(wn);                                            \
+        TZW_WAIT(6, 3); TZW_MM(D[6], 6, VC[6]) B[2] = lds_read16<WN + 2048>(wn);                                            \
         /* the patch reads have arrived (empty asm: nothing is computed with d before here) and the transform is done */   \
         /* HERE, not sunk to its first use right in front of an asm MFMA                                              */   \
         if (!(TZW_ABL & 2)) { TZW_TIED(d); transform(d, VN); }                                                              \
         else { _Pragma("unroll") for (int q = 0; q < 8; ++q) VN[q] = VC[q]; }                                               \
         TZW_TIE8(VN);                                                                                                       \
-        TZW_WAIT(7, 3); TZW_MM(D[7], 7, VC[7]) B[3] = lds_read16<3072>(wn);                                                 \
+        TZW_WAIT(7, 3); TZW_MM(D[7], 7, VC[7]) B[3] = lds_read16<WN + 3072>(wn);                                            \
         TZW_STAGE_TAIL                                                                                                      \
     }
 #pragma unroll 1
     for (int rep = 0; rep < ((TZW_ABL & 16) ? 2 : 1); ++rep) {   // (ablation 16, with 8: every loop twice -> time per stage)
     if (TZW_ABL & 16) s = 0;
 #pragma unroll 1
-    while (s < S1) {   // S1 is even (sources are multiples of 16 channels)
-        TZW_STAGE1(V0, V1)
-        TZW_STAGE1(V1, V0)
+    while (s < S1) {   // one 16-channel block = four stages = once round the ring
+        TZW_STAGE1(0, V0, V1)
+        TZW_STAGE1(1, V1, V0)
+        TZW_STAGE1(2, V0, V1)
+        TZW_STAGE1(3, V1, V0)
     }
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
@@ -449,8 +477,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // wave's classes are (a = ph, b = 0, 1); weight sets in consumption order lp = 2 tap + b; A fragments = the 2 x 3
     // half-resolution pixels around the tile (rows ph + tpy, columns b + tpx)
     if (UPS) {
-        auto read_u = [&](int slot_, f32x2 (&u)[3]) {
-            const unsigned ad = sbase + (unsigned)slot_ * SLOT + ubase;
+        unsigned udA[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) udA[k] = sbase + (unsigned)k * SLOT + ubase;
+        auto read_u = [&](unsigned ad, f32x2 (&u)[3]) {
             u[0] = lds_read2<0, 4>(ad);             // (row 0, columns 0, 1)
             u[1] = lds_read2<8, WLW * 4>(ad);        // (row 0, column 2), (row 1, column 0)
             u[2] = lds_read2<WLW * 4 + 4, WLW * 4 + 8>(ad);   // (row 1, columns 1, 2)
@@ -458,34 +488,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float A0[6], A1[6];
         {
             f32x2 u[3];
-            read_u(slot, u);
+            read_u(udA[0], u);   // (S1 is a multiple of 4: the first stage of this phase sits in slot 0)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]) : : "memory");
             A0[0] = u[0][0]; A0[1] = u[0][1]; A0[2] = u[1][0]; A0[3] = u[1][1]; A0[4] = u[2][0]; A0[5] = u[2][1];
             TZW_TIE6(A0);
             // (the weight stream was drained by that wait: restart it)
-            const unsigned wb = sbase + (unsigned)slot * SLOT + bbase;
-            B[0] = lds_read16<0>(wb);
-            B[1] = lds_read16<1024>(wb);
-            B[2] = lds_read16<2048>(wb);
-            B[3] = lds_read16<3072>(wb);
+            B[0] = lds_read16<0>(wbL);
+            B[1] = lds_read16<1024>(wbL);
+            B[2] = lds_read16<2048>(wbL);
+            B[3] = lds_read16<3072>(wbL);
         }
         // lp = 2 tap + b: tap = (tpy, tpx) -> A[3 tpy + b + tpx]
-#define TZW_STAGE2(AC, AN)                                                                                                  \
+#define TZW_STAGE2(K, AC, AN)                                                                                               \
     {                                                                                                                       \
-        TZW_STAGE_HEAD                                                                                                      \
+        TZW_STAGE_HEAD(K)                                                                                                   \
         f32x2 u[3];                                                                                                         \
-        TZW_WAIT(0, 3); TZW_MM(Y[0], 0, AC[0]) B[4] = lds_read16<4 * 1024>(wb);                                             \
-        TZW_WAIT(1, 3); TZW_MM(Y[1], 1, AC[1]) B[5] = lds_read16<5 * 1024>(wb);                                             \
-        if (!(TZW_ABL & 2)) read_u(nslot, u);                                                                               \
-        TZW_WAIT(2, 6); TZW_MM(Y[0], 2, AC[1]) B[6] = lds_read16<6 * 1024>(wb);                                             \
-        TZW_WAIT(3, 6); TZW_MM(Y[1], 3, AC[2]) B[7] = lds_read16<7 * 1024>(wb);                                             \
-        TZW_WAIT(4, 6); TZW_MM(Y[0], 4, AC[3]) B[0] = lds_read16<0>(wn);                                                    \
-        TZW_WAIT(5, 6); TZW_MM(Y[1], 5, AC[4]) B[1] = lds_read16<1024>(wn);                                                 \
-        TZW_WAIT(6, 3); TZW_MM(Y[0], 6, AC[4]) B[2] = lds_read16<2048>(wn);                                                 \
+        TZW_WAIT(0, 3); TZW_MM(Y[0], 0, AC[0]) B[4] = lds_read16<WO + 4 * 1024>(wb);                                        \
+        TZW_WAIT(1, 3); TZW_MM(Y[1], 1, AC[1]) B[5] = lds_read16<WO + 5 * 1024>(wb);                                        \
+        if (!(TZW_ABL & 2)) read_u(udA[KN], u);                                                                             \
+        TZW_WAIT(2, 6); TZW_MM(Y[0], 2, AC[1]) B[6] = lds_read16<WO + 6 * 1024>(wb);                                        \
+        TZW_WAIT(3, 6); TZW_MM(Y[1], 3, AC[2]) B[7] = lds_read16<WO + 7 * 1024>(wb);                                        \
+        TZW_WAIT(4, 6); TZW_MM(Y[0], 4, AC[3]) B[0] = lds_read16<WN>(wn);                                                   \
+        TZW_WAIT(5, 6); TZW_MM(Y[1], 5, AC[4]) B[1] = lds_read16<WN + 1024>(wn);                                            \
+        TZW_WAIT(6, 3); TZW_MM(Y[0], 6, AC[4]) B[2] = lds_read16<WN + 2048>(wn);                                            \
         if (!(TZW_ABL & 2)) { TZW_TIEU(u); AN[0] = u[0][0]; AN[1] = u[0][1]; AN[2] = u[1][0]; AN[3] = u[1][1]; AN[4] = u[2][0]; AN[5] = u[2][1]; } \
         else { _Pragma("unroll") for (int q = 0; q < 6; ++q) AN[q] = AC[q]; }                                               \
         TZW_TIE6(AN);                                                                                                       \
-        TZW_WAIT(7, 3); TZW_MM(Y[1], 7, AC[5]) B[3] = lds_read16<3072>(wn);                                                 \
+        TZW_WAIT(7, 3); TZW_MM(Y[1], 7, AC[5]) B[3] = lds_read16<WN + 3072>(wn);                                            \
         TZW_STAGE_TAIL                                                                                                      \
     }
 #pragma unroll 1
@@ -493,8 +522,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (TZW_ABL & 16) s = S1;
 #pragma unroll 1
         while (s < S) {
-            TZW_STAGE2(A0, A1)
-            TZW_STAGE2(A1, A0)
+            TZW_STAGE2(0, A0, A1)
+            TZW_STAGE2(1, A1, A0)
+            TZW_STAGE2(2, A0, A1)
+            TZW_STAGE2(3, A1, A0)
         }
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -506,6 +537,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef TZW_MM
 #undef TZW_STAGE_TAIL
 #undef TZW_STAGE_HEAD
+#undef TZW_ISSUE_TO
 #undef TZW_WAIT
 
     // ---- epilogues.  This wave's outputs: pixel row a = ph of its 16 tiles, columns b = 0, 1: Y[b][column tile][e],
