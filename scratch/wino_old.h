@@ -40,7 +40,7 @@ namespace tzw {
 #define TZW_NS 4
 #endif
 #ifndef TZW_XKB
-#define TZW_XKB 32
+#define TZW_XKB 16
 #endif
 // ring slots; stages in flight ahead of the one being multiplied (<= NS - 1).  Measured on one box (scripts/gpu_wino_ab.sh,
 // ms of k_wino per cfg3 step): LEAD 5: 43.64, 4: 43.62, 3: 43.21, 2: 43.34 -- three stages (3.5 us) cover the memory latency,
@@ -53,8 +53,8 @@ static constexpr int WBYTES = 16 * 1024;             // weights of a stage
 static constexpr int PP = 41, P1BYTES = 8 * PP * 16; // same-resolution patch plane: 8 DMA pieces of 41 slots (>= 18 x 18)
 static constexpr int UP = 13, P2BYTES = 8 * UP * 16; // half-resolution patch plane: 8 pieces of 13 slots (>= 10 x 10)
 static constexpr int SLOT = WBYTES + P1BYTES + P2BYTES;
-static constexpr int XBYTES = TZW_XKB * 1024;        // exchange areas of the wave pairs: two of 16 KB, used in turn
-static constexpr int LDS_BYTES = NS * SLOT + XBYTES; // 125,952: one workgroup per CU all the same (256 registers per wave)
+static constexpr int XBYTES = TZW_XKB * 1024;        // exchange area of the wave pairs
+static constexpr int LDS_BYTES = NS * SLOT + XBYTES; // 109,568: one workgroup per CU all the same (256 registers per wave)
 static_assert(LDS_BYTES <= 160 * 1024, "LDS of a CU");
 static constexpr int WPW = 18, WLW = 10;   // halo patch of 18 x 18 pixels, half-resolution patch of 10 x 10
 
@@ -393,80 +393,81 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
     TZW_STAMP(2)
 
-    // ---- output transform, oracle order, one column tile per round (everything of a round dies with it: the first form
-    // computed all row sums ahead and the compiler parked them in AGPRs -- 1100 vector instructions per wave with the matrix
-    // pipes idle; this one has ~450).
-    //   y[0][b] = ((init + Z[0][b]) + Z[1][b]) + Z[2][b] belongs to the wave with rows 0, 1 and needs Z[2] of its partner;
-    //   y[1][b] = ((init + Z[1][b]) - Z[2][b]) - Z[3][b] belongs to the wave with rows 2, 3 and needs Z[1]:
-    // exchanged through LDS, two areas of 16 KB in turn, so that one barrier a round is enough (a wave that writes area
-    // t & 1 again in round t + 2 has passed the barrier of round t + 1, behind which nobody reads round t's data any more)
+    // ---- output transform, oracle order.  Row sums of the wave's two transform rows:
     f32x4 Y[2][4];
     {
+        f32x4 z0[2][NT], z1[2][NT];
+#pragma unroll
+        for (int li = 0; li < 2; ++li)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                z0[li][t] = (D[4 * li + 0][t] + D[4 * li + 1][t]) + D[4 * li + 2][t];
+                z1[li][t] = (D[4 * li + 1][t] - D[4 * li + 2][t]) - D[4 * li + 3][t];
+            }
         // accumulator start of this wave's outputs: row a = ph of the tiles, columns b = 0, 1; register e <-> tile (g, e)
         f32x4 in0[NT], in1[NT];
         {
-            const int y = ty0 + 8 * (mt >> 1) + 2 * g + ph, x0 = tx0 + 8 * (mt & 1);
-            if (a.init && !(TZW_ABL & 64)) {
-                if (ty0 + 16 <= a.H && tx0 + 16 <= a.W) {   // (uniform) the whole tile inside the image: one lane offset, uniform steps
-                    const float* ip = a.init + (unsigned)((y * a.W + x0) * a.ncols + cb * (16 * NT) + r);
+            const int y = ty0 + 8 * (mt >> 1) + 2 * g + ph;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = cb * (16 * NT) + 16 * t + r;
+                if (a.init) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float* ie = ip + (unsigned)(2 * e * a.ncols);
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            in0[t][e] = ie[16 * t];
-                            in1[t][e] = ie[a.ncols + 16 * t];
-                        }
+                        const int x = tx0 + 8 * (mt & 1) + 2 * e;
+                        const bool ok = y < a.H && x < a.W;   // (W even wherever tiles are cut: x + 1 < W too)
+                        const float* ip = a.init + ((long long)(ok ? y * a.W + x : 0)) * a.ncols + col;
+                        in0[t][e] = ip[0];
+                        in1[t][e] = ip[x + 1 < a.W && ok ? a.ncols : 0];
                     }
                 } else {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const int col = cb * (16 * NT) + 16 * t + r;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int x = x0 + 2 * e;
-                            const bool ok = y < a.H && x < a.W;   // (W even wherever tiles are cut: x + 1 < W too)
-                            const float* ip = a.init + ((long long)(ok ? y * a.W + x : 0)) * a.ncols + col;
-                            in0[t][e] = ip[0];
-                            in1[t][e] = ip[x + 1 < a.W && ok ? a.ncols : 0];
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float b = a.bias[cb * (16 * NT) + 16 * t + r];
+                    const float b = a.bias[col];
                     in0[t] = in1[t] = (f32x4){b, b, b, b};
                 }
             }
         }
-        f32x4* xo = (f32x4*)(smem + NS * SLOT) + (wv * 2) * 64 + lane;
-        const f32x4* xi = (const f32x4*)(smem + NS * SLOT) + ((wv ^ 4) * 2) * 64 + lane;
+        // y[0][b] = ((init + Z[0][b]) + Z[1][b]) + Z[2][b] belongs to the wave with rows 0, 1 and needs Z[2] of its partner;
+        // y[1][b] = ((init + Z[1][b]) - Z[2][b]) - Z[3][b] belongs to the wave with rows 2, 3 and needs Z[1]: exchanged
+        // through 16 KB of LDS, one column tile per round
+        const int give = ph == 0 ? 1 : 0;
+        if (XBYTES >= 64 * 1024) {   // everything in one round: 8 waves x 8 x 1 KB
+            f32x4* xo = (f32x4*)(smem + NS * SLOT) + (wv * 8) * 64 + lane;
+            const f32x4* xi = (const f32x4*)(smem + NS * SLOT) + ((wv ^ 4) * 8) * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            constexpr int XA = XBYTES / 2 / 16;   // (f32x4 units) the second area
-            const int xa = (t & 1) * XA;
-            // (the accumulators of this round are read HERE: hoisted, they and the start values went through ~300 register
-            // moves between VGPRs and AGPRs)
-            asm volatile("" : "+a"(D[0][t]), "+a"(D[1][t]), "+a"(D[2][t]), "+a"(D[3][t]), "+a"(D[4][t]), "+a"(D[5][t]), "+a"(D[6][t]), "+a"(D[7][t]));
-            // row sums of the wave's two transform rows
-            const f32x4 za0 = (D[0][t] + D[1][t]) + D[2][t], za1 = (D[1][t] - D[2][t]) - D[3][t];
-            const f32x4 zb0 = (D[4][t] + D[5][t]) + D[6][t], zb1 = (D[5][t] - D[6][t]) - D[7][t];
-            if (ph == 0) {   // (uniform)
-                xo[xa] = zb0;
-                xo[xa + 64] = zb1;
-            } else {
-                xo[xa] = za0;
-                xo[xa + 64] = za1;
+            for (int t = 0; t < NT; ++t) {
+                xo[(2 * t) * 64] = z0[give][t];
+                xo[(2 * t + 1) * 64] = z1[give][t];
             }
-            if (!(TZW_ABL & 128)) __syncthreads();
-            const f32x4 p0 = xi[xa], p1 = xi[xa + 64];
-            if (ph == 0) {
-                Y[0][t] = ((in0[t] + za0) + zb0) + p0;
-                Y[1][t] = ((in1[t] + za1) + zb1) + p1;
-            } else {
-                Y[0][t] = ((in0[t] + p0) - za0) - zb0;
-                Y[1][t] = ((in1[t] + p1) - za1) - zb1;
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 p0 = xi[(2 * t) * 64], p1 = xi[(2 * t + 1) * 64];
+                if (ph == 0) {
+                    Y[0][t] = ((in0[t] + z0[0][t]) + z0[1][t]) + p0;
+                    Y[1][t] = ((in1[t] + z1[0][t]) + z1[1][t]) + p1;
+                } else {
+                    Y[0][t] = ((in0[t] + p0) - z0[0][t]) - z0[1][t];
+                    Y[1][t] = ((in1[t] + p1) - z1[0][t]) - z1[1][t];
+                }
+            }
+            __syncthreads();   // (the pooling epilogue and the next use of the area come behind it)
+        } else {
+            f32x4* xo = (f32x4*)(smem + NS * SLOT) + (wv * 2) * 64 + lane;
+            const f32x4* xi = (const f32x4*)(smem + NS * SLOT) + ((wv ^ 4) * 2) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                xo[0] = z0[give][t];
+                xo[64] = z1[give][t];
+                __syncthreads();
+                const f32x4 p0 = xi[0], p1 = xi[64];
+                if (ph == 0) {
+                    Y[0][t] = ((in0[t] + z0[0][t]) + z0[1][t]) + p0;
+                    Y[1][t] = ((in1[t] + z1[0][t]) + z1[1][t]) + p1;
+                } else {
+                    Y[0][t] = ((in0[t] + p0) - z0[0][t]) - z0[1][t];
+                    Y[1][t] = ((in1[t] + p1) - z1[0][t]) - z1[1][t];
+                }
+                __syncthreads();
             }
         }
     }
@@ -573,19 +574,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // (Asking for these ahead of the output transform through asm loads -- to hide their round trip -- is NOT
                 // safe: the compiler is free to reuse an asm load's destination register before the data lands, and did:
                 // the late write then hit an address register, a memory fault in the bench.  Plain loads, at their use.)
-                cp[b][e] = a.aux && !(TZW_ABL & 256) ? a.aux[pix[b][e] * R + ch] : 0.0f;
+                cp[b][e] = a.aux ? a.aux[pix[b][e] * R + ch] : 0.0f;
             }
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (TZW_ABL & 512) {
-                    if (ok[b][e]) {
-                        o0[pix[b][e] * R + ch] = Y[b][0][e] + Y[b][1 % NT][e] + cp[b][e];
-                        if (o1) o1[pix[b][e] * R + ch] = Y[b][2 % NT][e] + Y[b][3 % NT][e];
-                    }
-                    continue;
-                }
                 const float gi = tz_hard_sigmoid(Y[b][0][e]);
                 const float gf = tz_hard_sigmoid(Y[b][1 % NT][e]);
                 const float gg = tz_tanh(Y[b][2 % NT][e]);
@@ -613,10 +607,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const float v0 = tz_relu(Y[0][t][e]), v1 = tz_relu(Y[1][t][e]);
                 m[t][e] = v1 > v0 ? v1 : v0;
             }
-        // (the exchange area the last round of the output transform did NOT use: a partner may still be reading that one)
-        constexpr int XP = (NT & 1) * (XBYTES / 2 / 16);
-        f32x4* xo = (f32x4*)(smem + NS * SLOT) + XP + (wv * 2) * 64 + lane;
-        const f32x4* xi = (const f32x4*)(smem + NS * SLOT) + XP + ((wv ^ 4) * 2) * 64 + lane;
+        f32x4* xo = (f32x4*)(smem + NS * SLOT) + (wv * 2) * 64 + lane;
+        const f32x4* xi = (const f32x4*)(smem + NS * SLOT) + ((wv ^ 4) * 2) * 64 + lane;
         // (no run-time indices into m[]: it has to stay in registers)
         xo[0] = ph == 0 ? m[2] : m[0];                       // the column tiles the partner finishes
         xo[64] = ph == 0 ? m[NT - 1] : m[1];                 // (NT = 3: the second one of wave 0 is not used)
