@@ -35,5 +35,21 @@ for slot in range(8):
     d = np.diff(st[:, :6], axis=1) / 100.0   # 100 MHz -> us
     total = (st[:, 5] - st[:, 0]) / 100.0
     what = {7: "L1 gates", 6: "L2 gates", 4: "L3 gates", 2: "A1", 3: "A2"}.get(slot, "slot %d" % slot)
+    extra = ""
+    if (st[:, 6] > 0).all():
+        extra = "; epilogue: cell-state loads landed after %.2f" % ((st[:, 6] - st[:, 4]).mean() / 100.0)
+    # gap between the end of a workgroup and the start of the next one on the same CU is not visible here; the launch's
+    # span over its workgroups is
+    span = (st[:, 5].max() - st[:, 0].min()) / 100.0
+    # the same CU's consecutive workgroups: the gap between one's last stamp and the next one's first
+    hw = st[:, 7]
+    cu = ((hw >> 32) << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
+    gaps = []
+    for c in np.unique(cu):
+        q = st[cu == c]
+        q = q[np.argsort(q[:, 0])]
+        gaps += list((q[1:, 0] - q[:-1, 5]) / 100.0)
+    if gaps:
+        extra += "; %d CUs, gap between workgroups of a CU %.2f us (min %.2f, max %.2f)" % (len(np.unique(cu)), np.mean(gaps), np.min(gaps), np.max(gaps))
     print("%s: %d workgroups stamped, life %.1f us: " % (what, ok.sum(), total.mean()) +
-          ", ".join("%s %.2f" % (n, v) for n, v in zip(names, d.mean(0))))
+          ", ".join("%s %.2f" % (n, v) for n, v in zip(names, d.mean(0))) + extra + "; launch span %.1f us = %.2f lives" % (span, span / total.mean()))

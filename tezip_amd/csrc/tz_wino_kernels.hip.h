@@ -180,6 +180,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ty0 = (tile / a.tiles_x) * 16, tx0 = (tile % a.tiles_x) * 16;
     const int g = lane >> 4, r = lane & 15;
     TZW_STAMP(0)
+#ifdef TZW_STAMPS
+    if (tid == 0 && blockIdx.x < 4096) {   // where this workgroup runs: (XCC, SE, SH, CU) -- slot 7
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        tzw_stamps[(a.ncb & 3) | (EPI == EPI_LSTM ? 4 : 0)][blockIdx.x][7] = ((unsigned long long)(xcc & 15) << 32) | hw;
+    }
+#endif
     const unsigned sbase = lds_addr(smem);
     const int S1 = a.src[0].C >> 2;                       // stages of the same-resolution source
     const int S = S1 + (UPS ? a.src[1].C >> 2 : 0);       // ... and of the upsampled one
@@ -216,11 +223,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* xp1 = UPS ? a.src[1].p + (long long)n * a.src[1].nstride : nullptr;       // ... of the upsampled one
     int si = 0;                                                                            // ... its number
     const unsigned wvw = (unsigned)(2 * wv) * 1024, wvp = WBYTES + (unsigned)wv * (PP * 16), wvu = WBYTES + P1BYTES + (unsigned)wv * (UP * 16);
-#define TZW_ISSUE_TO(KI)                                                                                                    \
+#define TZW_ISSUE_W0(KI) dma_lanes(wp, lane16, sbase + (unsigned)(KI) * SLOT + wvw);
+#define TZW_ISSUE_W1(KI) dma_lanes(wp + 256, lane16, sbase + (unsigned)(KI) * SLOT + wvw + 1024);
+#define TZW_ISSUE_P(KI)                                                                                                     \
     {                                                                                                                       \
         const unsigned so = sbase + (unsigned)(KI) * SLOT;                                                                  \
-        dma_lanes(wp, lane16, so + wvw);                                                                                    \
-        dma_lanes(wp + 256, lane16, so + wvw + 1024);                                                                       \
         if (!UPS || si < S1) {                                                                                              \
             dma_gather(xp0, poff, pmask, so + wvp);                                                                         \
             xp0 += 4;                                                                                                       \
@@ -231,6 +238,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         wp += wstride;                                                                                                      \
         ++si;                                                                                                               \
     }
+#define TZW_ISSUE_TO(KI) { TZW_ISSUE_W0(KI) TZW_ISSUE_W1(KI) TZW_ISSUE_P(KI) }
     // zero the patch areas once: the slots of out-of-image pixels are never written by the DMA (a tile whose halo lies
     // inside the image has none)
     const bool interior = ty0 >= 2 && tx0 >= 2 && ty0 + 18 <= a.H && tx0 + 18 <= a.W;
@@ -347,8 +355,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define TZW_ABL 0
 #endif
 #define TZW_WAIT(P, N) if (!(TZW_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(B[P]) : : "memory")
+#ifndef TZW_ISSUE_AT
+#define TZW_ISSUE_AT 1
+#endif
+#define TZW_ISSUE_HERE(K, AT)                                                                                               \
+        if (TZW_ISSUE_AT == (AT) && !(TZW_ABL & 8) && s + LEAD < S) TZW_ISSUE_TO(((K) + LEAD) % NS)                         \
+        if (TZW_ISSUE_AT == 10 + (AT) - 1 && !(TZW_ABL & 8) && s + LEAD < S) TZW_ISSUE_W0(((K) + LEAD) % NS)                \
+        if (TZW_ISSUE_AT == 10 + (AT) - 2 && !(TZW_ABL & 8) && s + LEAD < S) TZW_ISSUE_W1(((K) + LEAD) % NS)                \
+        if (TZW_ISSUE_AT == 10 + (AT) - 3 && !(TZW_ABL & 8) && s + LEAD < S) TZW_ISSUE_P(((K) + LEAD) % NS)
 #define TZW_STAGE_HEAD(K)                                                                                                   \
-        if (!(TZW_ABL & 8) && s + LEAD < S) TZW_ISSUE_TO(((K) + LEAD) % NS)                                                 \
+        TZW_ISSUE_HERE(K, 0)                                                                                                \
         constexpr int KN = ((K) + 1) % NS;                                    /* the next stage's slot */                   \
         const unsigned wb = ((K) & 2) ? wbH : wbL, wn = (KN & 2) ? wbH : wbL;                                               \
         constexpr int WO = ((K) & 1) * SLOT, WN = (KN & 1) * SLOT;            /* ... folded into the read immediates */
@@ -364,10 +380,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         TZW_STAGE_HEAD(K)                                                                                                   \
         f32x2 d[3][2];                                                                                                      \
         TZW_WAIT(0, 3); TZW_MM(D[0], 0, VC[0]) B[4] = lds_read16<WO + 4 * 1024>(wb);                                        \
+        TZW_ISSUE_HERE(K, 1)                                                                                                \
         TZW_WAIT(1, 3); TZW_MM(D[1], 1, VC[1]) B[5] = lds_read16<WO + 5 * 1024>(wb);                                        \
+        TZW_ISSUE_HERE(K, 2)                                                                                                \
         if (!(TZW_ABL & 2)) read_d(adA[KN], d);                                                                             \
         TZW_WAIT(2, 9); TZW_MM(D[2], 2, VC[2]) B[6] = lds_read16<WO + 6 * 1024>(wb);                                        \
+        TZW_ISSUE_HERE(K, 3)                                                                                                \
         TZW_WAIT(3, 9); TZW_MM(D[3], 3, VC[3]) B[7] = lds_read16<WO + 7 * 1024>(wb);                                        \
+        TZW_ISSUE_HERE(K, 4)                                                                                                \
         TZW_WAIT(4, 9); TZW_MM(D[4], 4, VC[4]) B[0] = lds_read16<WN>(wn);                                                   \
         TZW_WAIT(5, 9); TZW_MM(D[5], 5, VC[5]) B[1] = lds_read16<WN + 1024>(wn);                                            \
         TZW_WAIT(6, 3); TZW_MM(D[6], 6, VC[6]) B[2] = lds_read16<WN + 2048>(wn);                                            \
@@ -484,36 +504,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             u[1] = lds_read2<8, WLW * 4>(ad);        // (row 0, column 2), (row 1, column 0)
             u[2] = lds_read2<WLW * 4 + 4, WLW * 4 + 8>(ad);   // (row 1, columns 1, 2)
         };
-        float A0[6], A1[6];
+        // (the fragments stay where the reads put them -- pairs; a copy into scalars was a register move per stage behind an
+        // asm read, which tests/test_build_guard.py does not let through)
+        f32x2 A0[3], A1[3];
         {
-            f32x2 u[3];
-            read_u(udA[0], u);   // (S1 is a multiple of 4: the first stage of this phase sits in slot 0)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]) : : "memory");
-            A0[0] = u[0][0]; A0[1] = u[0][1]; A0[2] = u[1][0]; A0[3] = u[1][1]; A0[4] = u[2][0]; A0[5] = u[2][1];
-            TZW_TIE6(A0);
+            read_u(udA[0], A0);   // (S1 is a multiple of 4: the first stage of this phase sits in slot 0)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A0[0]), "+v"(A0[1]), "+v"(A0[2]) : : "memory");
             // (the weight stream was drained by that wait: restart it)
             B[0] = lds_read16<0>(wbL);
             B[1] = lds_read16<1024>(wbL);
             B[2] = lds_read16<2048>(wbL);
             B[3] = lds_read16<3072>(wbL);
         }
-        // lp = 2 tap + b: tap = (tpy, tpx) -> A[3 tpy + b + tpx]
+        // lp = 2 tap + b: tap = (tpy, tpx) -> A[3 tpy + b + tpx]  (A[q] = fragment pair q >> 1, half q & 1)
 #define TZW_STAGE2(K, AC, AN)                                                                                               \
     {                                                                                                                       \
         TZW_STAGE_HEAD(K)                                                                                                   \
-        f32x2 u[3];                                                                                                         \
-        TZW_WAIT(0, 3); TZW_MM(Y[0], 0, AC[0]) B[4] = lds_read16<WO + 4 * 1024>(wb);                                        \
-        TZW_WAIT(1, 3); TZW_MM(Y[1], 1, AC[1]) B[5] = lds_read16<WO + 5 * 1024>(wb);                                        \
-        if (!(TZW_ABL & 2)) read_u(udA[KN], u);                                                                             \
-        TZW_WAIT(2, 6); TZW_MM(Y[0], 2, AC[1]) B[6] = lds_read16<WO + 6 * 1024>(wb);                                        \
-        TZW_WAIT(3, 6); TZW_MM(Y[1], 3, AC[2]) B[7] = lds_read16<WO + 7 * 1024>(wb);                                        \
-        TZW_WAIT(4, 6); TZW_MM(Y[0], 4, AC[3]) B[0] = lds_read16<WN>(wn);                                                   \
-        TZW_WAIT(5, 6); TZW_MM(Y[1], 5, AC[4]) B[1] = lds_read16<WN + 1024>(wn);                                            \
-        TZW_WAIT(6, 3); TZW_MM(Y[0], 6, AC[4]) B[2] = lds_read16<WN + 2048>(wn);                                            \
-        if (!(TZW_ABL & 2)) { TZW_TIEU(u); AN[0] = u[0][0]; AN[1] = u[0][1]; AN[2] = u[1][0]; AN[3] = u[1][1]; AN[4] = u[2][0]; AN[5] = u[2][1]; } \
-        else { _Pragma("unroll") for (int q = 0; q < 6; ++q) AN[q] = AC[q]; }                                               \
-        TZW_TIE6(AN);                                                                                                       \
-        TZW_WAIT(7, 3); TZW_MM(Y[1], 7, AC[5]) B[3] = lds_read16<WN + 3072>(wn);                                            \
+        TZW_WAIT(0, 3); TZW_MM(Y[0], 0, AC[0][0]) B[4] = lds_read16<WO + 4 * 1024>(wb);                                     \
+        TZW_ISSUE_HERE(K, 1)                                                                                                \
+        TZW_WAIT(1, 3); TZW_MM(Y[1], 1, AC[0][1]) B[5] = lds_read16<WO + 5 * 1024>(wb);                                     \
+        TZW_ISSUE_HERE(K, 2)                                                                                                \
+        if (!(TZW_ABL & 2)) read_u(udA[KN], AN);                                                                            \
+        TZW_WAIT(2, 6); TZW_MM(Y[0], 2, AC[0][1]) B[6] = lds_read16<WO + 6 * 1024>(wb);                                     \
+        TZW_ISSUE_HERE(K, 3)                                                                                                \
+        TZW_WAIT(3, 6); TZW_MM(Y[1], 3, AC[1][0]) B[7] = lds_read16<WO + 7 * 1024>(wb);                                     \
+        TZW_ISSUE_HERE(K, 4)                                                                                                \
+        TZW_WAIT(4, 6); TZW_MM(Y[0], 4, AC[1][1]) B[0] = lds_read16<WN>(wn);                                                \
+        TZW_WAIT(5, 6); TZW_MM(Y[1], 5, AC[2][0]) B[1] = lds_read16<WN + 1024>(wn);                                         \
+        TZW_WAIT(6, 3); TZW_MM(Y[0], 6, AC[2][0]) B[2] = lds_read16<WN + 2048>(wn);                                         \
+        /* the patch reads have arrived (they are older than the three weight reads that wait left outstanding) */          \
+        if (TZW_ABL & 2) { AN[0] = AC[0]; AN[1] = AC[1]; AN[2] = AC[2]; }                                                   \
+        TZW_TIEU(AN);                                                                                                       \
+        TZW_WAIT(7, 3); TZW_MM(Y[1], 7, AC[2][1]) B[3] = lds_read16<WN + 3072>(wn);                                         \
         TZW_STAGE_TAIL                                                                                                      \
     }
 #pragma unroll 1
@@ -537,6 +559,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef TZW_STAGE_TAIL
 #undef TZW_STAGE_HEAD
 #undef TZW_ISSUE_TO
+#undef TZW_ISSUE_W0
+#undef TZW_ISSUE_W1
+#undef TZW_ISSUE_P
+#undef TZW_ISSUE_HERE
 #undef TZW_WAIT
 
     // ---- epilogues.  This wave's outputs: pixel row a = ph of its 16 tiles, columns b = 0, 1: Y[b][column tile][e],
@@ -575,6 +601,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // the late write then hit an address register, a memory fault in the bench.  Plain loads, at their use.)
                 cp[b][e] = a.aux && !(TZW_ABL & 256) ? a.aux[pix[b][e] * R + ch] : 0.0f;
             }
+#ifdef TZW_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TZW_STAMP(6)
+#endif
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
