@@ -21,14 +21,14 @@ frames = synth.turbulence(8, 512, 512, seed=3)
 ctx.rollout(frames, 0, 2)
 ctx.rollout(frames, 0, 2)
 ctx.synchronize()
-buf = np.zeros((8, 4096, 8), np.uint64)
+buf = np.zeros((8, 4096, 16), np.uint64)
 lib = _lib.load()
 lib.tz_debug_wino_stamps.argtypes = [C.c_void_p]
 assert lib.tz_debug_wino_stamps(buf.ctypes.data) == 0
 names = ["prologue", "same-res loop", "output transform", "upsampled loop", "epilogue"]
 for slot in range(8):
     st = buf[slot]
-    ok = st[:, 0] > 0
+    ok = (st[:, 0] > 0) & (st[:, 5] > 0)
     if not ok.any():
         continue
     st = st[ok].astype(np.int64)
@@ -51,5 +51,10 @@ for slot in range(8):
         gaps += list((q[1:, 0] - q[:-1, 5]) / 100.0)
     if gaps:
         extra += "; %d CUs, gap between workgroups of a CU %.2f us (min %.2f, max %.2f)" % (len(np.unique(cu)), np.mean(gaps), np.min(gaps), np.max(gaps))
+    # core clock during the stage loops: cycles of s_memtime per microsecond of s_memrealtime
+    for a_, b_, nm in ((1, 2, "same-res loop"), (3, 4, "upsampled loop")):
+        dt = (st[:, b_] - st[:, a_]) / 100.0
+        if dt.mean() > 1.0:
+            extra += "; core clock in the %s %.0f MHz" % (nm, ((st[:, 8 + b_] - st[:, 8 + a_]) / dt).mean())
     print("%s: %d workgroups stamped, life %.1f us: " % (what, ok.sum(), total.mean()) +
           ", ".join("%s %.2f" % (n, v) for n, v in zip(names, d.mean(0))) + extra + "; launch span %.1f us = %.2f lives" % (span, span / total.mean()))

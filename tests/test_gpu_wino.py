@@ -142,3 +142,27 @@ def test_compress_decompress_matches_oracle_under_pa2(ctx, nt, h, w, p, window, 
         ctx.rollout_decode(ref["key_frame"].reshape(nt, h, w, 3), p)
         other = ctx.decode(payload, table)
         assert np.abs(other.astype(int) - frames.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("ipw", [2, 3, 6, 12])
+def test_column_blocks_per_workgroup(ipw, monkeypatch):
+    """A k_wino workgroup does several column blocks of its tile one after the other, the DMA stream running on from one
+    into the next (launch_wino_t picks how many from the grid; at these sizes it would pick 1): forced here through
+    TEZIP_WINO_IPW (every convolution whose column-block count it divides), ragged tiles included -- same bits."""
+    from tezip_amd import _lib
+    monkeypatch.setenv("TEZIP_WINO_IPW", str(ipw))
+    c = _lib.Context(0)
+    try:
+        c.set_contract(2)
+        rng = np.random.default_rng(17)
+        w = FULL.init_weights(seed=19, bias_scale=0.15)
+        for hp, wp in ((72, 88), (32, 32)):
+            net = _net(w, FULL, hp, wp)
+            c.load_model(FULL, w)
+            c.prepare(hp, wp, max_batch=2)
+            frames = rng.integers(0, 256, (3, hp, wp, 3)).astype(np.float32) / np.float32(255)
+            got = c.predict_next(frames)
+            for i in range(3):
+                np.testing.assert_array_equal(got[i], net.next(frames[i]), err_msg="%dx%d frame %d" % (hp, wp, i))
+    finally:
+        c.close()

@@ -94,8 +94,14 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
         if (e) ctx->lat_mode = atoi(e);
         e = getenv("TEZIP_PA");                  // arithmetic contract a context starts with (tz_set_contract): 0 (default), 1 or 2
         if (e && e[0] >= '0' && e[0] <= '2' && !e[1]) ctx->contract = e[0] - '0';
+        e = getenv("TEZIP_WINO_IPW");            // measurements: column blocks per k_wino workgroup (0 = per launch)
+        if (e) ctx->wino_ipw = atoi(e);
     }
     ctx->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = prop.multiProcessorCount;
+    }
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
     } else {

@@ -40,7 +40,8 @@ struct ConvArgs {
     const float* Wimg;  // the same weights in LDS image order for k_conv16 (see pack_conv), or null
     const float* Wblk;  // block-step image for k_conv16b (see pack_block_image), or null
     const float* Wlat;  // per-wave fragment image for k_convlat: [slot][column block][4 column tiles][lane][k-step], or null
-    const float* Wwino; // TZ-PA2 stage image for k_wino: [stage][column block][16 weight sets][lane][4 column tiles], or null
+    const float* Wwino; // TZ-PA2 stage image for k_wino: [column block][stage][16 weight sets][lane][4 column tiles], or null
+    int ipw;            // k_wino: column blocks a workgroup does one after the other (divides ncb)
     const float* zero;  // >= 16 bytes of zeros: LDS-DMA source of out-of-image patch pixels
     int ncols;
     const float* bias;  // [ncols]

@@ -56,6 +56,8 @@ struct tz_ctx {
     int conv_impl = 1;                // tz_set_conv_impl: 1 = LDS-DMA kernels where they apply
     int lat_mode = 1;                 // k_convlat: 0 never, 1 where the cost model says so, 2 wherever eligible (TEZIP_LAT)
     int contract = 0;                 // arithmetic contract of the predictor: 0 = by frame size, 1 = TZ-PA1, 2 = TZ-PA2 (tz_set_contract, TEZIP_PA)
+    int num_cus = 256;                // compute units of the device (k_wino: column blocks per workgroup)
+    int wino_ipw = 0;                 // TEZIP_WINO_IPW (measurements): column blocks per k_wino workgroup, 0 = chosen per launch
     // rollout-resident data
     int nt = 0, H = 0, W = 0, Hp = 0, Wp = 0, warm_up = 0;
     uint8_t* d_frames = nullptr;      // nt*H*W*3 (encoder: originals; decoder: key stack)

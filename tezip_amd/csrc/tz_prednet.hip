@@ -225,7 +225,8 @@ static int pack_conv(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, con
 //   then the same along c.
 // Stages behind those = the channel quads of the upsampled source segs[1]: 16 sets = (parity class (a, b), collapsed tap tp)
 // at index 8 a + 2 tp + b (the order in which wave (.., ph = a) of k_wino consumes them), values = pack_conv's collapsed sums.
-// Image: [stage][column block][set][lane = (channel of the quad) * 16 + column][column tile (4, zero beyond NT)].
+// Image: [column block][stage][set][lane = (channel of the quad) * 16 + column][column tile (4, zero beyond NT)]: the stages of
+// a column block, and then of the next one, are one contiguous stream (a k_wino workgroup walks it with one running pointer).
 static int pack_wino(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, const std::vector<ColSrc>& cols, int NT, PackedConv* pc) {
     if (segs.empty() || segs[0].up || segs[0].C % 16 || (NT != 3 && NT != 4) || segs.size() > 2 ||
         (segs.size() == 2 && (!segs[1].up || segs[1].C % 16)))
@@ -234,7 +235,7 @@ static int pack_wino(tz_ctx* ctx, tz_model* m, const std::vector<Seg>& segs, con
     const int S1 = segs[0].C / 4, S2 = segs.size() == 2 ? segs[1].C / 4 : 0;
     std::vector<float> I((size_t)(S1 + S2) * ncb * 16 * 256, 0.0f);
     auto at = [&](int st, int cb, int set, int lane, int nt) -> float& {
-        return I[((((size_t)st * ncb + cb) * 16 + set) * 64 + lane) * 4 + nt];
+        return I[((((size_t)cb * (S1 + S2) + st) * 16 + set) * 64 + lane) * 4 + nt];
     };
     for (int col = 0; col < ncols; ++col) {
         const ColSrc& cs = cols[col];
@@ -329,13 +330,22 @@ static void launch_conv16_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
 }
 
 template <int NT, int EPI, bool UPS>
-static int launch_wino_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
+static int launch_wino_t(tz_ctx* ctx, const ConvArgs& a0, int nbatch) {
     static bool attr_set = false;   // (per instantiation; the attribute belongs to the function, not to a context)
     if (!attr_set) {
         TZ_HIP(ctx, hipFuncSetAttribute((const void*)k_wino<NT, EPI, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, tzw::LDS_BYTES));
         attr_set = true;
     }
-    const int blocks = a.ncb * a.tiles_x * a.tiles_y * nbatch;
+    // Column blocks per workgroup: as many as leave a workgroup for every CU (one workgroup occupies a CU).  A workgroup pays
+    // its geometry and its first DMA round trip once, and the column blocks of a tile march through the SAME weight stream on
+    // all CUs at the same time.
+    ConvArgs a = a0;
+    const int tiles = a.tiles_x * a.tiles_y * nbatch;
+    a.ipw = 1;
+    for (int d = 2; d <= a.ncb; ++d)
+        if (a.ncb % d == 0 && (long long)tiles * (a.ncb / d) >= ctx->num_cus) a.ipw = d;
+    if (ctx->wino_ipw > 0 && a.ncb % ctx->wino_ipw == 0) a.ipw = ctx->wino_ipw;   // (TEZIP_WINO_IPW: measurements)
+    const int blocks = (a.ncb / a.ipw) * tiles;
     hipLaunchKernelGGL((k_wino<NT, EPI, UPS>), dim3(blocks), dim3(512), tzw::LDS_BYTES, ctx->stream, a);
     TZ_HIP(ctx, hipGetLastError());
     return TZ_OK;
@@ -374,9 +384,9 @@ static int effective_contract(const tz_ctx* ctx) {
 }
 
 #ifdef TZW_STAMPS
-// diagnostic build only (not in tezip_hip.h): the stamps of the last k_wino launches, [8 shape slots][4096 workgroups][8]
+// diagnostic build only (not in tezip_hip.h): the stamps of the last k_wino launches, [8 shape slots][4096 workgroups][16]
 extern "C" int tz_debug_wino_stamps(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tzw_stamps), sizeof(unsigned long long) * 8 * 4096 * 8) == hipSuccess ? 0 : -3;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tzw_stamps), sizeof(unsigned long long) * 8 * 4096 * 16) == hipSuccess ? 0 : -3;
 }
 #endif
 extern "C" int tz_set_contract(tz_ctx* ctx, int contract) {

@@ -159,8 +159,8 @@ __device__ __forceinline__ f32x2 pk_cross(f32x2 a, f32x2 b) {
 
 #ifdef TZW_STAMPS
 // diagnostic build: s_memrealtime (100 MHz) at six points of a workgroup's life, wave 0, per (kernel shape slot, workgroup)
-__device__ unsigned long long tzw_stamps[8][4096][8];
-#define TZW_STAMP(K) if (tid == 0 && blockIdx.x < 4096) tzw_stamps[(a.ncb & 3) | (EPI == EPI_LSTM ? 4 : 0)][blockIdx.x][K] = __builtin_amdgcn_s_memrealtime();
+__device__ unsigned long long tzw_stamps[8][4096][16];   // [0..6] real time at the phase boundaries, [7] where, [8 + K] the core clock counter at stamp K
+#define TZW_STAMP(K) if (tid == 0 && stamp_id < 4096) { tzw_stamps[(a.ncb & 3) | (EPI == EPI_LSTM ? 4 : 0)][stamp_id][K] = __builtin_amdgcn_s_memrealtime(); tzw_stamps[(a.ncb & 3) | (EPI == EPI_LSTM ? 4 : 0)][stamp_id][8 + (K)] = __builtin_amdgcn_s_memtime(); }
 #else
 #define TZW_STAMP(K)
 #endif
@@ -173,18 +173,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = wv & 3, ph = wv >> 2;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int cb = bid % a.ncb;
-    bid /= a.ncb;
+    // a workgroup walks over `ipw` column blocks of ITS tile one after the other (items): geometry, zero fill and the first
+    // DMA round trip happen once, the stream of stages runs on across the items (the first stages of the next item are
+    // issued under the last ones of the current)
+    const int ipw = a.ipw, ncbg = a.ncb / ipw;
+    const int cb0 = (bid % ncbg) * ipw;
+    bid /= ncbg;
     const int ntiles = a.tiles_x * a.tiles_y;
     const int tile = bid % ntiles, n = bid / ntiles;
     const int ty0 = (tile / a.tiles_x) * 16, tx0 = (tile % a.tiles_x) * 16;
     const int g = lane >> 4, r = lane & 15;
+#ifdef TZW_STAMPS
+    int stamp_id = blockIdx.x * a.ipw;   // one record per item
+#endif
     TZW_STAMP(0)
 #ifdef TZW_STAMPS
-    if (tid == 0 && blockIdx.x < 4096) {   // where this workgroup runs: (XCC, SE, SH, CU) -- slot 7
+    if (tid == 0 && stamp_id < 4096) {   // where this workgroup runs: (XCC, SE, SH, CU) -- slot 7
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
-        tzw_stamps[(a.ncb & 3) | (EPI == EPI_LSTM ? 4 : 0)][blockIdx.x][7] = ((unsigned long long)(xcc & 15) << 32) | hw;
+        for (int q = 0; q < a.ipw && stamp_id + q < 4096; ++q) tzw_stamps[(a.ncb & 3) | (EPI == EPI_LSTM ? 4 : 0)][stamp_id + q][7] = ((unsigned long long)(xcc & 15) << 32) | hw;
     }
 #endif
     const unsigned sbase = lds_addr(smem);
@@ -217,8 +224,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // instructions.  The stage loops are unrolled once per ring slot, so every LDS address below is a constant; the global
     // addresses are running scalar pointers (the first form recomputed them from the stage number: ~40 scalar instructions
     // per stage and wave, 3.4 % of the kernel -- TZW_ABL 32 against 8).
-    const float* wp = a.Wwino + ((long long)cb * 16 + 2 * wv) * 256;                      // weights of the next stage to issue
-    const long long wstride = (long long)a.ncb * (16 * 256);
+    // (the stage image is [column block][stage]: the weight pointer simply runs on from one item into the next)
+    const float* wp = a.Wwino + (((long long)cb0 * S) * 16 + 2 * wv) * 256;               // weights of the next stage to issue
     const float* xp0 = a.src[0].p + (long long)n * a.src[0].nstride;                       // ... its quad of the same-resolution source
     const float* xp1 = UPS ? a.src[1].p + (long long)n * a.src[1].nstride : nullptr;       // ... of the upsampled one
     int si = 0;                                                                            // ... its number
@@ -235,8 +242,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             dma_gather(xp1, uoff, umask, so + wvu);                                                                         \
             xp1 += 4;                                                                                                       \
         }                                                                                                                   \
-        wp += wstride;                                                                                                      \
-        ++si;                                                                                                               \
+        wp += 16 * 256;                                                                                                     \
+        if (++si == S) {   /* on to the next item: the next column block's stage 0, the sources from their first quad */   \
+            si = 0;                                                                                                         \
+            xp0 -= 4 * S1;                                                                                                  \
+            if (UPS) xp1 -= 4 * (S - S1);                                                                                   \
+        }                                                                                                                   \
     }
 #define TZW_ISSUE_TO(KI) { TZW_ISSUE_W0(KI) TZW_ISSUE_W1(KI) TZW_ISSUE_P(KI) }
     // zero the patch areas once: the slots of out-of-image pixels are never written by the DMA (a tile whose halo lies
@@ -252,12 +263,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     TZW_ISSUE_TO(0)
     TZW_ISSUE_TO(1)
     if (LEAD > 2) TZW_ISSUE_TO(2)
-
-    f32x4 D[8][4];
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) D[p][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // A address of this lane: tile r = (tyl, txl) of quadrant mt, channel g of the quad, first of the wave's three rows
     const int tyl = r >> 2, txl = r & 3;
@@ -323,10 +328,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
-    // stages 0 and 1 landed for everyone
+    // stages 0 and 1 landed for everyone (from the second item on the last stage of the item before has seen to that)
     if (nlead == LEAD) wait_vm_stages<LEAD - 2>();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < ipw; ++it) {
+    const int cb = cb0 + it;
+    const bool more = it + 1 < ipw;   // (uniform) the DMA stream runs on into another item
+    // (the pixel offsets of the output transform and of the epilogue do not depend on the item: hoisted out of this loop they
+    // sat in 16 registers through every stage loop and were spilled to scratch; they are made to depend on this)
+    int per_item = 0;
+    asm volatile("" : "+s"(per_item));
+    f32x4 D[8][4];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) D[p][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     TZW_STAMP(1)
     float V0[8], V1[8];
     {
@@ -359,17 +377,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define TZW_ISSUE_AT 1
 #endif
 #define TZW_ISSUE_HERE(K, AT)                                                                                               \
-        if (TZW_ISSUE_AT == (AT) && !(TZW_ABL & 8) && s + LEAD < S) TZW_ISSUE_TO(((K) + LEAD) % NS)                         \
-        if (TZW_ISSUE_AT == 10 + (AT) - 1 && !(TZW_ABL & 8) && s + LEAD < S) TZW_ISSUE_W0(((K) + LEAD) % NS)                \
-        if (TZW_ISSUE_AT == 10 + (AT) - 2 && !(TZW_ABL & 8) && s + LEAD < S) TZW_ISSUE_W1(((K) + LEAD) % NS)                \
-        if (TZW_ISSUE_AT == 10 + (AT) - 3 && !(TZW_ABL & 8) && s + LEAD < S) TZW_ISSUE_P(((K) + LEAD) % NS)
+        if (TZW_ISSUE_AT == (AT) && !(TZW_ABL & 8) && (s + LEAD < S || more)) TZW_ISSUE_TO(((K) + LEAD) % NS)                         \
+        if (TZW_ISSUE_AT == 10 + (AT) - 1 && !(TZW_ABL & 8) && (s + LEAD < S || more)) TZW_ISSUE_W0(((K) + LEAD) % NS)                \
+        if (TZW_ISSUE_AT == 10 + (AT) - 2 && !(TZW_ABL & 8) && (s + LEAD < S || more)) TZW_ISSUE_W1(((K) + LEAD) % NS)                \
+        if (TZW_ISSUE_AT == 10 + (AT) - 3 && !(TZW_ABL & 8) && (s + LEAD < S || more)) TZW_ISSUE_P(((K) + LEAD) % NS)
 #define TZW_STAGE_HEAD(K)                                                                                                   \
         TZW_ISSUE_HERE(K, 0)                                                                                                \
         constexpr int KN = ((K) + 1) % NS;                                    /* the next stage's slot */                   \
         const unsigned wb = ((K) & 2) ? wbH : wbL, wn = (KN & 2) ? wbH : wbL;                                               \
         constexpr int WO = ((K) & 1) * SLOT, WN = (KN & 1) * SLOT;            /* ... folded into the read immediates */
 #define TZW_STAGE_TAIL                                                                                                      \
-        if (s + LEAD < S) wait_vm_stages<LEAD - 2>();                                                                       \
+        if (s + LEAD < S || more) wait_vm_stages<LEAD - 2>();                                                               \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
         if (!(TZW_ABL & 1)) __builtin_amdgcn_s_barrier();                                                                   \
         ++s;
@@ -425,7 +443,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // accumulator start of this wave's outputs: row a = ph of the tiles, columns b = 0, 1; register e <-> tile (g, e)
         f32x4 in0[NT], in1[NT];
         {
-            const int y = ty0 + 8 * (mt >> 1) + 2 * g + ph, x0 = tx0 + 8 * (mt & 1);
+            const int y = ty0 + 8 * (mt >> 1) + 2 * g + ph + per_item, x0 = tx0 + 8 * (mt & 1);
             if (a.init && !(TZW_ABL & 64)) {
                 if (ty0 + 16 <= a.H && tx0 + 16 <= a.W) {   // (uniform) the whole tile inside the image: one lane offset, uniform steps
                     const float* ip = a.init + (unsigned)((y * a.W + x0) * a.ncols + cb * (16 * NT) + r);
@@ -567,7 +585,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- epilogues.  This wave's outputs: pixel row a = ph of its 16 tiles, columns b = 0, 1: Y[b][column tile][e],
     // accumulator row 4 g + e = tile (tyl = g, txl = e)
-    const int oy = ty0 + 8 * (mt >> 1) + 2 * g + ph;
+    const int oy = ty0 + 8 * (mt >> 1) + 2 * g + ph + per_item;
     if (EPI == EPI_RAW) {
         float* on = a.out0 + (long long)n * a.out0_nstride;
 #pragma unroll
@@ -652,7 +670,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         xo[64] = ph == 0 ? m[NT - 1] : m[1];                 // (NT = 3: the second one of wave 0 is not used)
         __syncthreads();
         const f32x4 q0 = xi[0], q1 = xi[64];
-        const int yp = (ty0 >> 1) + 4 * (mt >> 1) + g;
+        const int yp = (ty0 >> 1) + 4 * (mt >> 1) + g + per_item;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (ph == 1 && 2 + k >= NT) break;               // wave 1 finishes column tiles 2 .. NT - 1, wave 0 tiles 0, 1
@@ -675,9 +693,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
 #ifdef TZW_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TZW_STAMP(5)
+    if (more) {
+        ++stamp_id;
+        TZW_STAMP(0)   // (of the next item)
+    }
 #endif
+    }   // items
 }
 
 // k_wino_ref: the same TZ-PA2 convolutions (and epilogues) as k_wino, written the plain way -- one thread per (tile, column
@@ -693,6 +715,7 @@ __global__ __launch_bounds__(256) void k_wino_ref(const ConvArgs a) {
     const long long nthreads = (long long)TX * TY * a.ncb * gcols;
     const int n = blockIdx.y;
     const int S1 = a.src[0].C >> 2, C0 = a.src[0].C;
+    const int SR = S1 + (UPS ? a.src[1].C >> 2 : 0);            // stages of a column block in the image
     const float* x0 = a.src[0].p + (long long)n * a.src[0].nstride;
     const float* x1 = UPS ? a.src[1].p + (long long)n * a.src[1].nstride : nullptr;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nthreads; id += (long long)gridDim.x * blockDim.x) {
@@ -721,7 +744,7 @@ __global__ __launch_bounds__(256) void k_wino_ref(const ConvArgs a) {
                     t[rr][2] = d[rr][2] - d[rr][1];
                     t[rr][3] = d[rr][1] - d[rr][3];
                 }
-                const float* wq = a.Wwino + ((((long long)(c >> 2) * a.ncb + cb) * 16) * 64 + (c & 3) * 16 + j) * 4 + nt;
+                const float* wq = a.Wwino + ((((long long)cb * SR + (c >> 2)) * 16) * 64 + (c & 3) * 16 + j) * 4 + nt;
                 for (int jj = 0; jj < 4; ++jj) {
                     const float v0 = t[0][jj] - t[2][jj], v1 = t[1][jj] + t[2][jj], v2 = t[2][jj] - t[1][jj], v3 = t[1][jj] - t[3][jj];
                     D[0 + jj] = fmaf(v0, wq[(0 + jj) * 256], D[0 + jj]);
@@ -754,7 +777,7 @@ __global__ __launch_bounds__(256) void k_wino_ref(const ConvArgs a) {
                         for (int tp = 0; tp < 4; ++tp) {
                             const int ly = ty - 1 + ay + (tp >> 1), lx = tx - 1 + bx + (tp & 1);
                             const bool inside = ly >= 0 && ly < H2 && lx >= 0 && lx < W2;
-                            const float* wq = a.Wwino + ((((long long)(S1 + (c0 >> 2)) * a.ncb + cb) * 16 + 8 * ay + 2 * tp + bx) * 64 + j) * 4 + nt;
+                            const float* wq = a.Wwino + ((((long long)cb * SR + S1 + (c0 >> 2)) * 16 + 8 * ay + 2 * tp + bx) * 64 + j) * 4 + nt;
                             for (int k = 0; k < 4; ++k) {
                                 const float xv = inside ? x1[((long long)ly * W2 + lx) * a.src[1].pstride + c0 + k] : 0.0f;
                                 acc = fmaf(xv, wq[k * 64], acc);
