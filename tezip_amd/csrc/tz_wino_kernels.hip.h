@@ -97,6 +97,11 @@ __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
 __device__ __forceinline__ void mfma_acc(f32x4& acc, float a, float b) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
+// the first multiplication of a chain: the accumulator starts at the literal 0 (fma(a, b, +0), the same operation as on a zeroed
+// register -- without the 128 register writes per item that zeroing was)
+__device__ __forceinline__ void mfma_first(f32x4& acc, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+}
 // float32 add / subtract the compiler cannot pair into v_pk_add_f32 (it did: 16 packed adds + 12 moves to line their
 // operands up, 28 instructions where 20 do -- and a packed fp32 instruction takes the SIMD longer than a plain one, all of
 // it time the matrix pipe does not get).  Same IEEE results.
@@ -340,11 +345,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // sat in 16 registers through every stage loop and were spilled to scratch; they are made to depend on this)
     int per_item = 0;
     asm volatile("" : "+s"(per_item));
-    f32x4 D[8][4];
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) D[p][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 D[8][4];   // (first written by the first stage of the item: mfma_first)
     TZW_STAMP(1)
     float V0[8], V1[8];
     {
@@ -391,35 +392,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
         if (!(TZW_ABL & 1)) __builtin_amdgcn_s_barrier();                                                                   \
         ++s;
-#define TZW_MM(ACC, P, AV)                                                                                                  \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) mfma_acc(ACC[t], AV, B[P][t]);
-#define TZW_STAGE1(K, VC, VN)                                                                                               \
+#define TZW_MMF(F, ACC, P, AV)                                                                                              \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) F(ACC[t], AV, B[P][t]);
+#define TZW_MM(ACC, P, AV) TZW_MMF(mfma_acc, ACC, P, AV)
+#define TZW_STAGE1(K, VC, VN) TZW_STAGE1_(K, VC, VN, mfma_acc)
+#define TZW_STAGE1_(K, VC, VN, F)                                                                                           \
     {                                                                                                                       \
         TZW_STAGE_HEAD(K)                                                                                                   \
         f32x2 d[3][2];                                                                                                      \
-        TZW_WAIT(0, 3); TZW_MM(D[0], 0, VC[0]) B[4] = lds_read16<WO + 4 * 1024>(wb);                                        \
+        TZW_WAIT(0, 3); TZW_MMF(F, D[0], 0, VC[0]) B[4] = lds_read16<WO + 4 * 1024>(wb);                                        \
         TZW_ISSUE_HERE(K, 1)                                                                                                \
-        TZW_WAIT(1, 3); TZW_MM(D[1], 1, VC[1]) B[5] = lds_read16<WO + 5 * 1024>(wb);                                        \
+        TZW_WAIT(1, 3); TZW_MMF(F, D[1], 1, VC[1]) B[5] = lds_read16<WO + 5 * 1024>(wb);                                        \
         TZW_ISSUE_HERE(K, 2)                                                                                                \
         if (!(TZW_ABL & 2)) read_d(adA[KN], d);                                                                             \
-        TZW_WAIT(2, 9); TZW_MM(D[2], 2, VC[2]) B[6] = lds_read16<WO + 6 * 1024>(wb);                                        \
+        TZW_WAIT(2, 9); TZW_MMF(F, D[2], 2, VC[2]) B[6] = lds_read16<WO + 6 * 1024>(wb);                                        \
         TZW_ISSUE_HERE(K, 3)                                                                                                \
-        TZW_WAIT(3, 9); TZW_MM(D[3], 3, VC[3]) B[7] = lds_read16<WO + 7 * 1024>(wb);                                        \
+        TZW_WAIT(3, 9); TZW_MMF(F, D[3], 3, VC[3]) B[7] = lds_read16<WO + 7 * 1024>(wb);                                        \
         TZW_ISSUE_HERE(K, 4)                                                                                                \
-        TZW_WAIT(4, 9); TZW_MM(D[4], 4, VC[4]) B[0] = lds_read16<WN>(wn);                                                   \
-        TZW_WAIT(5, 9); TZW_MM(D[5], 5, VC[5]) B[1] = lds_read16<WN + 1024>(wn);                                            \
-        TZW_WAIT(6, 3); TZW_MM(D[6], 6, VC[6]) B[2] = lds_read16<WN + 2048>(wn);                                            \
+        TZW_WAIT(4, 9); TZW_MMF(F, D[4], 4, VC[4]) B[0] = lds_read16<WN>(wn);                                                   \
+        TZW_WAIT(5, 9); TZW_MMF(F, D[5], 5, VC[5]) B[1] = lds_read16<WN + 1024>(wn);                                            \
+        TZW_WAIT(6, 3); TZW_MMF(F, D[6], 6, VC[6]) B[2] = lds_read16<WN + 2048>(wn);                                            \
         /* the patch reads have arrived (empty asm: nothing is computed with d before here) and the transform is done */   \
         /* HERE, not sunk to its first use right in front of an asm MFMA                                              */   \
         if (!(TZW_ABL & 2)) { TZW_TIED(d); transform(d, VN); }                                                              \
         else { _Pragma("unroll") for (int q = 0; q < 8; ++q) VN[q] = VC[q]; }                                               \
         TZW_TIE8(VN);                                                                                                       \
-        TZW_WAIT(7, 3); TZW_MM(D[7], 7, VC[7]) B[3] = lds_read16<WN + 3072>(wn);                                            \
+        TZW_WAIT(7, 3); TZW_MMF(F, D[7], 7, VC[7]) B[3] = lds_read16<WN + 3072>(wn);                                            \
         TZW_STAGE_TAIL                                                                                                      \
     }
 #pragma unroll 1
     for (int rep = 0; rep < ((TZW_ABL & 16) ? 2 : 1); ++rep) {   // (ablation 16, with 8: every loop twice -> time per stage)
     if (TZW_ABL & 16) s = 0;
+    if (rep == 0) {    // the first block of an item: its first stage starts the chains
+        TZW_STAGE1_(0, V0, V1, mfma_first)
+        TZW_STAGE1(1, V1, V0)
+        TZW_STAGE1(2, V0, V1)
+        TZW_STAGE1(3, V1, V0)
+    }
 #pragma unroll 1
     while (s < S1) {   // one 16-channel block = four stages = once round the ring
         TZW_STAGE1(0, V0, V1)
@@ -573,6 +582,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     TZW_STAMP(4)
 #undef TZW_STAGE2
 #undef TZW_STAGE1
+#undef TZW_STAGE1_
+#undef TZW_MMF
 #undef TZW_MM
 #undef TZW_STAGE_TAIL
 #undef TZW_STAGE_HEAD
