@@ -14,18 +14,25 @@
 //   four parity classes over the same 2x2 half-resolution pixels), order: 16-channel block, channel quad, tap, channel.
 //
 // How (scripts/microbench/wino8.hip is the measured skeleton):
-//   workgroup = 8 waves = 16x16 output pixels x 64 (48) columns, ONE per CU (156 KB of LDS), two waves per SIMD.
-//   Wave (mt, ph): the 16 tiles of quadrant mt and the transform rows i = 2 ph, 2 ph + 1: 8 positions x NT column tiles
-//   = 128 accumulation registers, held in AGPRs by asm MFMAs with a tied operand.  The channel quad is the outermost loop:
-//   a STAGE = 16 KB of transformed weights [position][lane][4 column tiles] + one quad plane of the 18x18 halo patch
-//   (columns stored evens first: the 16 tiles of a wave sit on consecutive slots, 2-way bank conflicts instead of 4-way),
-//   DMA'd into a ring of 6 slots 5 stages ahead; per stage and wave 32 MFMAs, 8 ds_read_b128 of weights in one
-//   continuous stream 4 positions ahead, 6 ds_read2_b32 of the patch and 20 vector adds for the next stage's B^T d B,
-//   one counted vmcnt wait and one barrier.  After the last channel quad the partners exchange two row sums each through
-//   LDS and form their two outputs per tile; the upsampled source then runs through the same pipeline (stage = one channel
-//   quad: 4 classes x 4 taps of collapsed weights, 6 patch reads, no transform), the epilogue is fused.
+//   workgroup = 8 waves = 16x16 output pixels x 64 (48) columns, ONE per CU (123 KB of LDS, 256 registers per wave), two
+//   waves per SIMD.  Wave (mt, ph): the 16 tiles of quadrant mt and the transform rows i = 2 ph, 2 ph + 1: 8 positions x NT
+//   column tiles = 128 accumulation registers, held in AGPRs by asm MFMAs with a tied operand.  The channel quad is the
+//   outermost loop: a STAGE = 16 KB of transformed weights [position][lane][4 column tiles] + one quad plane of the 18x18
+//   halo patch (columns stored evens first: the 16 tiles of a wave sit on consecutive slots, 2-way bank conflicts instead of
+//   4-way), DMA'd into a ring of 4 slots 3 stages ahead; per stage and wave 32 MFMAs, 8 ds_read_b128 of weights in one
+//   continuous stream 4 positions ahead, 6 ds_read2_b32 of the patch and 10 packed adds for the next stage's B^T d B, one
+//   counted vmcnt wait and one barrier.  The stage loops are unrolled once per ring slot; the DMA issue of a stage sits
+//   behind its first four MFMAs (right behind the barrier both waves of a SIMD ran its scalar code with the matrix pipe
+//   empty: 5.5 % of the kernel).  After the last channel quad the partners exchange two row sums each through LDS and form
+//   their two outputs per tile; the upsampled source then runs through the same pipeline (stage = one channel quad: 4
+//   classes x 4 taps of collapsed weights, 3 patch reads, no transform), the epilogue is fused.  A workgroup does `ipw`
+//   column blocks of its tile one after the other (items): the stage image is [column block][stage], the DMA stream runs
+//   on from one item into the next.
 // Invariants nobody checks for us (DESIGN.md section 5 "hand-scheduled kernels" applies here too):
-//   * every wave issues exactly 3 LDS-DMA instructions per stage, so `vmcnt(9)` = "my pieces of stage s + 2 have landed";
+//   * every wave issues exactly 3 LDS-DMA instructions per stage, all of them before the stage's tail, so `vmcnt(3)` there
+//     = "my pieces of stage s + 2 have landed" (other loads or stores in flight only make that wait longer, never shorter:
+//     loads return in order);
+//   * S1 and S2 are multiples of 4 (sources of 16 k channels): an item starts in ring slot 0 whatever came before it;
 //   * the LDS queue is in order, so the lgkmcnt immediates below are counts of younger reads;
 //   * asm MFMAs get no hazard handling from the compiler: a VALU result is never consumed by the very next MFMA (empty
 //     asm statements pin the transform away from its first use), accumulators are read behind explicit wait states.
