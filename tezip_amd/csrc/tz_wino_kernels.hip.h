@@ -622,6 +622,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int ch = cb * 16 + r, R = a.Cout;
         float* o0 = a.out0 + (long long)n * a.out0_nstride;
         float* o1 = a.out1 ? a.out1 + (long long)n * a.out1_nstride : nullptr;
+        if (ty0 + 16 <= a.H && tx0 + 16 <= a.W && !(TZW_ABL & 512)) {
+            // (uniform) the whole tile inside the image: ONE lane offset for the eight outputs of a lane, the steps between
+            // them uniform -- scalar base + 32-bit lane offset addressing, no per-output predicates (the general form below
+            // spends ~25 instructions per output on 64-bit addresses and exec masks; in a serial section, with the matrix
+            // pipes idle, instructions are what costs)
+            const unsigned voff = 4u * (unsigned)((oy * a.W + tx0 + 8 * (mt & 1)) * R + ch);
+            const char* pc = (const char*)a.aux;
+            char* p0 = (char*)o0;
+            char* p1 = (char*)o1;
+            float cpv[2][4];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    cpv[b][e] = a.aux && !(TZW_ABL & 256) ? *(const float*)(pc + (size_t)(2 * e + b) * R * 4 + voff) : 0.0f;
+#ifdef TZW_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TZW_STAMP(6)
+#endif
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gi = tz_hard_sigmoid(Y[b][0][e]);
+                    const float gf = tz_hard_sigmoid(Y[b][1 % NT][e]);
+                    const float gg = tz_tanh(Y[b][2 % NT][e]);
+                    const float go = tz_hard_sigmoid(Y[b][3 % NT][e]);
+                    const float t1 = gf * cpv[b][e];
+                    const float t2 = gi * gg;
+                    const float c = t1 + t2;
+                    const float rr = go * tz_tanh(c);
+                    *(float*)(p0 + (size_t)(2 * e + b) * R * 4 + voff) = rr;
+                    if (o1) *(float*)(p1 + (size_t)(2 * e + b) * R * 4 + voff) = c;
+                }
+        } else {
         long long pix[2][4];
         bool ok[2][4];
         float cp[2][4];
@@ -665,6 +700,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (o1) o1[pix[b][e] * R + ch] = c;
                 }
             }
+        }
     } else if (EPI == EPI_POOL_ERR) {
         // prednet.py:289-291 then 274-277 of the next level: A = maxpool2x2(relu(conv)) -- the pooling window IS the tile --,
         // e = [relu(Ahat0 - A), relu(A - Ahat0)] at the pooled resolution.  The wave holds one row of every window; the
