@@ -46,13 +46,10 @@ namespace tzw {
 #ifndef TZW_NS
 #define TZW_NS 4
 #endif
-#ifndef TZW_XKB
-#define TZW_XKB 32
-#endif
 // ring slots; stages in flight ahead of the one being multiplied (<= NS - 1).  Measured on one box (scripts/gpu_wino_ab.sh,
-// ms of k_wino per cfg3 step): LEAD 5: 43.64, 4: 43.62, 3: 43.21, 2: 43.34 -- three stages (3.5 us) cover the memory latency,
-// more only fills the queues.  (The LDS a shorter ring frees could hold the whole exchange of the output transform at once,
-// TZW_XKB = 64: measured 6 % SLOWER, 46.0 against 43.3 ms, for reasons not pursued; the exchange stays one column tile a round.)
+// ms of k_wino per cfg3 step), first kernel: LEAD 5: 43.64, 4: 43.62, 3: 43.21, 2: 43.34; final schedule: 3: 37.2, 2: 39.2 --
+// three stages (3 us) cover the memory latency, more only fills the queues.  (The whole exchange of the output transform in
+// one round, 64 KB of LDS: measured 6 % SLOWER, 46.0 against 43.3 ms; it stays one column tile a round.)
 static constexpr int NS = TZW_NS, LEAD = TZW_LEAD;
 static_assert(LEAD >= 2 && LEAD <= NS - 1, "the slot a stage is DMA'd into must be one nobody reads any more");
 static_assert(NS == 4, "the stage loops are unrolled once per ring slot (every LDS address a constant), 4 stages = one 16-channel block");
@@ -60,7 +57,7 @@ static constexpr int WBYTES = 16 * 1024;             // weights of a stage
 static constexpr int PP = 41, P1BYTES = 8 * PP * 16; // same-resolution patch plane: 8 DMA pieces of 41 slots (>= 18 x 18)
 static constexpr int UP = 13, P2BYTES = 8 * UP * 16; // half-resolution patch plane: 8 pieces of 13 slots (>= 10 x 10)
 static constexpr int SLOT = WBYTES + P1BYTES + P2BYTES;
-static constexpr int XBYTES = TZW_XKB * 1024;        // exchange areas of the wave pairs: two of 16 KB, used in turn
+static constexpr int XBYTES = 32 * 1024;             // exchange areas of the wave pairs: two of 16 KB, used in turn
 static constexpr int LDS_BYTES = NS * SLOT + XBYTES; // 125,952: one workgroup per CU all the same (256 registers per wave)
 static_assert(LDS_BYTES <= 160 * 1024, "LDS of a CU");
 static constexpr int WPW = 18, WLW = 10;   // halo patch of 18 x 18 pixels, half-resolution patch of 10 x 10
