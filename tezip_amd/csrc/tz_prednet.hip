@@ -336,14 +336,19 @@ static int launch_wino_t(tz_ctx* ctx, const ConvArgs& a0, int nbatch) {
         TZ_HIP(ctx, hipFuncSetAttribute((const void*)k_wino<NT, EPI, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, tzw::LDS_BYTES));
         attr_set = true;
     }
-    // Column blocks per workgroup: as many as leave a workgroup for every CU (one workgroup occupies a CU).  A workgroup pays
-    // its geometry and its first DMA round trip once, and the column blocks of a tile march through the SAME weight stream on
-    // all CUs at the same time.
+    // Column blocks per workgroup (one workgroup occupies a CU): the divisor of ncb with the shortest launch in items --
+    // rounds of workgroups over the CUs x items per workgroup --, the largest one among equals: a workgroup pays its geometry
+    // and its first DMA round trip once, and the column blocks of a tile march through the SAME weight stream on all CUs at
+    // the same time.
     ConvArgs a = a0;
     const int tiles = a.tiles_x * a.tiles_y * nbatch;
     a.ipw = 1;
-    for (int d = 2; d <= a.ncb; ++d)
-        if (a.ncb % d == 0 && (long long)tiles * (a.ncb / d) >= ctx->num_cus) a.ipw = d;
+    long long best = -1;
+    for (int d = 1; d <= a.ncb; ++d) {
+        if (a.ncb % d) continue;
+        const long long wgs = (long long)tiles * (a.ncb / d), span = (wgs + ctx->num_cus - 1) / ctx->num_cus * d;
+        if (best < 0 || span <= best) best = span, a.ipw = d;
+    }
     if (ctx->wino_ipw > 0 && a.ncb % ctx->wino_ipw == 0) a.ipw = ctx->wino_ipw;   // (TEZIP_WINO_IPW: measurements)
     const int blocks = (a.ncb / a.ipw) * tiles;
     hipLaunchKernelGGL((k_wino<NT, EPI, UPS>), dim3(blocks), dim3(512), tzw::LDS_BYTES, ctx->stream, a);
