@@ -73,7 +73,11 @@ int tz_host_free(void* p);
 int tz_model_load(tz_ctx* ctx, int nb_layers, const int* stack_sizes, const int* r_stack_sizes,
                   const float* const* weights);
 /* Fix the padded frame size and the largest number of windows advanced together; allocates
- * activations and evaluates everything that does not depend on the input (t=0 states). */
+ * activations and evaluates everything that does not depend on the input (t=0 states).
+ * Hp, Wp: multiples of 8 and of 2^(levels-1) (compress.py:178-181: "Image size is out of scope").
+ * TZ_ERR_UNSUPPORTED when a level's widest per-frame plane (gate columns / error maps) would
+ * reach 2^30 floats: the kernels address inside one frame's plane with 32-bit offsets (the
+ * reference's model: up to ~44 M pixels a frame; frames and batch items are 64-bit strides). */
 int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch);
 /* X_hat[0,0] of predict((1,2,Hp,Wp,3)) (compress.py:197): input independent. out: Hp*Wp*3 f32 */
 int tz_predict_c0(tz_ctx* ctx, float* out);

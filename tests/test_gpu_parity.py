@@ -539,6 +539,19 @@ def test_rollout_rejects_short_sequences_and_bad_sizes(ctx):
         ctx.rollout(np.zeros((3, 24, 16, 3), np.uint8), 0, 2)
 
 
+def test_prepare_rejects_frames_whose_planes_pass_32_bit_offsets(ctx):
+    """The convolution kernels address inside one frame's plane of a level with 32-bit offsets: a frame size whose widest
+    plane would pass 2^30 floats is refused before anything is allocated (status UNSUPPORTED, message with the numbers);
+    the context stays usable."""
+    from tezip_amd._lib import TezipError
+    ctx.load_model(FULL, FULL.init_weights(seed=1))
+    with pytest.raises(TezipError) as ei:
+        ctx.prepare(8192, 8192, 1)            # level 1: 4096 x 4096 x 192 gate columns = 3.2e9 floats
+    assert "32-bit" in str(ei.value)
+    ctx.prepare(16, 16, 1)
+    assert ctx.predict_c0().shape == (16, 16, 3)
+
+
 def test_decode_rejects_key_stacks_that_do_not_cover_the_sequence(ctx):
     from tezip_amd._lib import TezipError
     cfg = SMALL

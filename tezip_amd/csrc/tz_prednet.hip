@@ -620,6 +620,17 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
     if ((Hp % (1 << (L - 1))) || (Wp % (1 << (L - 1))) || (Hp % 8) || (Wp % 8))
         return tz_fail(ctx, TZ_ERR_INVALID,
                        "Image size is out of scope for this model: padded size %dx%d must divide by 8 and 2^(levels-1)", Hp, Wp);
+    // The convolution kernels address inside ONE frame's plane of a level with 32-bit offsets (LDS-DMA lane offsets, the
+    // accumulator starts, the epilogues' lane offsets); batch items and frames are 64-bit strides.  The largest plane is a
+    // level's gate columns or error maps: keep it under 2^30 floats (4 GiB).  PredNet (3,48,96,192): up to ~44 M pixels a frame.
+    for (int l = 0; l < L; ++l) {
+        const long long npx = (long long)(Hp >> l) * (Wp >> l);
+        const long long widest = std::max<long long>(4LL * m->rstack[l], std::max<long long>(2LL * m->stack[l], 8));
+        if (npx * widest >= (1LL << 30))
+            return tz_fail(ctx, TZ_ERR_UNSUPPORTED,
+                           "frame of %dx%d pixels: level %d holds %lld floats per frame, the kernels address a frame's plane with 32-bit offsets (< 2^30 floats)",
+                           Hp, Wp, l, npx * widest);
+    }
     if (m->prepared && m->Hp == Hp && m->Wp == Wp && m->maxB >= max_batch) {
         m->cap = max_batch;
         return TZ_OK;
