@@ -331,10 +331,13 @@ static void launch_conv16_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
 
 template <int NT, int EPI, bool UPS>
 static int launch_wino_t(tz_ctx* ctx, const ConvArgs& a0, int nbatch) {
-    static bool attr_set = false;   // (per instantiation; the attribute belongs to the function, not to a context)
-    if (!attr_set) {
+    // (per instantiation and device: the attribute belongs to the function on a device, not to a context; a process that
+    // opens contexts on several devices sets it on each)
+    static bool attr_set[64] = {false};
+    const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 63;
+    if (!attr_set[dev] || dev == 63) {
         TZ_HIP(ctx, hipFuncSetAttribute((const void*)k_wino<NT, EPI, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, tzw::LDS_BYTES));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     // Column blocks per workgroup (one workgroup occupies a CU): the divisor of ncb with the shortest launch in items --
     // rounds of workgroups over the CUs x items per workgroup --, the largest one among equals: a workgroup pays its geometry
