@@ -77,8 +77,9 @@ def step(w, L, a, r_tm1, c_tm1, e_tm1):
     return pred, r, c, e
 
 
-def predict(weights, stack, rstack, X):
-    """Model.predict on (T, Hp, Wp, C) for one sample -> (T, Hp, Wp, C) (compress.py:227)."""
+def predict(weights, stack, rstack, X, return_states=False):
+    """Model.predict on (T, Hp, Wp, C) for one sample -> (T, Hp, Wp, C) (compress.py:227); with return_states also
+    the state list r + c + e (prednet.py:298) after the last step."""
     L = len(stack)
     w = split_weights(weights, L)
     T, hp, wp, _ = X.shape
@@ -89,4 +90,6 @@ def predict(weights, stack, rstack, X):
     for t in range(T):
         pred, r, c, e = step(w, L, X[t].astype(np.float32), r, c, e)
         out.append(pred)
+    if return_states:
+        return np.stack(out), r + c + e
     return np.stack(out)

@@ -36,15 +36,22 @@ class TorchPredNet:
 
     def predict2(self, frame):
         """frame (Hp,Wp,3) float32 in [0,1] -> (X_hat[0,0], X_hat[0,1]) as numpy (Hp,Wp,3)."""
+        f = np.ascontiguousarray(frame, dtype=np.float32)
+        outs = self.predict_seq(np.stack([f, np.zeros_like(f)]))
+        return outs[0], outs[1]
+
+    def predict_seq(self, X, return_states=False):
+        """Model.predict on one sample: X (T,Hp,Wp,3) -> X_hat (T,Hp,Wp,3); with return_states also the state list
+        (r, c, e per level, HWC numpy) after the last step, the layout of prednet.py:298."""
         L, st, rs, hp, wp = self.L, self.st, self.rs, self.hp, self.wp
         z = lambda c, l: torch.zeros(c, hp >> l, wp >> l, device=self.dev, dtype=self.dtype)  # noqa: E731
         r = [z(rs[l], l) for l in range(L)]
         c = [z(rs[l], l) for l in range(L)]
         e = [z(2 * st[l], l) for l in range(L)]
         outs = []
-        a0 = torch.from_numpy(np.ascontiguousarray(frame, dtype=np.float32)).to(self.dev, self.dtype).permute(2, 0, 1)
         with torch.no_grad():
-            for a in (a0, torch.zeros_like(a0)):
+            for t in range(len(X)):
+                a = torch.from_numpy(np.ascontiguousarray(X[t], dtype=np.float32)).to(self.dev, self.dtype).permute(2, 0, 1)
                 rn, cn = [None] * L, [None] * L
                 for l in reversed(range(L)):
                     up = [F.interpolate(rn[l + 1][None], scale_factor=2, mode="nearest")[0]] if l < L - 1 else []
@@ -63,7 +70,9 @@ class TorchPredNet:
                     if l < L - 1:
                         a = F.max_pool2d(torch.relu(self._conv(e[l], self.w["a"][l]))[None], 2)[0]
                 r, c = rn, cn
-        return outs[0], outs[1]
+        if return_states:
+            return np.stack(outs), [s.permute(1, 2, 0).to(torch.float32).cpu().numpy() for s in r + c + e]
+        return np.stack(outs)
 
     def c0(self, hp=None, wp=None):
         return self.predict2(np.zeros((self.hp, self.wp, 3), np.float32))[0]

@@ -104,6 +104,10 @@ def _install_stubs():
     _stub("hickle")
     # identity "zstd": the files then hold the pre-zstd streams
     _stub("zstd", compress=lambda data, level=3: bytes(data), decompress=lambda data: bytes(data))
+    # round 5: numpy stand-ins for the Keras surface prednet.py touches, so that the reference's own PredNet class
+    # can be instantiated and stepped (tests/golden/keras_standin.py says what that does and does not pin)
+    import keras_standin
+    keras_standin.install(sys.modules)
     sys.path.insert(0, REF)
 
 
@@ -520,8 +524,75 @@ def _train_fixture(out):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+# ---- round 5: the reference's own PredNet class, executed ----------------------------------------------------------
+PREDNET_CASES = [
+    # name, stack_sizes (= R_stack_sizes, train.py:51-52), Hp, Wp, T, weight seed, bias scale, frame seed
+    ("small", (3, 16, 32), 16, 24, 2, 7, 0.3, 31),
+    ("small_t3", (3, 16, 32), 16, 24, 3, 8, 0.3, 32),        # three real frames: K.rnn carries r, c, e across steps
+    ("full64", (3, 48, 96, 192), 64, 64, 2, 123, 0.2, 33),   # train.py:51-55's model
+    ("full72x88", (3, 48, 96, 192), 72, 88, 2, 124, 0.1, 34),
+]
+
+
+def _prednet_fixture(out):
+    """Instantiates /root/reference/src/prednet.py's PredNet the way compress.py:163-173 does (weights=..., the train
+    layer's config with output_mode='prediction'), lets its build() create the convolutions, and runs
+    get_initial_state + step over the (1, T, Hp, Wp, 3) input of compress.py:224-227 (frame, then zeros).  Recorded
+    per case: the names/shapes of `trainable_weights` in the order build() leaves them, the initial-state shapes, the
+    state list (r, c, e per level) after every step, and X_hat.  The weight VALUES are not stored (27 MB for the full
+    model): they are tezip_amd.prednet.PredNetConfig.init_weights(seed, bias_scale), whose sha256 is."""
+    import hashlib
+    sys.modules.pop("prednet", None)
+    import prednet as ref_prednet
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tezip_amd.prednet import PredNetConfig
+    out["pn_cases"] = np.array([c[0] for c in PREDNET_CASES])
+    for name, stack, hp, wp, T, wseed, bscale, fseed in PREDNET_CASES:
+        cfg = PredNetConfig(stack_sizes=stack)
+        weights = cfg.init_weights(seed=wseed, bias_scale=bscale)
+        L = len(stack)
+        # train.py:57-60 builds the layer with output_mode='error', return_sequences=True; compress.py:163-168 takes
+        # that layer's config, switches output_mode and passes the trained weight list back in through `weights=`
+        layer_config = dict(stack_sizes=stack, R_stack_sizes=stack, A_filt_sizes=(3,) * (L - 1),
+                            Ahat_filt_sizes=(3,) * L, R_filt_sizes=(3,) * L, output_mode="prediction",
+                            return_sequences=True, data_format="channels_last")
+        layer = ref_prednet.PredNet(weights=weights, **layer_config)
+        rng = np.random.default_rng(fseed)
+        X = np.zeros((1, T, hp, wp, 3), np.float32)
+        nreal = T - 1 if T == 2 else T
+        X[0, :nreal] = rng.integers(0, 256, size=(nreal, hp, wp, 3)).astype(np.float32) / np.float32(255)
+        rec = []
+        X_hat = layer(X, record=rec)
+        pre = "pn_%s_" % name
+        out[pre + "stack"] = np.array(stack, dtype=np.int64)
+        out[pre + "hw"] = np.array([hp, wp], dtype=np.int64)
+        out[pre + "wseed_bias"] = np.array([wseed, bscale], dtype=np.float64)
+        out[pre + "weights_sha256"] = np.array(hashlib.sha256(b"".join(w.tobytes() for w in weights)).hexdigest())
+        out[pre + "weight_names"] = np.array([v.name for v in layer.trainable_weights])
+        out[pre + "weight_shapes"] = np.array([list(v.value.shape) + [0] * (4 - v.value.ndim)
+                                               for v in layer.trainable_weights], dtype=np.int64)
+        out[pre + "state_shapes"] = np.array([list(s.shape) for s in rec[0]], dtype=np.int64)
+        assert all(not s.any() for s in rec[0])
+        out[pre + "X"] = X
+        out[pre + "X_hat"] = X_hat.astype(np.float32)
+        for t in range(1, T + 1):
+            for k, s in enumerate(rec[t]):
+                # the full model: every state of the last step, of the first step only e (the errors against the real
+                # frame, which are what the second step's gates read; r and c of step one do not depend on the input)
+                if name.startswith("small") or t == T or "rce"[k // L] == "e":
+                    out[pre + "t%d_%s%d" % (t, "rce"[k // L], k % L)] = s[0].astype(np.float32)
+        print("prednet %-10s %d weights, X_hat %s, |X_hat[0,1]-X[0,0]| mean %.4f" % (
+            name, len(layer.trainable_weights), X_hat.shape, float(np.abs(X_hat[0, 1] - X[0, 0]).mean())))
+
+
 def main():
     _install_stubs()
+    if "--prednet-only" in sys.argv:
+        pn = {}
+        _prednet_fixture(pn)
+        np.savez_compressed(os.path.join(HERE, "ref_prednet.npz"), **pn)
+        print("ref_prednet.npz:", len(pn), "arrays")
+        return
     if "--train-only" in sys.argv:
         tr = {}
         _train_fixture(tr)
@@ -560,6 +631,10 @@ def main():
     _train_fixture(tr)
     np.savez_compressed(os.path.join(HERE, "ref_train.npz"), **tr)
     print("ref_train.npz:", len(tr), "arrays")
+    pn = {}
+    _prednet_fixture(pn)
+    np.savez_compressed(os.path.join(HERE, "ref_prednet.npz"), **pn)
+    print("ref_prednet.npz:", len(pn), "arrays")
 
 
 if __name__ == "__main__":

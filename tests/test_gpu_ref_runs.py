@@ -1,0 +1,108 @@
+"""The HIP operator seams fed the reference's OWN executions, with no oracle in between.
+
+tests/golden/ref_runs*.npz hold 17 executions of /root/reference/src/compress.py `run` and decompress.py `run` (fake
+predictor tests/golden/fake_predictor.py in place of the Keras model, identity in place of zstd: make_golden.py).  The
+predictions of such a run are a pure function of the frames and of which frames the reference made key frames, so
+they are rebuilt here from the reference's key_frame.dat with the fake predictor alone, and then
+
+  encoder (compress.py:292-373):  tz_delta_encode -> tz_error_bound -> tz_spatial_delta (+1600, histogram)
+                                  -> tz_build_table -> tz_remap      == the reference's entropy.dat payload + table
+  decoder (decompress.py:203-256): tz_unmap -> tz_spatial_undelta -> tz_reconstruct of the REFERENCE's payload
+                                  == the images the reference's decompress.run wrote.
+
+Byte for byte.  Nothing under oracle/ is imported."""
+import os
+
+import numpy as np
+import pytest
+
+import fake_predictor
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+RUNS = {}
+for _f in ("ref_runs.npz", "ref_runs2.npz", "ref_runs3.npz"):
+    _R = np.load(os.path.join(GOLDEN, _f))
+    RUNS.update({str(n): _R for n in _R["run_names"]})
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tezip_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _load(name):
+    R, pre = RUNS[name], "run_%s_" % name
+    f = R[pre + "frames"]
+    frames = np.ascontiguousarray(f if f.ndim == 4 else np.repeat(f[..., None], 3, axis=-1))   # compress.py:104-111: 'L' -> RGB
+    nt, h, w, _ = frames.shape
+    p, win, gray, entropy = (int(v) for v in R[pre + "params"])
+    stream = R[pre + "entropy"]
+    # trailer (compress.py:375-395): payload | table | T  (or -1) | 1, nt, H, W, 3 | PREPROCESS
+    assert stream[-6:].tolist() == [1, nt, h, w, 3, p]
+    tlen = int(stream[-7])
+    assert (tlen >= 0) == bool(entropy)
+    payload = stream[: nt * h * w * 3]
+    table = stream[nt * h * w * 3: -7] if tlen >= 0 else None
+    assert table is None or len(table) == tlen
+    key_frames = R[pre + "key_frame"].reshape(nt, h, w, 3)
+    key = np.array([bool(key_frames[i].any()) for i in range(nt)])              # decompress.py:123-129
+    return dict(frames=frames, p=p, mode=str(R[pre + "mode"]), bound=R[pre + "bound"].tolist(), entropy=bool(entropy),
+                payload=payload, table=table, key_frames=key_frames, key=key, decoded=R[pre + "decoded"])
+
+
+def _predictions(frames, key, p):
+    """What the reference's predictor seam returned, frame by frame (compress.py:189-229 = decompress.py:143-175): C0
+    for the warm-up frames, g(real frame) right after a key frame, g(previous prediction) otherwise.  At a key frame
+    the slot is a placeholder on both sides (delta forced to 0 / base = the key byte)."""
+    nt, h, w, _ = frames.shape
+    hp, wp = (h + 7) // 8 * 8, (w + 7) // 8 * 8
+    x_pad = np.zeros((nt, hp, wp, 3), np.float32)
+    x_pad[:, :h, :w] = frames.astype(np.float32) / np.float32(255)                # compress.py:138, data_utils.py:77-92
+    c0 = fake_predictor.c0_image(hp, wp)
+    pred = np.empty((nt, hp, wp, 3), np.float32)
+    for i in range(nt):
+        if i < p or key[i]:
+            pred[i] = c0
+        else:
+            pred[i] = fake_predictor.g_next(x_pad[i - 1] if key[i - 1] else pred[i - 1])
+    return pred
+
+
+@pytest.mark.parametrize("name", sorted(RUNS))
+def test_encoder_seams_reproduce_the_reference_payload(ctx, name):
+    r = _load(name)
+    frames, key, p = r["frames"], r["key"], r["p"]
+    nt = len(frames)
+    pred = _predictions(frames, key, p)
+    idx = np.arange(nt)
+    zero = ((idx == 0) | ((idx >= p) & key)).astype(np.uint8)       # compress.py:314: slot 0 of every group
+    skip = ((idx < p) | key).astype(np.uint8)                        # compress.py:315-316: warm-up group, slot 0
+    delta = ctx.delta_encode(pred, frames, zero)
+    ctx.error_bound(frames, delta, r["mode"], r["bound"], skip)
+    if r["entropy"]:
+        hist = np.zeros(2111, np.uint64)
+        y = ctx.spatial_delta(delta, 1, hist=hist)
+        table = ctx.build_table(hist)
+        np.testing.assert_array_equal(table, r["table"])
+        np.testing.assert_array_equal(ctx.remap(y, table), r["payload"])
+    else:
+        np.testing.assert_array_equal(ctx.spatial_delta(delta, 0), r["payload"])
+
+
+@pytest.mark.parametrize("name", sorted(RUNS))
+def test_decoder_seams_reproduce_the_reference_images(ctx, name):
+    r = _load(name)
+    frames, key, p = r["frames"], r["key"], r["p"]
+    nt, h, w, _ = frames.shape
+    pred = _predictions(frames, key, p)
+    x = ctx.unmap(r["payload"], r["table"], offset=True) if r["table"] is not None else np.ascontiguousarray(r["payload"])
+    d = ctx.spatial_undelta(x).reshape(nt, h, w, 3)
+    idx = np.arange(nt)
+    base_is_key = ((idx == 0) | ((idx >= p) & key)).astype(np.uint8)   # decompress.py:150-159, 181: the key frame itself
+    out = ctx.reconstruct(pred, r["key_frames"], base_is_key, d)
+    np.testing.assert_array_equal(out, r["decoded"])
