@@ -172,7 +172,7 @@ def wino_executed_flops_per_px0(cfg):
         gate_srcs_ok = (2 * st[l]) % 16 == 0 and (l == L - 1 or rs[l + 1] % 16 == 0) and rs[l] % 16 == 0
         if gate_srcs_ok:
             mac += (4 * 2 * st[l] + (4 * rs[l + 1] if l < L - 1 else 0)) * 4 * rs[l] / 4 ** l
-        if l < L - 1 and (2 * st[l]) % 16 == 0 and st[l + 1] % 48 == 0:
+        if l < L - 1 and (2 * st[l]) % 16 == 0 and (st[l + 1] % 64 == 0 or st[l + 1] % 48 == 0):   # tz_prednet.hip plain_nt
             mac += 4 * 2 * st[l] * st[l + 1] / 4 ** l
     return 2 * mac
 
@@ -186,7 +186,7 @@ def conv16_flops_per_px0(cfg):
         gate_srcs_ok = (2 * st[l]) % 16 == 0 and (l == L - 1 or rs[l + 1] % 16 == 0) and rs[l] % 16 == 0
         if gate_srcs_ok:
             mac += (9 * 2 * st[l] + (4 * rs[l + 1] if l < L - 1 else 0)) * 4 * rs[l] / 4 ** l
-        if l < L - 1 and (2 * st[l]) % 16 == 0 and st[l + 1] % 48 == 0:
+        if l < L - 1 and (2 * st[l]) % 16 == 0 and (st[l + 1] % 64 == 0 or st[l + 1] % 48 == 0):   # tz_prednet.hip plain_nt
             mac += 9 * 2 * st[l] * st[l + 1] / 4 ** l
     return 2 * mac
 
@@ -545,6 +545,8 @@ def main():
                                     "k_conv16_ms_per_step": k16, "k_conv16_frac_of_mfma_peak": c16_flops / (k16 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                     "tz_pa2_over_tz_pa1": value / rate1,
                                     "note": "the step of rounds 1-3 (every convolution a direct fmaf chain, k_conv16), same job, same box"}
+            except Exception as e:
+                extras["tz_pa1"] = {"error": repr(e)}
             finally:
                 ctx.set_contract(0)
                 own_step()
@@ -599,7 +601,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, frames[:8].cpu().numpy())
+        cpu = cpu_baseline(cfg, frames[:20].cpu().numpy())
         tr = extras.get("compression_ratio_trained")
         if isinstance(tr, dict) and "_weights" in tr:   # checker leg: small slice, HIP stream vs oracle stream
             cpu["trained_ratio_check"] = ratio_check_vs_oracle(ctx, cfg, tr.pop("_weights"), frames)
@@ -618,8 +620,10 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "value_definition": "device-resident: frames already in HBM when the clock starts, payload left in HBM, table on the "
-                                "host (the task contract's definition of `value`); SURVEY.md 8d / BASELINE.md 4 define frames/s "
-                                "host to host -- that rate is value_host_to_host (pinned buffers) and the host_to_host object",
+                                "host.  The bench contract fixes this definition (inputs resident in HBM when the timed region "
+                                "starts; a PCIe-inclusive rate is never `value`).  SURVEY.md 8d / BASELINE.md 4 define the "
+                                "BASELINE metric host to host: THAT number is value_host_to_host (pinned buffers, PCIe both ways "
+                                "inside the clock), measured in this same run -- quote it when comparing with the 50 frames/s target",
             "value_host_to_host": (extras.get("host_to_host") or {}).get("pinned_frames_per_s"),
             "higher_is_better": True,
             "scaling": "weak",
@@ -1002,30 +1006,34 @@ def host_cores():
     return n
 
 
-def cpu_baseline(cfg, frames8):
+def cpu_baseline(cfg, frames):
     """The oracle (a C/OpenMP port of the same path; the reference's Keras predictor cannot
     run here) on a bounded sample: one 512x512 window of 1 key + k predicted frames,
-    predict + delta, sized to ~15-25 s of CPU work."""
+    predict + delta, sized to ~20-25 s of CPU work; every frame is timed on its own so that the
+    line carries the spread (a shared box's host cores are noisy: rounds 3-4 saw 0.59 .. 0.79)."""
     cores = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)  # read by libgomp when the oracle library loads
     from oracle import coracle
     coracle.build()
     net = coracle.CPredNet(cfg.init_weights(seed=123), cfg.stack_sizes, cfg.R_stack_sizes, H, W)
     net.c0()  # t0 constants, untimed like tz_model_prepare
+    per = []
     t0 = time.perf_counter()
-    cur = coracle.u8_to_f32_frame(frames8[0], H, W)
-    cur = net.next(cur)
-    coracle.delta_frame(cur, frames8[1])
-    one = time.perf_counter() - t0
-    k = int(max(1, min(6, round(18.0 / max(one, 1e-3)) - 1)))
-    for i in range(k):
+    cur = coracle.u8_to_f32_frame(frames[0], H, W)
+    budget, i = 22.0, 0
+    while i < len(frames) - 1 and i < 19 and (i < 2 or (time.perf_counter() - t0) + per[-1] < budget):
+        t1 = time.perf_counter()
         cur = net.next(cur)
-        coracle.delta_frame(cur, frames8[2 + i])
+        coracle.delta_frame(cur, frames[1 + i])
+        per.append(time.perf_counter() - t1)
+        i += 1
     total = time.perf_counter() - t0
-    n = 1 + k
+    n = len(per)
+    rates = sorted(1.0 / t for t in per)
     return {"value": n / total, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d predicted 512x512x3 frames of the same stack (PredNet live work + delta), "
-                      "C oracle with OpenMP on the %d host cores of this job" % (n, cores)}
+            "per_frame_frames_per_s": {"min": rates[0], "median": rates[n // 2], "max": rates[-1]},
+            "sample": "%d predicted 512x512x3 frames of the same stack (one window: PredNet live work + delta each), "
+                      "C oracle with OpenMP on the %d host cores of this job; %.1f s of CPU work" % (n, cores, total)}
 
 
 if __name__ == "__main__":

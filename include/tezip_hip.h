@@ -47,6 +47,10 @@ typedef enum { TZ_MODE_ABS = 0, TZ_MODE_REL = 1, TZ_MODE_ABSREL = 2, TZ_MODE_PWR
 #define TZ_MAX_LEVELS 8
 
 int tz_version(void);
+/* "tezip_hip <version> gfx950 defines:<diagnostic switches this library was compiled with>".  A library whose string
+ * names a switch after "defines:" is a measurement build (csrc/tz_wino_kernels.hip.h: TZW_ABL computes WRONG results by
+ * design); bench.py and the tests refuse it.  No reference counterpart (the reference is interpreted Python). */
+const char* tz_build_info(void);
 const char* tz_strerror(int status);
 const char* tz_last_error(const tz_ctx* ctx);
 
@@ -102,9 +106,16 @@ int tz_set_conv_impl(tz_ctx* ctx, int lds_dma);
  * conv3x3_wino), everything else as in TZ-PA1.  Encoder and decoder must use the same contract: the on-disk format of the
  * reference has no place to record it.  0 (the default; or the environment variable TEZIP_PA) = by padded frame size, which
  * both sides know: TZ-PA2 from 256 x 256 pixels on, TZ-PA1 below.  tz_get_contract returns the contract in force (1 or 2)
- * for the prepared model.  Switching re-prepares nothing. */
+ * for the prepared model.  Switching re-prepares nothing.
+ * The prediction stack a rollout leaves in the context is STAMPED with the contract that produced it: tz_rollout_contract
+ * returns that stamp (1 or 2; TZ_ERR_STATE without a rollout) -- it is what the host records next to entropy.dat
+ * (tezip_amd.json) and what a decoder adopts --, and tz_encode / tz_encode_begin / tz_encode_delta / tz_decode /
+ * tz_decode_delta fail with TZ_ERR_STATE when the contract in force differs from the stamp (a tz_set_contract between a
+ * rollout and its encode/decode), because decompress.py:252-253 needs the decoder's predictions bit-identical to the
+ * encoder's. */
 int tz_set_contract(tz_ctx* ctx, int contract);
 int tz_get_contract(tz_ctx* ctx);
+int tz_rollout_contract(tz_ctx* ctx);
 /* Diagnostic: the inverse scan of decompress.py:22-29 (k_scan2p) lets a workgroup wait for the block sums of the workgroups
  * in front of it; that wait is bounded, and an expiry surfaces as TZ_ERR_HIP at the context's next stream synchronisation
  * (tz_ctx_synchronize, or any call that delivers host results).  This entry makes the next scans wait for the status words

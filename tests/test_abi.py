@@ -36,7 +36,9 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 def test_version_and_strerror(lib):
     L = lib.load()
-    assert L.tz_version() == 100
+    assert L.tz_version() == 101
+    # a product build names no diagnostic switch (a library built with TEZIP_DEFINES is refused by _lib.load())
+    assert L.tz_build_info() == b"tezip_hip 101 gfx950 defines:" and lib.diagnostic_defines() == []
     assert L.tz_strerror(0) == b"ok" and L.tz_strerror(-2) == b"no HIP device"
 
 

@@ -44,7 +44,7 @@ def test_cli_roundtrip_and_reference_format(tmp_path, gray, p, window, thr, mode
     ddir = _write(tmp_path, frames, gray)
     cdir, udir = str(tmp_path / "comp"), str(tmp_path / "out")
     compress.run(mdir, ddir, cdir, p, window, thr, mode, bound, True, True, entropy)
-    assert sorted(os.listdir(cdir)) == ["entropy.dat", "filename.txt", "key_frame.dat"]
+    assert sorted(os.listdir(cdir)) == ["entropy.dat", "filename.txt", "key_frame.dat", "tezip_amd.json"]
     names = ["frame_%03d.png" % t for t in range(nt)]
     assert open(os.path.join(cdir, "filename.txt")).read() == O.filename_txt(names, not gray)
     key_bytes = np.frombuffer(zstd.decompress(open(os.path.join(cdir, "key_frame.dat"), "rb").read()), np.uint8)
@@ -168,7 +168,7 @@ def test_sweep_under_torchrun_writes_the_files_of_one_process(tmp_path):
     r = subprocess.run(cmd, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert sorted(os.listdir(two)) == ["entropy.dat", "filename.txt", "key_frame.dat", "sweep.txt"]
+    assert sorted(os.listdir(two)) == ["entropy.dat", "filename.txt", "key_frame.dat", "sweep.txt", "tezip_amd.json"]
     for name in ("filename.txt", "key_frame.dat", "entropy.dat", "sweep.txt"):
         assert open(os.path.join(one, name), "rb").read() == open(os.path.join(two, name), "rb").read(), name
     assert open(os.path.join(two, "sweep.txt")).read().count("<- best") == 1

@@ -58,7 +58,7 @@ def test_learn_then_compress_then_uncompress_on_the_gpu(tmp_path):
     _write_pngs(ddir, test)
     cdir, udir = str(tmp_path / "comp"), str(tmp_path / "out")
     out = _cli(["-c", mdir, ddir, cdir, "-p", "0", "-w", "6", "-m", "abs", "-b", "0"])
-    assert "compress mode" in out and sorted(os.listdir(cdir)) == ["entropy.dat", "filename.txt", "key_frame.dat"]
+    assert "compress mode" in out and sorted(os.listdir(cdir)) == ["entropy.dat", "filename.txt", "key_frame.dat", "tezip_amd.json"]
     _cli(["-u", mdir, cdir, udir])
     got = np.stack([np.array(Image.open(os.path.join(udir, "f%03d.png" % t))) for t in range(12)])
     assert np.array_equal(got, test)                            # lossless

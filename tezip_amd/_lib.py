@@ -27,6 +27,7 @@ MODES = {"abs": 0, "rel": 1, "absrel": 2, "pwrel": 3}
 
 _SIGS = {
     "tz_version": (C.c_int, []),
+    "tz_build_info": (C.c_char_p, []),
     "tz_strerror": (C.c_char_p, [C.c_int]),
     "tz_last_error": (C.c_char_p, [C.c_void_p]),
     "tz_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -42,6 +43,7 @@ _SIGS = {
     "tz_scan_fault_inject": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint]),
     "tz_set_contract": (C.c_int, [C.c_void_p, C.c_int]),
     "tz_get_contract": (C.c_int, [C.c_void_p]),
+    "tz_rollout_contract": (C.c_int, [C.c_void_p]),
     "tz_act_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tz_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                              C.c_void_p, C.c_void_p]),
@@ -108,7 +110,22 @@ def load():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
         _LIB = lib
+        if diagnostic_defines(lib) and not os.environ.get("TEZIP_ALLOW_DIAGNOSTIC_BUILD"):
+            _LIB = None
+            raise ImportError("%s is a MEASUREMENT build (%s; compiled with TEZIP_DEFINES): its kernels are ablated or "
+                              "instrumented and must not serve jobs, tests or the bench.  Rebuild with `python -m "
+                              "tezip_amd.build` (TEZIP_DEFINES unset), or set TEZIP_ALLOW_DIAGNOSTIC_BUILD=1 in a "
+                              "measurement script." % (LIB_PATH, " ".join(diagnostic_defines(lib))))
     return _LIB
+
+
+def build_info(lib=None):
+    return (lib or load()).tz_build_info().decode()
+
+
+def diagnostic_defines(lib=None):
+    """The diagnostic switches the loaded library was compiled with (tz_build_info), [] for a product build."""
+    return build_info(lib).split("defines:", 1)[1].split()
 
 
 def pad8(v):
@@ -313,6 +330,13 @@ class Context:
 
     def get_contract(self):
         return int(self.lib.tz_get_contract(self.h))
+
+    def rollout_contract(self):
+        """The contract the resident prediction stack was made under (the stamp tz_rollout / tz_rollout_decode left)."""
+        rc = int(self.lib.tz_rollout_contract(self.h))
+        if rc < 0:
+            self._ck(rc)
+        return rc
 
     def scan_fault_inject(self, epoch_skew=0, poll_limit=0):
         """Diagnostic: make the inverse scan's bounded wait expire (see tz_scan_fault_inject); (0, 0) = normal."""

@@ -18,6 +18,18 @@ FLAGS = (["-D" + d for d in os.environ.get("TEZIP_DEFINES", "").split()] if os.e
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
+STAMP = os.path.join(CSRC, ".build_flags")
+
+
+def _flags_changed():
+    """The objects in csrc/ were compiled with another flag set (TEZIP_DEFINES: the diagnostic variants of
+    scripts/gpu_wino_ab.sh are built into the same libtezip_hip.so) -> everything is stale, whatever the mtimes say."""
+    try:
+        return open(STAMP).read() != " ".join(FLAGS)
+    except OSError:
+        return True
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -27,6 +39,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    force = force or _flags_changed()
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -50,6 +63,8 @@ def build(force=False, verbose=False):
                     print(err)
     if jobs or force or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
+        with open(STAMP, "w") as f:
+            f.write(" ".join(FLAGS))
     return LIB
 
 

@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-from . import _lib, weights, zstd
+from . import _lib, sidecar, weights, zstd
 from . import dist as tzdist
 from .data_utils import padding_shape
 
@@ -331,6 +331,9 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
                     print("table_create:{0}".format(prof["table_create"][0] / 1e3) + "[sec]")
                     print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
             _stream_outputs(ctx, OUTPUT_DIR, nt, H, W, key, table if ENTROPY_RUN else None, PREPROCESS, SHUFFLE, pool)
+            doc = sidecar.write(OUTPUT_DIR, ctx.rollout_contract(), wts, hp, wp)   # the contract the predictions were made under
+            if VERBOSE:
+                print("arithmetic contract:", doc["arithmetic_contract"])
             stages.mark("key_frame.dat + entropy.dat")
         finally:
             ctx.close()
@@ -389,5 +392,8 @@ def _run_sharded(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THR
             key, _ = ctx.rollout(origine_img, PREPROCESS, None, THRESHOLD)
             payload, table, _ = ctx.encode(MODE, BOUND_VALUE, ENTROPY_RUN, shuffle=SHUFFLE)
         write_outputs(OUTPUT_DIR, origine_img, key, payload, table if ENTROPY_RUN else None, PREPROCESS, SHUFFLE)
+        doc = sidecar.write(OUTPUT_DIR, ctx.get_contract(), wts, hp, wp)   # every rank runs under the same TEZIP_PA / frame size
+        if VERBOSE:
+            print("arithmetic contract:", doc["arithmetic_contract"])
     finally:
         ctx.close()

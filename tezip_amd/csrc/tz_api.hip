@@ -61,7 +61,47 @@ extern "C" int tz_scan_fault_inject(tz_ctx* ctx, unsigned epoch_skew, unsigned p
     return TZ_OK;
 }
 
-extern "C" int tz_version(void) { return 100; }
+extern "C" int tz_version(void) { return 101; }
+
+// What this library was compiled with: "tezip_hip <version> gfx950" and, after "defines:", every diagnostic switch of
+// csrc/ that was on (TZW_ABL produces WRONG results by design; TZW_STAMPS / TZW_LEAD / TZW_ISSUE_AT / TZW_PK change the
+// kernels that are measured).  A library whose string names any of them is a measurement build: bench.py and the test
+// suite refuse it (tezip_amd/_lib.py diagnostic_defines).
+extern "C" const char* tz_build_info(void) {
+    return "tezip_hip 101 gfx950 defines:"
+#ifdef TZW_ABL
+           " TZW_ABL"
+#endif
+#ifdef TZW_STAMPS
+           " TZW_STAMPS"
+#endif
+#ifdef TZW_LEAD
+           " TZW_LEAD"
+#endif
+#ifdef TZW_ISSUE_AT
+           " TZW_ISSUE_AT"
+#endif
+#ifdef TZW_PK
+           " TZW_PK"
+#endif
+        ;
+}
+
+int tz_check_pred_contract(tz_ctx* ctx, const char* who) {
+    const int now = tz_get_contract(ctx);
+    if (ctx->pred_contract && now != ctx->pred_contract)
+        return tz_fail(ctx, TZ_ERR_STATE,
+                       "%s: the resident predictions were made under TZ-PA%d, the contract in force is now TZ-PA%d "
+                       "(tz_set_contract between the rollout and its encode/decode): roll out again",
+                       who, ctx->pred_contract, now);
+    return TZ_OK;
+}
+
+extern "C" int tz_rollout_contract(tz_ctx* ctx) {
+    if (!ctx) return TZ_ERR_INVALID;
+    if (!ctx->have_rollout) return tz_fail(ctx, TZ_ERR_STATE, "no rollout in this context");
+    return ctx->pred_contract;
+}
 
 extern "C" const char* tz_strerror(int s) {
     switch (s) {
@@ -1057,6 +1097,7 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
         ctx->group_first = gfirst;
         ctx->quant_skip = qskip;
         ctx->have_rollout = true;
+        ctx->pred_contract = tz_get_contract(ctx);
         ctx->rollout_is_decode = false;
         if (key_mask) memcpy(key_mask, key.data(), nt);
         if (mse_log) memcpy(mse_log, mse.data(), sizeof(double) * nt);
@@ -1128,6 +1169,7 @@ extern "C" int tz_rollout_decode(tz_ctx* ctx, const uint8_t* key_frames, int nt,
     if (rc == TZ_OK) {
         ctx->key_mask = recon_key;
         ctx->have_rollout = true;
+        ctx->pred_contract = tz_get_contract(ctx);
         ctx->rollout_is_decode = true;
         if (key_mask)
             for (int i = 0; i < nt; ++i) key_mask[i] = flags[i] ? 1 : 0;
@@ -1257,6 +1299,7 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
                          int* table_len, int16_t* delta_out) {
     if (!ctx || !table_len || ((entropy & 1) && !table)) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode needs a tz_rollout first");
+    TZ_TRY(tz_check_pred_contract(ctx, "tz_encode"));
     ctx->enc_pending = false;
     if (!payload) {  // keep the payload in the context: it leaves through tz_payload_get
         const size_t n = (size_t)ctx->nt * ctx->H * ctx->W * 3;
@@ -1328,6 +1371,7 @@ extern "C" int tz_encode_begin(tz_ctx* ctx, int mode, double b0, double b1, int 
                                int16_t* edge) {
     if (!ctx || !edge || (entropy && !hist)) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode_begin needs a tz_rollout first");
+    TZ_TRY(tz_check_pred_contract(ctx, "tz_encode_begin"));
     if (mode < 0 || mode > 3) return tz_fail(ctx, TZ_ERR_INVALID, "unknown error-bound mode %d", mode);
     ctx->enc_pending = false;
     const size_t N = (size_t)ctx->nt * ctx->H * ctx->W * 3;
@@ -1428,6 +1472,7 @@ extern "C" int tz_byte_unshuffle(tz_ctx* ctx, const uint8_t* in, size_t n, int16
 extern "C" int tz_encode_delta(tz_ctx* ctx, int mode, double b0, double b1, int16_t* delta_out) {
     if (!ctx || !delta_out) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode_delta needs a tz_rollout first");
+    TZ_TRY(tz_check_pred_contract(ctx, "tz_encode_delta"));
     const int nt = ctx->nt, H = ctx->H, W = ctx->W;
     const size_t N = (size_t)nt * H * W * 3;
     std::vector<tz_out> outs;
@@ -1447,6 +1492,7 @@ extern "C" int tz_encode_delta(tz_ctx* ctx, int mode, double b0, double b1, int1
 extern "C" int tz_decode_delta(tz_ctx* ctx, const int16_t* delta, uint8_t* frames_out) {
     if (!ctx || !delta || !frames_out) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || !ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_decode_delta needs a tz_rollout_decode first");
+    TZ_TRY(tz_check_pred_contract(ctx, "tz_decode_delta"));
     const int nt = ctx->nt, H = ctx->H, W = ctx->W;
     const size_t N = (size_t)nt * H * W * 3;
     std::vector<tz_out> outs;
@@ -1470,6 +1516,7 @@ extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, size_t payload_len
                          uint8_t* frames_out) {
     if (!ctx) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || !ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_decode needs a tz_rollout_decode first");
+    TZ_TRY(tz_check_pred_contract(ctx, "tz_decode"));
     if (table_len > TZ_NBINS || (table_len >= 0 && !table && table_len > 0)) return tz_fail(ctx, TZ_ERR_INVALID, "bad table");
     const int nt = ctx->nt, H = ctx->H, W = ctx->W;
     const size_t N = (size_t)nt * H * W * 3;

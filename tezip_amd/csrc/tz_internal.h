@@ -67,6 +67,8 @@ struct tz_ctx {
     std::vector<uint8_t> group_first; // nt: 1 where a group starts (delta slot 0 -> 0)
     std::vector<uint8_t> quant_skip;  // nt: 1 where error_bound is not applied
     bool have_rollout = false, rollout_is_decode = false;
+    int pred_contract = 0;            // the arithmetic contract that produced the resident prediction stack (stamped by
+                                      // tz_rollout / tz_rollout_decode; tz_encode* / tz_decode* refuse a flip in between)
     // pinned staging ring for small host->device uploads (index arrays, masks, LUTs): the copy
     // out of it is truly asynchronous and the memory outlives the caller's locals
     uint8_t* ring = nullptr;
@@ -117,6 +119,8 @@ struct tz_ctx {
 };
 
 int tz_fail(tz_ctx* ctx, int status, const char* fmt, ...);
+// TZ_ERR_STATE when the contract in force is no longer the one the resident prediction stack was made under
+int tz_check_pred_contract(tz_ctx* ctx, const char* who);
 static constexpr unsigned TZ_FAULT_SCAN_POLL = 1u;   // k_scan2p: a status word never showed the launch's epoch
 int tz_fault_word(tz_ctx* ctx);      // makes the fault word on first use
 int tz_stream_sync(tz_ctx* ctx);     // hipStreamSynchronize(ctx->stream) + TZ_ERR_HIP if a kernel reported a fault

@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-from . import _lib, zstd
+from . import _lib, sidecar, zstd
 from . import dist as tzdist
 from .compress import SHUFFLE_MARK, make_context, open_model
 from .data_utils import padding_shape
@@ -48,7 +48,21 @@ def check_stream(shape, warm_up, payload_len, key_len):
 TAIL_ELEMS = _lib.TZ_NBINS + 8  # the longest trailer: table (<= 2111 symbols) + T + shape(5) + warm_up
 
 
-def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shape, VERBOSE, device):
+def adopt_contract(DATA_DIR, wts, VERBOSE):
+    """The arithmetic contract this directory must be decoded under (tezip_amd/sidecar.py): the one tezip_amd.json
+    records; without that file --pa / TEZIP_PA, else None = by frame size.  A contradiction ends the run like the
+    reference's own input errors do (message + exit)."""
+    try:
+        contract = sidecar.resolve(sidecar.read(DATA_DIR), wts)
+    except sidecar.SidecarMismatch as e:
+        print("ERROR:", e)
+        exit()
+    if VERBOSE and contract:
+        print("arithmetic contract: TZ-PA%d" % contract)
+    return contract
+
+
+def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shape, VERBOSE, device, contract=None):
     """decompress.py:87-279 with nothing of size nt*H*W on the host: entropy.dat is decompressed
     piece by piece straight into HBM (the trailer is read from the last piece), key_frame.dat
     likewise, the decoded frames come back window by window and are PNG-encoded on a thread pool
@@ -65,6 +79,8 @@ def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shap
     ctx = _lib.Context(device)
     try:
         ctx.load_model(cfg, wts)
+        if contract:
+            ctx.set_contract(contract)
         tail = np.zeros(0, np.int16)
         total = off = 0
         with open(paths["entropy.dat"], "rb") as f:
@@ -173,8 +189,9 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
         isRGB = bool(int(file_names.pop(0)))
 
     cfg, wts, model_shape = open_model(WEIGHTS_DIR)
+    contract = adopt_contract(DATA_DIR, wts, VERBOSE)
     if job is None and not os.environ.get("TEZIP_NO_STREAMING"):
-        done = _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shape, VERBOSE, device)
+        done = _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shape, VERBOSE, device, contract)
         if done:
             return
 
@@ -207,6 +224,8 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
         device = tzdist.init_from_env()
     ctx = make_context(cfg, wts, hp, wp, 64 if nt > 64 else max(1, nt), device)
     try:
+        if contract:
+            ctx.set_contract(contract)
         if shape[0] == SHUFFLE_MARK:  # this build's opt-in byte planes -> the int16 payload
             payload = ctx.byte_unshuffle(np.ascontiguousarray(payload).view(np.uint8))
         if job:

@@ -109,9 +109,10 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOWS, MODE, BOUND_VALU
     job = tzdist.active()
     if job:
         device = tzdist.init_from_env()
-    ctx, ctx_error = None, None
+    ctx, ctx_error, contract = None, None, None
     try:
         ctx = make_context(cfg, wts, hp, wp, 1, device)
+        contract = ctx.get_contract()   # TEZIP_PA / the frame size: the same on every rank and for every candidate
     except Exception as e:  # the other ranks are on their way into a collective: tell them there
         ctx_error = e
     try:
@@ -149,6 +150,8 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOWS, MODE, BOUND_VALU
             f.write(f"{int(is_rgb)}\n")
             for name in files:
                 f.write("%s\n" % name)
+        from . import sidecar
+        sidecar.write(OUTPUT_DIR, contract, wts, hp, wp)
         raw = nt * H * W * (3 if is_rgb else 1)
         with open(os.path.join(OUTPUT_DIR, "sweep.txt"), "w") as f:
             for r in rows:
