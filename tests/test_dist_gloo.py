@@ -121,11 +121,10 @@ class OracleContext:
         return payload, table, None
 
 
-def _case():
+def _case(nt=14, h=13, w=19):
     import fake_predictor
     from oracle import oracle as O
     rng = np.random.default_rng(21)
-    nt, h, w = 14, 13, 19
     yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
     frames = np.stack([np.clip(np.stack([120 + 60 * np.sin((xx + 2 * t) / 5.0), 90 + 40 * np.cos((yy - t) / 4.0),
                                          128 + 0.0 * xx], -1) + rng.normal(0, 3, (h, w, 3)), 0, 255).astype(np.uint8)
@@ -306,3 +305,59 @@ def test_sweep_sharded_equals_single_process(world, windows, p, mode, bound):
 def test_sweep_failure_on_one_rank_stops_every_rank(world, fail_on_window):
     import torch.multiprocessing as mp
     mp.spawn(_sweep_worker, args=(world, _free_port(), (2, 3, 4, 5, 7), 0, "abs", [0.0], fail_on_window), nprocs=world, join=True)
+
+
+def _rank_local_worker(rank, world, port, nt, window, mode, bound):
+    """A rank is handed a FETCH callable instead of the stack (what the sharded CLI does with the image files): it must
+    ask for its own frame range and nothing else, and with gather=False the decoder gives every rank its own frames."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), os.path.join(here, "golden")]
+    import torch.distributed as dist
+    from oracle import oracle as O
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        frames, pred = _case(nt, 16, 16)
+        frames = np.repeat(frames[..., :1], 3, axis=-1)          # cfg4's detector frames are 'L' expanded to RGB
+        shards = tzdist.plan_shards(nt, 0, window, world)
+        asked = []
+
+        def fetch(a, b):
+            asked.append((a, b))
+            return frames[a:b]
+
+        eng = OracleEngine(pred)
+        res = tzdist.compress_sharded(eng, fetch, 0, window, mode, bound, True, nt=nt)
+        f0, f1 = shards[rank]
+        assert asked == ([(f0, f1)] if f1 > f0 else []), (rank, asked, shards)
+        ref = O.compress_oracle(frames, 0, window, None, mode, bound, pred, True)
+        ref_payload, ref_table, _, _ = O.parse_stream(ref["stream"])
+        if rank == 0:
+            payload, table, key = res
+            assert (key == ref["key"]).all() and (payload == ref_payload).all() and (table == ref_table).all()
+        else:
+            assert res is None
+        a, b, mine = tzdist.decompress_sharded(eng, ref["key_frame"].reshape(frames.shape), ref_payload, ref_table, 0,
+                                               gather=False)
+        whole = O.decode_stream(ref["stream"], ref["key_frame"], pred)
+        assert mine.shape == (b - a,) + frames.shape[1:] and (mine == whole[a:b]).all()
+        # the ranks' ranges tile the sequence: together they hold every frame once
+        spans = [None] * world
+        dist.all_gather_object(spans, (a, b))
+        used = [s for s in spans if s[1] > s[0]]
+        assert used[0][0] == 0 and used[-1][1] == nt and all(x[1] == y[0] for x, y in zip(used, used[1:]))
+        if nt // window >= world:
+            assert len(used) == world
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nt,window,mode,bound", [
+    (32, 4, "abs", [2.0]),     # 8 windows on 8 ranks: one window per rank, the split BASELINE.json configs[3] names
+    (20, 4, "abs", [0.0]),     # 5 windows on 8 ranks: three ranks hold nothing and still take part in every collective
+])
+def test_world_8_one_window_per_rank(nt, window, mode, bound):
+    """World size 8 (north_star: 'one window per GPU'; /root/reference has no counterpart) on gloo: byte
+    identical to one process, every rank touching its own frames only."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rank_local_worker, args=(8, _free_port(), nt, window, mode, bound), nprocs=8, join=True)

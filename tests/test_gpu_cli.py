@@ -120,17 +120,33 @@ def test_cli_under_torchrun_shards_windows_and_writes_identical_files(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
-        env = dict(os.environ, TEZIP_DIST_BACKEND="gloo", TEZIP_SINGLE_DEVICE="1")
+        env = dict(os.environ, TEZIP_DIST_BACKEND="gloo", TEZIP_SINGLE_DEVICE="1", TEZIP_IO_LOG=str(iolog))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", str(port), "-m", "tezip_amd.tezip"] + args
         r = subprocess.run(cmd, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
+    def ranges(what, rank):
+        return [tuple(int(v) for v in r.split(":")) for r in open(iolog / ("%s.rank%d" % (what, rank))).read().split()]
+
+    iolog = tmp_path / "iolog"
+    iolog.mkdir()
     torchrun(["-c", mdir, ddir, two, "-p", "1", "-w", "4", "-m", "abs", "-b", "2"])
     for name in ("filename.txt", "key_frame.dat", "entropy.dat"):
         assert open(os.path.join(one, name), "rb").read() == open(os.path.join(two, name), "rb").read(), name
+    # rank-local I/O (compress.py:97-122 is one loop over every file): a rank decodes the images of its own windows,
+    # rank 0 in addition the key frames of the other rank's windows (one file per window) for key_frame.dat
+    from tezip_amd import dist as tzdist
+    (a0, b0), (a1, b1) = tzdist.plan_shards(nt, 1, 4, 2)
+    assert (a0, b0, b1) == (0, a1, nt) and 0 < a1 < nt
+    assert ranges("compress", 1) == [(a1, b1)]
+    r0 = ranges("compress", 0)
+    assert r0[0] == (a0, b0) and all(b - a == 1 and a >= a1 for a, b in r0[1:]) and len(r0) - 1 <= (b1 - a1 + 3) // 4 + 1
     torchrun(["-u", mdir, two, out2])
+    # ... and writes the images of its own key intervals (decompress.py:266-279), nothing gathered on rank 0
+    w0, w1 = ranges("decompress", 0), ranges("decompress", 1)
+    assert len(w0) == len(w1) == 1 and w0[0][0] == 0 and w0[0][1] == w1[0][0] and w1[0][1] == nt and 0 < w0[0][1] < nt
     got = np.stack([np.array(Image.open(os.path.join(out2, "frame_%03d.png" % t))) for t in range(nt)])
     assert np.abs(got.astype(int) - frames.astype(int)).max() <= 3
     udir = str(tmp_path / "out1")

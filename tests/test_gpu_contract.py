@@ -42,7 +42,7 @@ def job(tmp_path, monkeypatch):
     cdir = str(tmp_path / "comp")
     args = tezip.build_parser().parse_args(["-c", mdir, ddir, cdir, "-p", "0", "-w", "3", "-m", "abs", "-b", "0", "--pa", "2"])
     tezip.main(args)
-    monkeypatch.delenv("TEZIP_PA", raising=False)      # tezip.main exported it for the contexts of that run
+    assert "TEZIP_PA" not in os.environ                 # --pa lives for the run only (tezip.main puts the variable back)
     return dict(frames=frames, mdir=mdir, cdir=cdir, nt=nt, tmp=tmp_path)
 
 

@@ -339,13 +339,45 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
             ctx.close()
 
 
+class _NotImages(Exception):
+    """A rank met a file that is not an image of the stack's size and mode (the reference's message, compress.py:124-131)."""
+
+
+def _decode_list(src, indices, pool):
+    """The frames `indices` of a FrameSource as one uint8 (len, H, W, 3) array, decoded on `pool`."""
+    indices = list(indices)
+    out = np.empty((len(indices), src.H, src.W, 3), np.uint8)
+    futs = [pool.submit(src._decode_into, out[j], src.paths[i]) for j, i in enumerate(indices)]
+    try:
+        for ft in futs:
+            ft.result()
+    except src.errors:
+        raise _NotImages(src.data_dir)
+    return out
+
+
+def pack_outputs_from_keys(nt, H, W, key, key_frames, payload, table, warm_up, shuffled=False):
+    """pack_outputs for a caller that holds only the key frames: `key_frames` maps frame index -> uint8 (H, W, 3)."""
+    stack = np.zeros((nt, H, W, 3), np.uint8)
+    for i in np.nonzero(key)[0]:
+        stack[i] = key_frames[int(i)]
+    key_bytes = zstd.compress_array(stack, 9, zstd.default_threads())
+    stream = build_stream(payload, table, (SHUFFLE_MARK if shuffled else 1, nt, H, W, 3), warm_up)
+    return key_bytes, zstd.compress_array(stream, 9, zstd.default_threads())
+
+
 def _run_sharded(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, MODE, BOUND_VALUE, VERBOSE,
                  ENTROPY_RUN, device, SHUFFLE):
-    rank0 = tzdist.active()[0] == 0
+    """Under torch.distributed.run.  SWP: the windows are sharded over the ranks and so is the image I/O -- every rank
+    lists the directory (names only) and decodes the files of ITS frame range, nothing else (compress.py:97-122 decodes
+    every file in one loop); rank 0 additionally reads the few key frames key_frame.dat needs and writes the files.
+    DWP does not shard (its windows are found sequentially): rank 0 runs it alone."""
+    job = tzdist.active()
+    rank0 = job[0] == 0
     if rank0 and not os.path.exists(OUTPUT_DIR):
         os.mkdir(OUTPUT_DIR)
-    origine_img, files, isRGB = load_images(DATA_DIR)
-    nt, H, W = origine_img.shape[:3]
+    src = FrameSource(DATA_DIR)          # lists, probes the first image (mode, size): same messages as load_images
+    nt, H, W, files, isRGB = src.nt, src.H, src.W, src.files, src.is_rgb
     cfg, wts, model_shape = open_model(WEIGHTS_DIR)
     hp, wp = padding_shape(H, W)
     if model_shape is not None and (model_shape[0] != hp or model_shape[1] != wp):
@@ -364,9 +396,8 @@ def _run_sharded(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THR
             f.write(f"{int(isRGB)}\n")
             for file_name in files:
                 f.write("%s\n" % file_name)
-    job = tzdist.active()
     if WINDOW_SIZE is None:
-        if job[0] == 0:
+        if rank0:
             print("NOTE: DWP (-t) finds its windows sequentially and does not shard: running on rank 0 only.")
         else:
             return
@@ -378,22 +409,68 @@ def _run_sharded(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THR
     else:
         nwin = 1
     ctx = make_context(cfg, wts, hp, wp, min(nwin, 64), device)
+    decoded = []          # (f0, f1) ranges this rank decoded: tests read it through TEZIP_IO_LOG
     try:
-        if job:
-            # frame windows sharded over the ranks (tezip_amd/dist.py); rank 0 writes the files
-            res = tzdist.compress_sharded(tzdist.HipEngine(ctx, device), origine_img, PREPROCESS, WINDOW_SIZE, MODE,
-                                          BOUND_VALUE, ENTROPY_RUN)
+        with ThreadPoolExecutor(max_workers=io_threads()) as pool:
+            own = {}
+
+            def fetch(f0, f1):
+                decoded.append((f0, f1))
+                own["f0"], own["frames"] = f0, _decode_list(src, range(f0, f1), pool)
+                return own["frames"]
+
+            try:
+                if job:
+                    res = tzdist.compress_sharded(tzdist.HipEngine(ctx, device), fetch, PREPROCESS, WINDOW_SIZE, MODE,
+                                                  BOUND_VALUE, ENTROPY_RUN, nt=nt)
+                else:
+                    frames = fetch(0, nt)
+                    key, _ = ctx.rollout(frames, PREPROCESS, None, THRESHOLD)
+                    payload, table, _ = ctx.encode(MODE, BOUND_VALUE, ENTROPY_RUN, shuffle=SHUFFLE)
+                    res = (payload, table, key)
+            except _NotImages:
+                src.fail()
             if res is None:
                 return
             payload, table, key = res
-            if SHUFFLE:
+            if job and SHUFFLE:
                 payload = ctx.byte_shuffle(np.ascontiguousarray(payload)).view(np.int16)
-        else:
-            key, _ = ctx.rollout(origine_img, PREPROCESS, None, THRESHOLD)
-            payload, table, _ = ctx.encode(MODE, BOUND_VALUE, ENTROPY_RUN, shuffle=SHUFFLE)
-        write_outputs(OUTPUT_DIR, origine_img, key, payload, table if ENTROPY_RUN else None, PREPROCESS, SHUFFLE)
+            # key_frame.dat (compress.py:271-278): the key frames of rank 0's own range are in memory, the others -- one
+            # per window -- are read from their files here
+            f0 = own.get("f0", 0)
+            have = own.get("frames")
+            key_frames = {}
+            missing = []
+            for i in (int(v) for v in np.nonzero(key)[0]):
+                if have is not None and f0 <= i < f0 + len(have):
+                    key_frames[i] = have[i - f0]
+                else:
+                    missing.append(i)
+            try:
+                for i, arr in zip(missing, _decode_list(src, missing, pool)):
+                    key_frames[i] = arr
+                decoded.extend((i, i + 1) for i in missing)
+            except _NotImages:
+                src.fail()
+        key_bytes, entropy_bytes = pack_outputs_from_keys(nt, H, W, key, key_frames, payload, table if ENTROPY_RUN else None,
+                                                          PREPROCESS, SHUFFLE)
+        with open(os.path.join(OUTPUT_DIR, "key_frame.dat"), mode='wb') as f:
+            f.write(key_bytes)
+        with open(os.path.join(OUTPUT_DIR, "entropy.dat"), mode='wb') as f:
+            f.write(entropy_bytes)
         doc = sidecar.write(OUTPUT_DIR, ctx.get_contract(), wts, hp, wp)   # every rank runs under the same TEZIP_PA / frame size
         if VERBOSE:
             print("arithmetic contract:", doc["arithmetic_contract"])
     finally:
+        _log_io("compress", job, decoded)
         ctx.close()
+
+
+def _log_io(what, job, ranges):
+    """TEZIP_IO_LOG=<dir>: every rank leaves `<what>.rank<r>` with the frame ranges it decoded / encoded (tests assert
+    that a rank of a sharded job touches the files of its own windows only)."""
+    d = os.environ.get("TEZIP_IO_LOG")
+    if d:
+        rank = job[0] if job else 0
+        with open(os.path.join(d, "%s.rank%d" % (what, rank)), "w") as f:
+            f.write(" ".join("%d:%d" % r for r in ranges) + "\n")

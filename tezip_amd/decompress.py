@@ -223,16 +223,16 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
     if job:
         device = tzdist.init_from_env()
     ctx = make_context(cfg, wts, hp, wp, 64 if nt > 64 else max(1, nt), device)
+    first = 0           # index of frames[0] in the sequence: a rank of a sharded job holds (and saves) its own windows only
     try:
         if contract:
             ctx.set_contract(contract)
         if shape[0] == SHUFFLE_MARK:  # this build's opt-in byte planes -> the int16 payload
             payload = ctx.byte_unshuffle(np.ascontiguousarray(payload).view(np.uint8))
         if job:
-            # key intervals sharded over the ranks (tezip_amd/dist.py); rank 0 saves the images
-            frames = tzdist.decompress_sharded(tzdist.HipEngine(ctx, device), key_frames, payload, table, warm_up)
-            if frames is None:
-                return
+            # key intervals sharded over the ranks (tezip_amd/dist.py); no frame travels: each rank saves its own
+            first, _, frames = tzdist.decompress_sharded(tzdist.HipEngine(ctx, device), key_frames, payload, table, warm_up,
+                                                         gather=False)
         else:
             if VERBOSE:
                 ctx.prof_enable(True)
@@ -251,12 +251,31 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
 
     from concurrent.futures import ThreadPoolExecutor
     from PIL import Image
-    from .compress import io_threads
-    print("save as RGB" if isRGB else "save as gray")
+    from .compress import _log_io, io_threads
+    if rank0:
+        print("save as RGB" if isRGB else "save as gray")
 
     def save(j):
         # decompress.py:272-278: the grayscale save is overwritten by an unconditional RGB save
-        Image.fromarray(frames[j]).save(os.path.join(OUTPUT_DIR, file_names[j]))
+        Image.fromarray(frames[j]).save(os.path.join(OUTPUT_DIR, file_names[first + j]))
 
+    if job:
+        # the output directory was made by rank 0 before anything else; the ranks meet once more so that none returns
+        # (and the launcher none reports success) before every file is written -- or learns that a rank could not
+        import torch.distributed as dist
+        err = None
+        try:
+            with ThreadPoolExecutor(max_workers=io_threads()) as pool:
+                list(pool.map(save, range(len(frames))))
+        except Exception as e:
+            err = e
+        _log_io("decompress", job, [(first, first + len(frames))])
+        try:
+            tzdist._all_ok(err is None, dist, "writing the decoded images")
+        except RuntimeError:
+            if err is not None:
+                raise err
+            raise
+        return
     with ThreadPoolExecutor(max_workers=io_threads()) as pool:  # PIL's encoder releases the GIL
         list(pool.map(save, range(nt)))

@@ -403,9 +403,12 @@ def plan_decode_shards(keys, nt, warm_up, world):
     return [(cuts[i], cuts[i + 1]) for i in range(used)] + [(nt, nt)] * (world - used)
 
 
-def decompress_sharded(engine, key_frames, payload, table, warm_up, to_host=True):
+def decompress_sharded(engine, key_frames, payload, table, warm_up, to_host=True, gather=True):
     """Sharded decode: every rank passes the same key-frame stack, payload and table; rank 0
-    gets the (nt, H, W, 3) uint8 frames, other ranks None."""
+    gets the (nt, H, W, 3) uint8 frames, other ranks None.
+    gather=False: nothing is sent to rank 0 -- every rank gets (f0, f1, its own (f1-f0, H, W, 3) uint8 frames on the
+    host), so that each rank can write the image files of its own windows (decompress.py:266-279 is one loop over all
+    frames; PNG files are independent)."""
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
     nt, H, W, C = key_frames.shape
@@ -459,6 +462,11 @@ def decompress_sharded(engine, key_frames, payload, table, warm_up, to_host=True
         if err is not None:
             raise err
         raise
+    if not gather:
+        if f1 == f0:
+            return f0, f1, np.zeros((0, H, W, C), np.uint8)
+        local = engine.host(frames) if hasattr(engine, "host") else np.asarray(frames)
+        return f0, f1, np.asarray(local, np.uint8).reshape(f1 - f0, H, W, C)
     full = _gather_shards(engine, frames, [(b - a) * fe for a, b in shards], dist)
     if rank != 0:
         return None

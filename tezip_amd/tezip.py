@@ -107,12 +107,10 @@ def check_compress(arg):
     return None
 
 
-def main(arg):
+def _main(arg):
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # launched by torch.distributed.run: one rank per GPU
         from . import dist as tzdist
         tzdist.init_from_env()
-    if getattr(arg, "pa", None) is not None:
-        os.environ["TEZIP_PA"] = str(arg.pa)   # every context of this process starts with it (tz_ctx_create)
     gpu = probe_gpu(arg.force)
     print("GPU MODE" if gpu else "CPU MODE")
     chosen = [name for name in ("learn", "compress", "uncompress") if getattr(arg, name) is not None]
@@ -140,6 +138,22 @@ def main(arg):
     threshold = arg.threshold[0] if arg.threshold is not None else None
     return compress.run(model, src, dst, arg.preprocess[0], window, threshold, arg.mode[0], arg.bound, gpu,
                         arg.verbose, arg.no_entropy, SHUFFLE=arg.shuffle)
+
+
+def main(arg):
+    """--pa travels to the library as TEZIP_PA (every context made during this run starts with it: tz_ctx_create); the
+    variable is put back when the run ends, so that a caller that drives main() in-process is left as it was."""
+    if getattr(arg, "pa", None) is None:
+        return _main(arg)
+    before = os.environ.get("TEZIP_PA")
+    os.environ["TEZIP_PA"] = str(arg.pa)
+    try:
+        return _main(arg)
+    finally:
+        if before is None:
+            os.environ.pop("TEZIP_PA", None)
+        else:
+            os.environ["TEZIP_PA"] = before
 
 
 if __name__ == "__main__":
