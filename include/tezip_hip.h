@@ -80,8 +80,11 @@ int tz_model_load(tz_ctx* ctx, int nb_layers, const int* stack_sizes, const int*
  * activations and evaluates everything that does not depend on the input (t=0 states).
  * Hp, Wp: multiples of 8 and of 2^(levels-1) (compress.py:178-181: "Image size is out of scope").
  * TZ_ERR_UNSUPPORTED when a level's widest per-frame plane (gate columns / error maps) would
- * reach 2^30 floats: the kernels address inside one frame's plane with 32-bit offsets (the
- * reference's model: up to ~44 M pixels a frame; frames and batch items are 64-bit strides). */
+ * reach 2^30 floats: the kernels address inside one frame's plane with 32-bit offsets (frames and
+ * batch items are 64-bit strides).  Which level binds depends on the model: for the reference's
+ * (3,48,96,192) it is level 1's 192 gate columns, i.e. frames up to ~22.3 M pixels (4096 x 4096
+ * passes, 8192 x 8192 does not); the error text names the model's limit.  A deviation: the
+ * reference's frame size is bounded by memory only. */
 int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch);
 /* X_hat[0,0] of predict((1,2,Hp,Wp,3)) (compress.py:197): input independent. out: Hp*Wp*3 f32 */
 int tz_predict_c0(tz_ctx* ctx, float* out);
@@ -166,6 +169,16 @@ int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t*
  * fetched in pieces of `count` int16 elements starting at `offset` (compress.py:375-400 appends and
  * compresses one monolithic array). */
 int tz_payload_get(tz_ctx* ctx, size_t offset, size_t count, int16_t* out);
+/* Deferred hand-over of the payload (a caller that compresses one sequence after the other; compress.py:375-400 is one
+ * blocking pass per job).  With tz_set_payload_deferred(ctx, 1) a tz_encode whose `payload` is PINNED host memory
+ * (tz_host_alloc) and whose entropy bit is set returns as soon as the last chunk of the payload is queued on the copy
+ * stream: table and *table_len are final, the payload buffer is complete only after tz_payload_wait -- the device -> host
+ * transfer (2.4 ms for a cfg3 sequence) then runs under the next sequence's tz_rollout instead of in front of it.  At
+ * most one transfer is in flight: the next tz_encode orders its own remap behind it, so a caller alternates between two
+ * host buffers and calls tz_payload_wait (free by then) before it reads the older one.  Every other form of tz_encode,
+ * tz_ctx_synchronize and tz_ctx_destroy settle a transfer in flight first. */
+int tz_set_payload_deferred(tz_ctx* ctx, int on);
+int tz_payload_wait(tz_ctx* ctx);
 /* First stage of tz_encode only (compress.py:292-319): delta + error-bound quantisation of the
  * context-resident rollout -> int16 delta stack nt*H*W*3.  Used when frame windows are sharded
  * over GPUs: the spatial delta and the histogram then need a carry / a sum across shards

@@ -103,3 +103,46 @@ def test_k_wino_stage_bodies_move_no_register_behind_an_asm_read(tmp_path):
             assert not bad, (m.group(1), bad[:8])
             assert all("a[" in i.split(",")[0] for i in b if i.startswith("v_mfma")), m.group(1)   # accumulators in AGPRs, in place
     assert seen >= 6   # LSTM / RAW with and without an upsampled source, pool + error with 3 and 4 column tiles
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="no ROCm LLVM tools")
+def test_k_wino_reads_no_accumulator_in_the_shadow_of_an_mfma(tmp_path):
+    """The other half of the asm-MFMA contract (the guard above covers the stage bodies only): the compiler does
+    not know that the asm MFMAs write the AGPRs it reads in the output transform and in the epilogues, so it inserts no
+    wait states for them -- the kernel does, by hand (`s_nop 15` twice behind each stage loop; a v_mfma_f32_16x16x4_f32
+    needs 8 passes = up to 18 wait states before another unit may read its result).  Statically, in the code object just
+    built: walking back from EVERY instruction of a k_wino function that reads an AGPR and is not itself an MFMA, at least
+    18 wait states of instructions (s_nop N counts N + 1) lie between it and the nearest MFMA in program order."""
+    if not os.path.exists(OBJ):
+        from tezip_amd import build
+        build.build()
+    work = tmp_path / "co"
+    work.mkdir()
+    shutil.copy(OBJ, work / "k.o")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objdump"), "--offloading", "k.o"], cwd=work, stdout=subprocess.DEVNULL)
+    co = [f for f in os.listdir(work) if "amdgcn" in f]
+    text = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co[0]], cwd=work, text=True)
+    NEED = 18
+    seen = readers = 0
+    for fn in re.split(r"\n(?=[0-9a-f]+ <)", text):
+        m = re.match(r"[0-9a-f]+ <([^>]+)>:", fn)
+        if not m or "k_wino" not in m.group(1) or "k_wino_ref" in m.group(1):
+            continue
+        seen += 1
+        body = [l.split("//")[0].strip() for l in fn.splitlines()[1:] if l.strip()]
+        for i, ins in enumerate(body):
+            if ins.startswith("v_mfma") or not re.search(r"\ba(\d+|\[\d+:\d+\])", ins.split(" ", 1)[1] if " " in ins else ""):
+                continue
+            ops = ins.split(" ", 1)[1].split(",")
+            srcs = ops[1:] if ins.startswith(("v_accvgpr_read", "v_")) else ops   # (stores / ds_write: every operand is a source)
+            if not any(re.search(r"\ba(\d+|\[\d+:\d+\])", o) for o in srcs):
+                continue
+            readers += 1
+            waited, j = 0, i - 1
+            while j >= 0 and waited < NEED:
+                prev = body[j]
+                assert not prev.startswith("v_mfma"), (m.group(1), "accumulator read %d wait states behind an MFMA" % waited, body[j:i + 1][:8])
+                nop = re.match(r"s_nop (\d+)", prev)
+                waited += int(nop.group(1)) + 1 if nop else 1
+                j -= 1
+    assert seen >= 6 and readers >= 6 * 96   # every instantiation reads its accumulators somewhere

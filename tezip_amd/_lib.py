@@ -56,6 +56,8 @@ _SIGS = {
     "tz_payload_put": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "tz_decoded_get": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "tz_payload_get": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "tz_set_payload_deferred": (C.c_int, [C.c_void_p, C.c_int]),
+    "tz_payload_wait": (C.c_int, [C.c_void_p]),
     "tz_get_predictions": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tz_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                             C.POINTER(C.c_int), C.c_void_p]),
@@ -458,6 +460,14 @@ class Context:
                                     C.byref(tlen), _ptr(delta)))
         t = table[: tlen.value].copy() if tlen.value >= 0 else None
         return payload, t, delta
+
+    def set_payload_deferred(self, on=True):
+        """tz_set_payload_deferred: encode(payload=<pinned host buffer>) returns with the device -> host transfer of
+        the payload still running; payload_wait() completes it (it overlaps the next sequence's rollout)."""
+        self._ck(self.lib.tz_set_payload_deferred(self.h, int(bool(on))))
+
+    def payload_wait(self):
+        self._ck(self.lib.tz_payload_wait(self.h))
 
     def encode_begin(self, mode, bound, entropy=True):
         """First phase of a window-sharded encode (tz_encode_begin): -> (hist uint64[2111] | None,

@@ -154,6 +154,7 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
     if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_keys, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_frames, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_compute, hipEventDisableTiming) != hipSuccess) {
@@ -184,6 +185,7 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
 extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
     if (!ctx) return TZ_OK;
     (void)hipSetDevice(ctx->device);
+    (void)tz_payload_settle(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     tz_model_free(ctx);
     tz_pool_release_all(ctx);
@@ -192,6 +194,8 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
     if (ctx->d_pred) (void)hipFree(ctx->d_pred);
     if (ctx->d_sched) (void)hipFree(ctx->d_sched);
     if (ctx->d_payload) (void)hipFree(ctx->d_payload);
+    if (ctx->d_payload_stage) (void)hipFree(ctx->d_payload_stage);
+    if (ctx->ev_payload) (void)hipEventDestroy(ctx->ev_payload);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_scan_status) (void)hipFree(ctx->d_scan_status);
     if (ctx->h_fault) (void)hipHostFree((void*)ctx->h_fault);
@@ -204,6 +208,10 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    if (ctx->down_stream) {
+        (void)hipStreamSynchronize(ctx->down_stream);
+        (void)hipStreamDestroy(ctx->down_stream);
     }
     for (int i = 0; i < tz_ctx::kStages; ++i) {
         if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
@@ -228,7 +236,27 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
 
 extern "C" int tz_ctx_synchronize(tz_ctx* ctx) {
     if (!ctx) return TZ_ERR_INVALID;
+    TZ_TRY(tz_payload_settle(ctx));
     return tz_stream_sync(ctx);
+}
+
+int tz_payload_settle(tz_ctx* ctx) {
+    if (!ctx->payload_inflight) return TZ_OK;
+    ctx->payload_inflight = false;
+    TZ_HIP(ctx, hipEventSynchronize(ctx->ev_payload));
+    return TZ_OK;
+}
+
+extern "C" int tz_set_payload_deferred(tz_ctx* ctx, int on) {
+    if (!ctx) return TZ_ERR_INVALID;
+    if (!on) TZ_TRY(tz_payload_settle(ctx));
+    ctx->defer_payload = on ? 1 : 0;
+    return TZ_OK;
+}
+
+extern "C" int tz_payload_wait(tz_ctx* ctx) {
+    if (!ctx) return TZ_ERR_INVALID;
+    return tz_payload_settle(ctx);
 }
 
 extern "C" void* tz_ctx_stream(tz_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -1231,9 +1259,9 @@ static void build_dec_lut(const int16_t* table, int T, int apply_offset, std::ve
 // ------------------------------------------------------------------------ encode / decode
 // Last stage of tz_encode: rank remap (compress.py:369).  A host payload leaves chunk by chunk on
 // the copy stream behind the remap kernel, so that the device -> host transfer overlaps it.
-static int remap_out(tz_ctx* ctx, const int16_t* d_sd, size_t N, const int16_t* lut, tz_out* o) {
+static int remap_out(tz_ctx* ctx, const int16_t* d_sd, size_t N, const int16_t* lut, tz_out* o, bool defer = false) {
     constexpr int kChunks = 8;
-    if (!o->host || N < ((size_t)1 << 22)) return tzk_lut(ctx, d_sd, N, lut, 0, (int16_t*)o->dev);
+    if (!o->host || (N < ((size_t)1 << 22) && !defer)) return tzk_lut(ctx, d_sd, N, lut, 0, (int16_t*)o->dev);
     const size_t per = ((N + kChunks - 1) / kChunks + 7) & ~(size_t)7;
     while (ctx->chunk_ev.size() < (size_t)kChunks) {
         hipEvent_t e;
@@ -1249,10 +1277,16 @@ static int remap_out(tz_ctx* ctx, const int16_t* d_sd, size_t N, const int16_t* 
     k = 0;
     for (size_t off = 0; off < N; off += per, ++k) {
         const size_t n = std::min(per, N - off);
-        TZ_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_ev[k], 0));
-        TZ_TRY(tz_d2h(ctx, (int16_t*)o->host + off, (const int16_t*)o->dev + off, n * 2, ctx->copy_stream));
+        TZ_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, ctx->chunk_ev[k], 0));
+        TZ_TRY(tz_d2h(ctx, (int16_t*)o->host + off, (const int16_t*)o->dev + off, n * 2, ctx->down_stream));
     }
-    TZ_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if (defer) {   // the caller collects the payload with tz_payload_wait: the transfer runs under whatever comes next
+        if (!ctx->ev_payload) TZ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_payload, hipEventDisableTiming));
+        TZ_HIP(ctx, hipEventRecord(ctx->ev_payload, ctx->down_stream));
+        ctx->payload_inflight = true;
+    } else {
+        TZ_HIP(ctx, hipStreamSynchronize(ctx->down_stream));
+    }
     o->done = true;
     return TZ_OK;
 }
@@ -1315,7 +1349,27 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
     std::vector<tz_out> outs;
     tz_out o_pay, o_delta, o_final;
     void *d_hist = nullptr, *d_sd = nullptr, *d_edge = nullptr;
-    int rc = tz_dev_out(ctx, payload, N * 2, &o_pay);
+    // a transfer of the call before may still be reading the staging buffer (and writing the caller's previous host
+    // buffer): it has ~a rollout's time to finish, and must have before this call's remap writes the buffer again
+    int rc = TZ_OK;
+    const bool defer = ctx->defer_payload && entropy && !shuffle && tz_ptr_kind(payload) == 1;
+    if (ctx->payload_inflight) {
+        if (defer) {
+            hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->ev_payload, 0);
+            if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e));
+        } else {
+            rc = tz_payload_settle(ctx);
+        }
+    }
+    if (rc == TZ_OK && defer) {
+        if (ctx->cap_payload_stage < N * 2) rc = tz_payload_settle(ctx);   // (growing frees the old buffer)
+        if (rc == TZ_OK) rc = tz_ensure(ctx, (void**)&ctx->d_payload_stage, &ctx->cap_payload_stage, N * 2);
+        o_pay.bytes = N * 2;
+        o_pay.host = payload;
+        o_pay.dev = ctx->d_payload_stage;
+    } else if (rc == TZ_OK) {
+        rc = tz_dev_out(ctx, payload, N * 2, &o_pay);
+    }
     if (rc == TZ_OK && shuffle) {  // the stages below write the plain payload to a scratch buffer instead
         o_final = o_pay;
         o_pay = tz_out();
@@ -1349,7 +1403,7 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
             ctx->prof[TZP_TABLE].total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             ctx->prof[TZP_TABLE].launches += 1;
         }
-        if (rc == TZ_OK) rc = remap_out(ctx, (const int16_t*)d_sd, N, lut.data(), &o_pay);  // 369
+        if (rc == TZ_OK) rc = remap_out(ctx, (const int16_t*)d_sd, N, lut.data(), &o_pay, defer);  // 369
     }
     if (rc == TZ_OK && shuffle) {
         rc = tzk_shuffle(ctx, (const int16_t*)o_pay.dev, N, (uint8_t*)o_final.dev, 0);

@@ -81,6 +81,8 @@ struct tz_ctx {
     // rollout computes; the payload leaves chunk by chunk behind the remap kernel).  Pinned host
     // memory (tz_host_alloc) is DMA'd directly; pageable memory is pipelined through `stage`.
     hipStream_t copy_stream = nullptr;
+    hipStream_t down_stream = nullptr;   // device -> host leg of the payload hand-over: a stream of its own, so that a deferred
+                                         // transfer (tz_set_payload_deferred) does not sit in front of the next sequence's uploads
     hipEvent_t ev_keys = nullptr, ev_frames = nullptr, ev_compute = nullptr;
     // second compute stream of a static rollout schedule (run_schedule): the windows advance as two independent
     // groups, so that one group's launch fills the CUs the other group's draining launch leaves idle
@@ -112,6 +114,14 @@ struct tz_ctx {
     const uint8_t* pending_src = nullptr;  // host frame stack whose non-key frames are still to be sent
     std::vector<uint8_t> pending_sent;     // nt: 1 = already on its way
     std::vector<hipEvent_t> chunk_ev;  // payload chunk hand-over events (compute -> copy stream)
+    // deferred payload hand-over (tz_set_payload_deferred): tz_encode returns once the last chunk of the payload is QUEUED
+    // on the copy stream; the device -> host transfer then runs under the next sequence's rollout.  The chunks leave from
+    // a staging buffer of the context's own (a pool block would be handed out again by the next call).
+    int defer_payload = 0;
+    bool payload_inflight = false;
+    hipEvent_t ev_payload = nullptr;        // recorded on the copy stream behind the last chunk
+    int16_t* d_payload_stage = nullptr;
+    size_t cap_payload_stage = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool prof_on = false;
@@ -124,6 +134,7 @@ int tz_check_pred_contract(tz_ctx* ctx, const char* who);
 static constexpr unsigned TZ_FAULT_SCAN_POLL = 1u;   // k_scan2p: a status word never showed the launch's epoch
 int tz_fault_word(tz_ctx* ctx);      // makes the fault word on first use
 int tz_stream_sync(tz_ctx* ctx);     // hipStreamSynchronize(ctx->stream) + TZ_ERR_HIP if a kernel reported a fault
+int tz_payload_settle(tz_ctx* ctx);  // waits for a deferred payload transfer still in flight (no-op without one)
 
 #define TZ_HIP(ctx, expr)                                                                      \
     do {                                                                                       \

@@ -21,6 +21,7 @@
 // size, grid shape or device.
 //
 #include <algorithm>
+#include <atomic>
 
 #include "tz_conv_kernels.hip.h"
 #include "tz_wino_kernels.hip.h"
@@ -333,11 +334,14 @@ template <int NT, int EPI, bool UPS>
 static int launch_wino_t(tz_ctx* ctx, const ConvArgs& a0, int nbatch) {
     // (per instantiation and device: the attribute belongs to the function on a device, not to a context; a process that
     // opens contexts on several devices sets it on each)
-    static bool attr_set[64] = {false};
+    // (contexts of several threads may launch at once: the flag is atomic and is set only AFTER the attribute is, so a thread
+    // that reads it set launches with the attribute in place; two threads that both find it clear both set the attribute,
+    // which is idempotent)
+    static std::atomic<bool> attr_set[64];
     const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 63;
-    if (!attr_set[dev] || dev == 63) {
+    if (dev == 63 || !attr_set[dev].load(std::memory_order_acquire)) {
         TZ_HIP(ctx, hipFuncSetAttribute((const void*)k_wino<NT, EPI, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, tzw::LDS_BYTES));
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     // Column blocks per workgroup (one workgroup occupies a CU): the divisor of ncb with the shortest launch in items --
     // rounds of workgroups over the CUs x items per workgroup --, the largest one among equals: a workgroup pays its geometry
@@ -459,8 +463,9 @@ static int launch_conv(tz_ctx* ctx, int NT, int epi, const ConvArgs& a, int nbat
     for (int s = 0; s < a.nsrc; ++s) {
         ups = ups || a.src[s].up;
         fullk = fullk && (a.src[s].C % 16) == 0;
-        // k_conv16 / k_convlat address a source image through 32-bit byte offsets from its base (patch geometry
-        // worked out once per workgroup): a level of 4 GiB or more goes through the general kernel
+        // k_conv16 / k_convlat address a source image through 32-bit byte offsets from its base (patch geometry worked out
+        // once per workgroup).  Defensive only since round 4: tz_model_prepare refuses every frame size whose planes could
+        // reach that (the general kernel has 32-bit plane offsets of its own), so this never selects another path
         const long long hs = a.src[s].up ? a.H >> 1 : a.H, ws = a.src[s].up ? a.W >> 1 : a.W;
         fullk = fullk && hs * ws * a.src[s].pstride * 4 < (1LL << 32);
     }
@@ -625,14 +630,24 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
                        "Image size is out of scope for this model: padded size %dx%d must divide by 8 and 2^(levels-1)", Hp, Wp);
     // The convolution kernels address inside ONE frame's plane of a level with 32-bit offsets (LDS-DMA lane offsets, the
     // accumulator starts, the epilogues' lane offsets); batch items and frames are 64-bit strides.  The largest plane is a
-    // level's gate columns or error maps: keep it under 2^30 floats (4 GiB).  PredNet (3,48,96,192): up to ~44 M pixels a frame.
+    // level's gate columns or error maps: keep it under 2^30 floats (4 GiB).  Which level binds depends on the model; for
+    // PredNet (3,48,96,192) it is level 1 (4 x 48 gate columns at a quarter of the pixels): frames up to ~22.3 M pixels
+    // (4096 x 4096 passes, 8192 x 8192 does not).  A deviation from the reference, whose frame size is bounded by memory
+    // only; there is no 64-bit-offset fallback kernel.
+    long long limit_px = -1;   // this model's largest accepted frame, in level-0 pixels
+    for (int l = 0; l < L; ++l) {
+        const long long widest = std::max<long long>(4LL * m->rstack[l], std::max<long long>(2LL * m->stack[l], 8));
+        const long long lim = (((1LL << 30) - 1) / widest) << (2 * l);
+        if (limit_px < 0 || lim < limit_px) limit_px = lim;
+    }
     for (int l = 0; l < L; ++l) {
         const long long npx = (long long)(Hp >> l) * (Wp >> l);
         const long long widest = std::max<long long>(4LL * m->rstack[l], std::max<long long>(2LL * m->stack[l], 8));
         if (npx * widest >= (1LL << 30))
             return tz_fail(ctx, TZ_ERR_UNSUPPORTED,
-                           "frame of %dx%d pixels: level %d holds %lld floats per frame, the kernels address a frame's plane with 32-bit offsets (< 2^30 floats)",
-                           Hp, Wp, l, npx * widest);
+                           "frame of %dx%d pixels: level %d holds %lld floats per frame, the kernels address a frame's plane with 32-bit "
+                           "offsets (< 2^30 floats); this model accepts frames up to about %lld pixels",
+                           Hp, Wp, l, npx * widest, limit_px);
     }
     if (m->prepared && m->Hp == Hp && m->Wp == Wp && m->maxB >= max_batch) {
         m->cap = max_batch;

@@ -722,6 +722,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
         const f32x4 q0 = xi[0], q1 = xi[64];
         const int yp = (ty0 >> 1) + 4 * (mt >> 1) + g + per_item;
+        if (ty0 + 16 <= a.H && tx0 + 16 <= a.W && (cb + 1) * (16 * NT) <= C && !(TZW_ABL & 512)) {
+            // (uniform) the whole tile inside the image and the whole column block inside the stack: ONE lane offset per
+            // array for the outputs of a lane, uniform steps between them -- scalar base + 32-bit lane offset addressing, no
+            // per-output predicates (what the LSTM epilogue got in round 4; the general form below spends ~25 instructions
+            // per output on 64-bit addresses and exec masks, in a serial section with the matrix pipes idle)
+            const unsigned pix = (unsigned)(yp * W2 + (tx0 >> 1) + 4 * (mt & 1));
+            const unsigned colw = (unsigned)(cb * (16 * NT) + r);
+            const char* ph_ = (const char*)a.aux;
+            char* po = (char*)o;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (ph == 1 && 2 + k >= NT) break;
+                const int t = (ph == 0 ? 0 : 2) + k;
+                const f32x4 mine = ph == 0 ? m[k] : m[(2 + k) % NT], other = k == 0 ? q0 : q1;
+                const unsigned hoff = 4u * (pix * (unsigned)C + colw + 16u * t), ooff = 4u * (pix * 2u * (unsigned)C + colw + 16u * t);
+                float hv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = *(const float*)(ph_ + (size_t)e * C * 4 + hoff);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float mm = other[e] > mine[e] ? other[e] : mine[e];
+                    const float d1 = hv[e] - mm, d2 = mm - hv[e];
+                    *(float*)(po + (size_t)e * C * 8 + ooff) = tz_relu(d1);
+                    *(float*)(po + (size_t)e * C * 8 + (size_t)C * 4 + ooff) = tz_relu(d2);
+                }
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (ph == 1 && 2 + k >= NT) break;               // wave 1 finishes column tiles 2 .. NT - 1, wave 0 tiles 0, 1
