@@ -486,14 +486,23 @@ def main():
                 seq = {"k": 0, "ok": True}
                 ctx.set_payload_deferred(True)
 
+                dbg = [] if os.environ.get("TEZIP_BENCH_DEBUG") else None
+
                 def pstep():
+                    t0 = time.perf_counter()
                     ctx.rollout(hf, WARM_UP, WINDOW)
+                    t1 = time.perf_counter()
                     ctx.payload_wait()                      # (free: the transfer had a whole rollout to finish)
+                    t2 = time.perf_counter()
                     ctx.encode(MODE, BOUND, True, payload=hp2[seq["k"] & 1])
                     seq["k"] += 1
+                    if dbg is not None:
+                        dbg.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
 
                 el = job.timed(pstep, hsteps, 1, drain=ctx.payload_wait)
                 ctx.payload_wait()
+                if dbg:
+                    print("pipelined step (rollout, payload_wait, encode) ms:", [tuple(round(v * 1e3, 2) for v in d) for d in dbg], file=sys.stderr)
                 seq["ok"] = bool((hp2[0] == ref_payload).all() and (hp2[1] == ref_payload).all())
                 h2h["pinned_pipelined_frames_per_s"] = frames.shape[0] * hsteps / el
                 h2h["pinned_pipelined_ms_per_step"] = el / hsteps * 1e3

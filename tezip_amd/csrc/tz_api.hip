@@ -592,6 +592,20 @@ extern "C" int tz_timer_stop(tz_ctx* ctx, float* ms) {
 static int pad8(int v) { return (v + 7) / 8 * 8; }  // data_utils.py:103-107
 
 // decompress.py:123-129: is there a non-zero sample in frame f?  16 bytes per lane where the frame allows it.
+// Key frames of a PINNED host stack, fetched by the compute stream itself (zero-copy reads over PCIe: page-locked host
+// memory is device-addressable): the first predictor step then never waits for a DMA engine that may still be busy with
+// the previous sequence's deferred payload (tz_set_payload_deferred) -- HIP hands streams to SDMA engines as it likes, and
+// a host -> device copy queued behind a 126 MB device -> host transfer starts 2.3 ms late.
+__global__ __launch_bounds__(256) void k_fetch_frames(const uint8_t* __restrict__ host, uint8_t* __restrict__ dev, const int* __restrict__ which,
+                                                      size_t frame_bytes) {
+    const size_t base = (size_t)which[blockIdx.y] * frame_bytes;
+    const size_t n16 = frame_bytes / 16;
+    const uint4* s = (const uint4*)(host + base);
+    uint4* d = (uint4*)(dev + base);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+    if (blockIdx.x == 0 && threadIdx.x < (frame_bytes & 15)) dev[base + n16 * 16 + threadIdx.x] = host[base + n16 * 16 + threadIdx.x];
+}
+
 __global__ void k_any_nonzero(const uint8_t* __restrict__ frames, size_t frame_bytes, int* __restrict__ flags) {
     int f = blockIdx.y;
     const uint8_t* p = frames + (size_t)f * frame_bytes;
@@ -729,13 +743,27 @@ static int rollout_setup(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int 
     TZ_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compute, 0));
     if (first && !first->empty() && (int)first->size() < nt) {
         ctx->pending_sent.assign(nt, 0);
+        // frames at 16-byte-aligned offsets of a pinned stack: the compute stream reads them itself (k_fetch_frames)
+        const bool fetch = tz_ptr_kind(frames) == 1 && fsz % 16 == 0 && ((uintptr_t)frames & 15) == 0 && first->size() <= 4096;
+        std::vector<int> which;
         for (int f : *first) {
             if (f < 0 || f >= nt || ctx->pending_sent[f]) continue;
-            TZ_TRY(tz_h2d(ctx, ctx->d_frames + (size_t)f * fsz, frames + (size_t)f * fsz, fsz, ctx->copy_stream));
+            if (fetch) which.push_back(f);
+            else TZ_TRY(tz_h2d(ctx, ctx->d_frames + (size_t)f * fsz, frames + (size_t)f * fsz, fsz, ctx->copy_stream));
             ctx->pending_sent[f] = 1;
         }
-        TZ_HIP(ctx, hipEventRecord(ctx->ev_keys, ctx->copy_stream));
-        TZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_keys, 0));
+        if (fetch && !which.empty()) {
+            void* d_which;
+            TZ_TRY(tz_pool_alloc(ctx, which.size() * sizeof(int), &d_which));
+            TZ_TRY(tz_upload(ctx, d_which, which.data(), which.size() * sizeof(int)));
+            const unsigned gx = (unsigned)std::min<size_t>((fsz / 16 + 255) / 256, 256);
+            hipLaunchKernelGGL(k_fetch_frames, dim3(gx, (unsigned)which.size()), dim3(256), 0, ctx->stream, frames, ctx->d_frames,
+                               (const int*)d_which, fsz);
+            TZ_HIP(ctx, hipGetLastError());
+        } else {
+            TZ_HIP(ctx, hipEventRecord(ctx->ev_keys, ctx->copy_stream));
+            TZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_keys, 0));
+        }
         ctx->pending_src = frames;
         return TZ_OK;
     }
