@@ -141,8 +141,10 @@ def test_k_wino_reads_no_accumulator_in_the_shadow_of_an_mfma(tmp_path):
             waited, j = 0, i - 1
             while j >= 0 and waited < NEED:
                 prev = body[j]
+                if prev.startswith(("s_branch", "s_endpgm")):   # nothing falls through an unconditional branch: this block is
+                    break                                        # entered by a jump (a loop that runs zero times skips its MFMAs)
                 assert not prev.startswith("v_mfma"), (m.group(1), "accumulator read %d wait states behind an MFMA" % waited, body[j:i + 1][:8])
                 nop = re.match(r"s_nop (\d+)", prev)
                 waited += int(nop.group(1)) + 1 if nop else 1
                 j -= 1
-    assert seen >= 6 and readers >= 6 * 96   # every instantiation reads its accumulators somewhere
+    assert seen >= 7 and readers >= 7 * 96   # every instantiation reads its accumulators somewhere

@@ -145,7 +145,11 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
     } else {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        // (highest dispatch priority: the side launches on stream2 -- lowest -- are there to fill what this stream leaves idle)
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (getenv("TEZIP_PRIO_DEBUG")) fprintf(stderr, "[tezip] stream priority range: least %d greatest %d\n", prio_least, prio_greatest);
+        if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
             delete ctx;
             return TZ_ERR_HIP;
         }
@@ -166,7 +170,13 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
         if (e) ctx->split_rollout = atoi(e);
         e = getenv("TEZIP_DECODE_UNFUSED");
         if (e) ctx->decode_unfused = atoi(e);
-        if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        e = getenv("TEZIP_EPART");
+        if (e) ctx->epart_mode = atoi(e);
+        // stream2 takes work that must not delay the compute stream's (the side launches of "E-part ahead" fill the CUs the
+        // critical path leaves idle): lowest dispatch priority the device offers
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_least) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
             tz_ctx_destroy(ctx);
@@ -221,6 +231,10 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
     if (ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2);
         (void)hipStreamDestroy(ctx->stream2);
+    }
+    for (int l = 0; l < TZ_MAX_LEVELS; ++l) {
+        if (ctx->ev_epart_src[l]) (void)hipEventDestroy(ctx->ev_epart_src[l]);
+        if (ctx->ev_epart_done[l]) (void)hipEventDestroy(ctx->ev_epart_done[l]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);

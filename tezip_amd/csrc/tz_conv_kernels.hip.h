@@ -42,6 +42,8 @@ struct ConvArgs {
     const float* Wlat;  // per-wave fragment image for k_convlat: [slot][column block][4 column tiles][lane][k-step], or null
     const float* Wwino; // TZ-PA2 stage image for k_wino: [column block][stage][16 weight sets][lane][4 column tiles], or null
     int ipw;            // k_wino: column blocks a workgroup does one after the other (divides ncb)
+    int wino_stride;    // k_wino: stages per column block in Wwino when the launch walks only PART of them (0 = all of them)
+    int wino_first;     // ... and the first stage of that part (a launch over the same-resolution phase: 0; over the upsampled one: S1)
     const float* zero;  // >= 16 bytes of zeros: LDS-DMA source of out-of-image patch pixels
     int ncols;
     const float* bias;  // [ncols]

@@ -89,6 +89,10 @@ struct tz_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int split_rollout = 0;            // TEZIP_SPLIT=1 turns it on (measured in round 3: slower, see run_schedule)
+    // "E-part ahead" (round 5, tz_model_predict_batch_dev): per level, E_l ready on the compute stream / the launch over it
+    // finished on stream2
+    hipEvent_t ev_epart_src[TZ_MAX_LEVELS] = {nullptr}, ev_epart_done[TZ_MAX_LEVELS] = {nullptr};
+    int epart_mode = -1;              // TEZIP_EPART: -1 where launches cannot fill the chip (default), 0 never, 1 wherever possible
     static constexpr int kStages = 4;
     static constexpr size_t kStageBytes = (size_t)8 << 20;
     uint8_t* stage[kStages] = {nullptr, nullptr, nullptr, nullptr};

@@ -330,7 +330,7 @@ static void launch_conv16_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
     hipLaunchKernelGGL((k_conv16<NT, EPI, UPS>), dim3(blocks), dim3(NTHR), 0, ctx->stream, a);
 }
 
-template <int NT, int EPI, bool UPS>
+template <int NT, int EPI, bool UPS, bool NOSAME = false>
 static int launch_wino_t(tz_ctx* ctx, const ConvArgs& a0, int nbatch) {
     // (per instantiation and device: the attribute belongs to the function on a device, not to a context; a process that
     // opens contexts on several devices sets it on each)
@@ -340,7 +340,7 @@ static int launch_wino_t(tz_ctx* ctx, const ConvArgs& a0, int nbatch) {
     static std::atomic<bool> attr_set[64];
     const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 63;
     if (dev == 63 || !attr_set[dev].load(std::memory_order_acquire)) {
-        TZ_HIP(ctx, hipFuncSetAttribute((const void*)k_wino<NT, EPI, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, tzw::LDS_BYTES));
+        TZ_HIP(ctx, hipFuncSetAttribute((const void*)k_wino<NT, EPI, UPS, NOSAME>, hipFuncAttributeMaxDynamicSharedMemorySize, tzw::LDS_BYTES));
         attr_set[dev].store(true, std::memory_order_release);
     }
     // Column blocks per workgroup (one workgroup occupies a CU): the divisor of ncb with the shortest launch in items --
@@ -356,9 +356,10 @@ static int launch_wino_t(tz_ctx* ctx, const ConvArgs& a0, int nbatch) {
         const long long wgs = (long long)tiles * (a.ncb / d), span = (wgs + ctx->num_cus - 1) / ctx->num_cus * d;
         if (best < 0 || span <= best) best = span, a.ipw = d;
     }
+    if (a0.ipw > 0 && a.ncb % a0.ipw == 0) a.ipw = a0.ipw;                         // (the caller knows better: side launches want short workgroups)
     if (ctx->wino_ipw > 0 && a.ncb % ctx->wino_ipw == 0) a.ipw = ctx->wino_ipw;   // (TEZIP_WINO_IPW: measurements)
     const int blocks = (a.ncb / a.ipw) * tiles;
-    hipLaunchKernelGGL((k_wino<NT, EPI, UPS>), dim3(blocks), dim3(512), tzw::LDS_BYTES, ctx->stream, a);
+    hipLaunchKernelGGL((k_wino<NT, EPI, UPS, NOSAME>), dim3(blocks), dim3(512), tzw::LDS_BYTES, ctx->stream, a);
     TZ_HIP(ctx, hipGetLastError());
     return TZ_OK;
 }
@@ -372,7 +373,11 @@ static int launch_wino_ref_t(tz_ctx* ctx, const ConvArgs& a, int nbatch) {
     return TZ_OK;
 }
 
-static int launch_wino(tz_ctx* ctx, int NT, int epi, bool ups, const ConvArgs& a, int nbatch) {
+static int launch_wino(tz_ctx* ctx, int NT, int epi, bool ups, const ConvArgs& a, int nbatch, bool nosame = false) {
+    if (nosame) {   // the second launch of a split gate convolution (tz_model_predict_batch_dev, "E-part ahead")
+        if (NT == 4 && epi == EPI_LSTM && ups && ctx->conv_impl) return launch_wino_t<4, EPI_LSTM, true, true>(ctx, a, nbatch);
+        return tz_fail(ctx, TZ_ERR_UNSUPPORTED, "no split TZ-PA2 kernel for NT=%d epilogue=%d upsampled=%d", NT, epi, (int)ups);
+    }
     if (!ctx->conv_impl) {   // tz_set_conv_impl(0): the plain statement of the same chains
         if (NT == 4 && epi == EPI_LSTM) return ups ? launch_wino_ref_t<4, EPI_LSTM, true>(ctx, a, nbatch) : launch_wino_ref_t<4, EPI_LSTM, false>(ctx, a, nbatch);
         if (NT == 4 && epi == EPI_RAW) return ups ? launch_wino_ref_t<4, EPI_RAW, true>(ctx, a, nbatch) : launch_wino_ref_t<4, EPI_RAW, false>(ctx, a, nbatch);
@@ -681,7 +686,8 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         TZ_TRY(dmalloc(ctx, m, (void**)&m->E[l], (size_t)max_batch * npx * ec * 4));
         TZ_TRY(dmalloc(ctx, m, (void**)&m->R1[l], (size_t)max_batch * npx * R * 4));
         // split gate launches (small grids only, see tz_model_predict_batch_dev): [item][pixel][4R] accumulators
-        if (l >= 1 && l < L - 1 && (size_t)max_batch * npx * 4 * R * 4 <= ((size_t)64 << 20))
+        // (also the hand-over buffer of a gate convolution that runs as two k_wino launches: "E-part ahead" below)
+        if (l >= 1 && l < L - 1 && (size_t)max_batch * npx * 4 * R * 4 <= ((size_t)160 << 20))
             TZ_TRY(dmalloc(ctx, m, (void**)&m->P[l], (size_t)max_batch * npx * 4 * R * 4));
     }
     TZ_TRY(dmalloc(ctx, m, (void**)&m->d_idx, sizeof(int) * 3 * max_batch));
@@ -866,6 +872,69 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         a.out0_nstride = npx(l + 1) * 2 * m->stack[l + 1];
         a.out0 = m->E[l + 1] + slot0 * a.out0_nstride;
     };
+    // "E-part ahead" (round 5): a gate convolution under TZ-PA2 is two phases in ONE chain per output -- the same-resolution
+    // source E_l, then the upsampled R_{l+1} -- and only the second one sits on the step's critical path
+    // (A_0 -> A_1 -> ... -> gates L-1 -> ... -> gates 0).  When the launches of a step cannot fill the chip (one window at a time:
+    // the top-level gates are 192 workgroups on 256 CUs, and so on down), the first phase of level l runs as a launch of its
+    // own on stream2 as soon as E_l exists, leaves every chain as it stands behind the output transform in P_l (float32, what
+    // the fused kernel holds in registers at that point), and the launch on the critical path starts from P_l and walks the
+    // upsampled source only.  Same chains, same order, same bits; the workgroups of the side launch fill the CUs the
+    // critical path leaves idle.  At B = 4 (cfg3) every launch is a whole number of chip-rounds: off.
+    bool epart[TZ_MAX_LEVELS] = {false};
+    if (effective_contract(ctx) == 2 && ctx->conv_impl && ctx->stream2 && !ctx->split_rollout && ctx->epart_mode != 0) {
+        bool underfilled = ctx->epart_mode == 1;
+        for (int l = 1; l < L && !underfilled; ++l) {   // the k_wino launches of a step: A_l (l < L - 1) and the gates of level l
+            const long long tiles = (long long)((hl(l) + 15) / 16) * ((wl(l) + 15) / 16) * n;
+            const long long items[2] = {m->gate_t1[l].d_Wwino ? tiles * m->gate_t1[l].ncb : 0,
+                                        l < L - 1 && m->a_conv[l].d_Wwino ? tiles * m->a_conv[l].ncb : 0};
+            for (long long it : items) {
+                if (!it) continue;
+                const long long rounds = (it + ctx->num_cus - 1) / ctx->num_cus;
+                if ((double)it / (double)(rounds * ctx->num_cus) < 0.8) underfilled = true;
+            }
+        }
+        if (underfilled)
+            for (int l = 1; l < L - 1; ++l) {
+                // (by itself only where the side launch is a chip-round or more of work: on smaller grids a step is a chain of
+                // launch latencies, which two more launches do not shorten)
+                const long long items = (long long)((hl(l) + 15) / 16) * ((wl(l) + 15) / 16) * n * m->gate_t1[l].ncb;
+                epart[l] = m->P[l] && m->gate_t1[l].d_Wwino && m->gate_t1[l].NT == 4 && m->gate_t1[l].segs.size() == 2 &&
+                           (m->rstack[l + 1] % 16) == 0 && (2 * m->stack[l]) % 16 == 0 && (ctx->epart_mode == 1 || items >= ctx->num_cus);
+            }
+    }
+    auto epart_launch = [&](int l) -> int {   // the launch over E_l, on stream2, behind the A convolution that wrote E_l
+        if (!ctx->ev_epart_src[l]) {
+            TZ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_epart_src[l], hipEventDisableTiming));
+            TZ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_epart_done[l], hipEventDisableTiming));
+        }
+        ConvArgs ge;
+        gate_args(l, ge);
+        ge.wino_stride = (ge.src[0].C + ge.src[1].C) >> 2;
+        ge.wino_first = 0;
+        ge.nsrc = 1;                      // the chains over E_l only
+        ge.initf = nullptr;
+        ge.aux = ge.auxf = nullptr;
+        ge.out0_nstride = npx(l) * ge.ncols;
+        ge.out0 = m->P[l] + slot0 * ge.out0_nstride;
+        ge.ipw = 1;   // short workgroups: a CU a side workgroup holds is one the critical path may be waiting for
+        TZ_HIP(ctx, hipEventRecord(ctx->ev_epart_src[l], ctx->stream));
+        TZ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_epart_src[l], 0));
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->stream2;       // (the launchers and their profiling scopes take the context's stream)
+        int rc = launch_conv(ctx, 4, EPI_RAW, ge, n);
+        ctx->stream = main_stream;
+        TZ_TRY(rc);
+        TZ_HIP(ctx, hipEventRecord(ctx->ev_epart_done[l], ctx->stream2));
+        return TZ_OK;
+    };
+    {
+        static const int lv = getenv("TEZIP_EPART_LEVELS") ? atoi(getenv("TEZIP_EPART_LEVELS")) : -1;   // measurements: bit l = level l may split
+        if (lv >= 0)
+            for (int l = 1; l < L - 1; ++l) epart[l] = epart[l] && ((lv >> l) & 1);
+    }
+    int epart_top = 0;
+    for (int l = 1; l < L - 1; ++l)
+        if (epart[l]) epart_top = l;
     bool split[TZ_MAX_LEVELS] = {false};
     for (int l = 0; l < L - 1; ++l) {  // t0 bottom-up
         const PackedConv& pc = m->a_conv[l];
@@ -898,6 +967,12 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
             }
         }
         TZ_TRY(launch_conv(ctx, pc.NT, EPI_POOL_ERR, a, n));
+        // The side launches go out behind the A convolution that writes the E of the HIGHEST split level (the A convolutions
+        // below it fill the chip by themselves), the highest level first: its second half is the first one the critical path
+        // will ask for.
+        if (l + 1 == epart_top)
+            for (int q = epart_top; q >= 1; --q)
+                if (epart[q]) TZ_TRY(epart_launch(q));
     }
     for (int l = L - 1; l >= 0; --l) {  // t1 top-down
         const PackedConv& pc = m->gate_t1[l];
@@ -916,6 +991,18 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
             if (pu.wide) hipLaunchKernelGGL((k_convlat<EPI_LSTM, true, 2>), dim3(pu.blocks), dim3(256), 0, ctx->stream, a);
             else hipLaunchKernelGGL((k_convlat<EPI_LSTM, true, 1>), dim3(pu.blocks), dim3(256), 0, ctx->stream, a);
             TZ_HIP(ctx, hipGetLastError());
+            continue;
+        }
+        if (epart[l]) {   // the chains go on from P_l over the upsampled source
+            a.wino_stride = (a.src[0].C + a.src[1].C) >> 2;
+            a.wino_first = a.src[0].C >> 2;
+            a.init_nstride = npx(l) * a.ncols;
+            a.init = m->P[l] + slot0 * a.init_nstride;
+            a.initf = nullptr;
+            TZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_epart_done[l], 0));
+            tz_prof_scope ps(ctx, TZP_CONV);
+            ps.sub = TZP_WINO;
+            TZ_TRY(launch_wino(ctx, 4, EPI_LSTM, true, a, n, true));
             continue;
         }
         TZ_TRY(launch_conv(ctx, pc.NT, pc.NT == 4 ? EPI_LSTM : EPI_LSTM_PACKED, a, n));

@@ -173,10 +173,16 @@ __device__ unsigned long long tzw_stamps[8][4096][16];   // [0..6] real time at 
 #else
 #define TZW_STAMP(K)
 #endif
-// EPI: EPI_LSTM (NT = 4: columns [i | f | g | o] x 16 channels), EPI_POOL_ERR (NT = 3 or 4), EPI_RAW (NT = 4; tests).
+// EPI: EPI_LSTM (NT = 4: columns [i | f | g | o] x 16 channels), EPI_POOL_ERR (NT = 3 or 4), EPI_RAW (NT = 4).
 // src[0]: the same-resolution source (multiple of 16 channels); src[1] (UPS): the half-resolution source.
-template <int NT, int EPI, bool UPS>
+// A gate convolution can also run as TWO launches (round 5, tz_prednet.hip "E-part ahead"; launches that cannot fill the
+// chip): <4, EPI_RAW, false> over the same-resolution source alone, which leaves every output's chain as it stands behind
+// the output transform in out0 ([pixel][column], per batch item), and <4, EPI_LSTM, true, NOSAME> which starts from those
+// values (a.init with a.init_nstride per item) and walks the upsampled source only.  Same chains, same order, the
+// intermediate is a float32 either way: same bits.  Both walk a PART of the stage image: a.wino_stride / a.wino_first.
+template <int NT, int EPI, bool UPS, bool NOSAME = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wino(const ConvArgs a) {
+    static_assert(!NOSAME || UPS, "a launch without the same-resolution phase walks the upsampled source");
     using namespace tzw;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -204,8 +210,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #endif
     const unsigned sbase = lds_addr(smem);
-    const int S1 = a.src[0].C >> 2;                       // stages of the same-resolution source
+    const int S1 = NOSAME ? 0 : a.src[0].C >> 2;          // stages of the same-resolution source
     const int S = S1 + (UPS ? a.src[1].C >> 2 : 0);       // ... and of the upsampled one
+    const int SI = a.wino_stride ? a.wino_stride : S;     // stages per column block in the image (a launch may walk a part)
 
     // ---- DMA geometry, once per workgroup.  Same-resolution plane: piece wv = slots 41 wv ..; slot = row * 18 + column
     // with the columns stored evens first.  Half-resolution plane: piece wv = slots 13 wv .., slot = row * 10 + column.
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // addresses are running scalar pointers (the first form recomputed them from the stage number: ~40 scalar instructions
     // per stage and wave, 3.4 % of the kernel -- TZW_ABL 32 against 8).
     // (the stage image is [column block][stage]: the weight pointer simply runs on from one item into the next)
-    const float* wp = a.Wwino + (((long long)cb0 * S) * 16 + 2 * wv) * 256;               // weights of the next stage to issue
+    const float* wp = a.Wwino + (((long long)cb0 * SI + a.wino_first) * 16 + 2 * wv) * 256;   // weights of the next stage to issue
     const float* xp0 = a.src[0].p + (long long)n * a.src[0].nstride;                       // ... its quad of the same-resolution source
     const float* xp1 = UPS ? a.src[1].p + (long long)n * a.src[1].nstride : nullptr;       // ... of the upsampled one
     int si = 0;                                                                            // ... its number
@@ -254,6 +261,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         wp += 16 * 256;                                                                                                     \
         if (++si == S) {   /* on to the next item: the next column block's stage 0, the sources from their first quad */   \
             si = 0;                                                                                                         \
+            wp += (SI - S) * (16 * 256);   /* (a launch over a part of the stages skips the rest of the block's) */          \
             xp0 -= 4 * S1;                                                                                                  \
             if (UPS) xp1 -= 4 * (S - S1);                                                                                   \
         }                                                                                                                   \
@@ -352,15 +360,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 D[8][4];   // (first written by the first stage of the item: mfma_first)
     TZW_STAMP(1)
     float V0[8], V1[8];
-    {
-        f32x2 d[3][2];
-        read_d(adA[0], d);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]) : : "memory");
-        transform(d, V0);
-        TZW_TIE8(V0);
-    }
     f32x4 B[8];
-    {   // the weight reads run as one continuous stream, four positions ahead, across the stage boundaries
+    if (!NOSAME) {
+        {
+            f32x2 d[3][2];
+            read_d(adA[0], d);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[2][0]), "+v"(d[2][1]) : : "memory");
+            transform(d, V0);
+            TZW_TIE8(V0);
+        }
+        // the weight reads run as one continuous stream, four positions ahead, across the stage boundaries
         B[0] = lds_read16<0>(wbL);
         B[1] = lds_read16<1024>(wbL);
         B[2] = lds_read16<2048>(wbL);
@@ -424,6 +433,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         TZW_WAIT(7, 3); TZW_MMF(F, D[7], 7, VC[7]) B[3] = lds_read16<WN + 3072>(wn);                                            \
         TZW_STAGE_TAIL                                                                                                      \
     }
+    if (!NOSAME) {
 #pragma unroll 1
     for (int rep = 0; rep < ((TZW_ABL & 16) ? 2 : 1); ++rep) {   // (ablation 16, with 8: every loop twice -> time per stage)
     if (TZW_ABL & 16) s = 0;
@@ -442,6 +452,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+    }
     TZW_STAMP(2)
 
     // ---- output transform, oracle order, one column tile per round (everything of a round dies with it: the first form
@@ -458,8 +469,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         {
             const int y = ty0 + 8 * (mt >> 1) + 2 * g + ph + per_item, x0 = tx0 + 8 * (mt & 1);
             if (a.init && !(TZW_ABL & 64)) {
+                const float* initn = a.init + (long long)n * a.init_nstride;   // (0 for the per-model G0; a split launch's start values are per item)
                 if (ty0 + 16 <= a.H && tx0 + 16 <= a.W) {   // (uniform) the whole tile inside the image: one lane offset, uniform steps
-                    const float* ip = a.init + (unsigned)((y * a.W + x0) * a.ncols + cb * (16 * NT) + r);
+                    const float* ip = initn + (unsigned)((y * a.W + x0) * a.ncols + cb * (16 * NT) + r);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float* ie = ip + (unsigned)(2 * e * a.ncols);
@@ -477,7 +489,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         for (int e = 0; e < 4; ++e) {
                             const int x = x0 + 2 * e;
                             const bool ok = y < a.H && x < a.W;   // (W even wherever tiles are cut: x + 1 < W too)
-                            const float* ip = a.init + ((long long)(ok ? y * a.W + x : 0)) * a.ncols + col;
+                            const float* ip = initn + ((long long)(ok ? y * a.W + x : 0)) * a.ncols + col;
                             in0[t][e] = ip[0];
                             in1[t][e] = ip[x + 1 < a.W && ok ? a.ncols : 0];
                         }
@@ -493,6 +505,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         f32x4* xo = (f32x4*)(smem + NS * SLOT) + (wv * 2) * 64 + lane;
         const f32x4* xi = (const f32x4*)(smem + NS * SLOT) + ((wv ^ 4) * 2) * 64 + lane;
+        if (NOSAME) {   // the chains as the launch over the same-resolution source left them
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                Y[0][t] = in0[t];
+                Y[1][t] = in1[t];
+            }
+            // into their accumulation registers HERE, two wait states ahead of any MFMA that takes them as C (the asm MFMAs get
+            // no hazard handling: a v_accvgpr_write sunk to right in front of the first stage would be read too early)
+            static_assert(!NOSAME || NT == 4, "the split launch exists for gate convolutions");
+            asm volatile("" : "+a"(Y[0][0]), "+a"(Y[0][1]), "+a"(Y[0][2]), "+a"(Y[0][3]), "+a"(Y[1][0]), "+a"(Y[1][1]), "+a"(Y[1][2]), "+a"(Y[1][3]));
+            asm volatile("s_nop 1" ::: "memory");
+        } else
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             constexpr int XA = XBYTES / 2 / 16;   // (f32x4 units) the second area
