@@ -80,4 +80,10 @@ def test_the_line_says_which_frames_per_second_value_is(bench):
     import inspect
     src = inspect.getsource(bench.main)
     assert '"value_definition": "device-resident' in src and '"value_host_to_host":' in src
+    assert '"value_host_to_host_pipelined":' in src and "pinned_pipelined_payloads_equal_device_resident" in src   # round 5
+    # a 64-multiple A convolution counts like a 48-multiple one (the predicate of tz_prednet.hip plain_nt)
+    from tezip_amd.prednet import PredNetConfig
+    wide = PredNetConfig(stack_sizes=(3, 64, 128))
+    # gates of level 1 (E_1 as Winograd + up(R_2) collapsed), gates of level 2, and A_1 (128 = 2 x 64 columns)
+    assert bench.wino_executed_flops_per_px0(wide) == 2 * ((4 * 128 + 4 * 128) * 4 * 64 / 4 + 4 * 256 * 4 * 128 / 16 + 4 * 128 * 128 / 4)
     assert '"configs"' in src and '"cfg5_sweep"' in src      # every BASELINE.json config has a driver-run number

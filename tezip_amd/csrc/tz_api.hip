@@ -144,6 +144,14 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
     }
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
+        // a caller's stream: the split gate launches of "E-part ahead" only pay when the compute stream outranks stream2
+        // (measured: at equal priority the side workgroups sit on the CUs the critical path wants, +5 % per step)
+        int prio = 0, prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (hipStreamGetPriority(ctx->stream, &prio) != hipSuccess || prio != prio_greatest || prio_greatest == prio_least) {
+            (void)hipGetLastError();
+            if (ctx->epart_mode < 0) ctx->epart_mode = 0;
+        }
     } else {
         // (highest dispatch priority: the side launches on stream2 -- lowest -- are there to fill what this stream leaves idle)
         int prio_least = 0, prio_greatest = 0;
