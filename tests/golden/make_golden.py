@@ -18,7 +18,13 @@ What it does:
   * (round 4) runs the reference's train_data_create.process_data and data_utils.SequenceGenerator on a small PNG
     tree (hickle.dump captured, keras' Iterator replaced by a sequential stand-in) -> ref_train.npz.
 
-Run:  /opt/conda/bin/python3.9 tests/golden/make_golden.py      (--train-only: just ref_train.npz)
+  * (round 5) instantiates the reference's own `PredNet` class (prednet.py) over numpy stand-ins for the Keras surface it
+    touches (tests/golden/keras_standin.py) and runs its build / get_initial_state / step -> ref_prednet.npz.
+
+Every file regenerates bit for bit except ref_train.npz, whose folder order inside a split follows the reference's `set()`
+iteration (string hashing: PYTHONHASHSEED); the tests compare it per folder.
+
+Run:  /opt/conda/bin/python3.9 tests/golden/make_golden.py      (--train-only: just ref_train.npz; --prednet-only: just ref_prednet.npz)
 (python3.9 + numpy 1.26 because the reference calls ndarray.tostring(), removed in numpy 2.)
 Nothing from the reference's source text is written to the fixtures: only arrays.
 """
