@@ -13,6 +13,10 @@ F32 = np.float32
 BT2 = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
 G2 = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
 AT2 = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+# F(3x3, 3x3) (interpolation points 0, +-1, 2, inf): 25 multiplies per 9 outputs
+BT3 = np.array([[2, -1, -2, 1, 0], [0, -2, -1, 1, 0], [0, 2, -3, 1, 0], [0, -1, 0, 1, 0], [0, 2, -1, -2, 1]], np.float64)
+G3 = np.array([[1 / 2, 0, 0], [-1 / 2, -1 / 2, -1 / 2], [-1 / 6, 1 / 6, -1 / 6], [1 / 6, 1 / 3, 2 / 3], [0, 0, 1]], np.float64)
+AT3 = np.array([[1, 1, 1, 1, 0], [0, 1, -1, 2, 0], [0, 1, 1, 4, 1]], np.float64)
 # F(4x4, 3x3)
 BT4 = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
                 [0, 4, 0, -5, 0, 1]], np.float64)
@@ -72,8 +76,9 @@ def ref64(x, w):
 
 
 def main():
-    print("float32 error against a float64 convolution, 12x12 outputs, 24 output columns, glorot-scaled weights")
-    print("%-34s %12s %12s %12s   %s" % ("source (channels, value model)", "direct", "F(2x2)", "F(4x4)", "F(4x4) / F(2x2)  [rms | max]"))
+    print("float32 error (rms/max) against a float64 convolution, 12x12 outputs, 24 output columns, glorot-scaled weights")
+    print("%-34s %15s %15s %15s %15s   %s" % ("source (channels, value model)", "direct", "F(2x2)", "F(3x3)", "F(4x4)",
+                                                "F(3x3) / F(2x2) and F(4x4) / F(2x2)  [rms | max]"))
     rng = np.random.default_rng(5)
     for C, kind in ((96, "e: relu of normal"), (192, "e: relu of normal"), (384, "e: relu of normal"), (96, "uniform [0,1]"),
                     (192, "r: tanh-like in [-1,1]")):
@@ -87,11 +92,11 @@ def main():
         w = rng.uniform(-lim, lim, (3, 3, C, 24)).astype(F32)
         ref = ref64(x, w)
         errs = []
-        for got in (direct32(x, w), wino(x, w, 2, BT2, G2, AT2), wino(x, w, 4, BT4, G4, AT4)):
+        for got in (direct32(x, w), wino(x, w, 2, BT2, G2, AT2), wino(x, w, 3, BT3, G3, AT3), wino(x, w, 4, BT4, G4, AT4)):
             e = np.abs(got.astype(np.float64) - ref)
             errs.append((np.sqrt((e ** 2).mean()), e.max()))
-        print("%-34s %12s %12s %12s   %.1f | %.1f" % ("%d, %s" % (C, kind), *("%.1e/%.1e" % e for e in errs),
-                                                      errs[2][0] / errs[1][0], errs[2][1] / errs[1][1]))
+        print("%-34s %15s %15s %15s %15s   %.1f | %.1f   %.1f | %.1f" % ("%d, %s" % (C, kind), *("%.1e/%.1e" % e for e in errs),
+              errs[2][0] / errs[1][0], errs[2][1] / errs[1][1], errs[3][0] / errs[1][0], errs[3][1] / errs[1][1]))
 
 
 if __name__ == "__main__":
