@@ -766,7 +766,14 @@ static int rollout_setup(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int 
     if (first && !first->empty() && (int)first->size() < nt) {
         ctx->pending_sent.assign(nt, 0);
         // frames at 16-byte-aligned offsets of a pinned stack: the compute stream reads them itself (k_fetch_frames)
-        const bool fetch = tz_ptr_kind(frames) == 1 && fsz % 16 == 0 && ((uintptr_t)frames & 15) == 0 && first->size() <= 4096;
+        // (the device's view of the block: the same address for tz_host_alloc memory, possibly another one for memory the
+        // caller registered himself; no mapping -> the copy engine as before)
+        const uint8_t* dev_view = nullptr;
+        bool fetch = tz_ptr_kind(frames) == 1 && fsz % 16 == 0 && first->size() <= 4096;
+        if (fetch && (hipHostGetDevicePointer((void**)&dev_view, (void*)frames, 0) != hipSuccess || !dev_view || ((uintptr_t)dev_view & 15))) {
+            (void)hipGetLastError();
+            fetch = false;
+        }
         std::vector<int> which;
         for (int f : *first) {
             if (f < 0 || f >= nt || ctx->pending_sent[f]) continue;
@@ -779,7 +786,7 @@ static int rollout_setup(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int 
             TZ_TRY(tz_pool_alloc(ctx, which.size() * sizeof(int), &d_which));
             TZ_TRY(tz_upload(ctx, d_which, which.data(), which.size() * sizeof(int)));
             const unsigned gx = (unsigned)std::min<size_t>((fsz / 16 + 255) / 256, 256);
-            hipLaunchKernelGGL(k_fetch_frames, dim3(gx, (unsigned)which.size()), dim3(256), 0, ctx->stream, frames, ctx->d_frames,
+            hipLaunchKernelGGL(k_fetch_frames, dim3(gx, (unsigned)which.size()), dim3(256), 0, ctx->stream, dev_view, ctx->d_frames,
                                (const int*)d_which, fsz);
             TZ_HIP(ctx, hipGetLastError());
         } else {

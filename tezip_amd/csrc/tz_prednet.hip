@@ -882,16 +882,26 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
     // critical path leaves idle.  At B = 4 (cfg3) every launch is a whole number of chip-rounds: off.
     bool epart[TZ_MAX_LEVELS] = {false};
     if (effective_contract(ctx) == 2 && ctx->conv_impl && ctx->stream2 && !ctx->split_rollout && ctx->epart_mode != 0) {
+        // How much of the chip the step's k_wino launches leave idle: a launch of `items` workgroup-items of `stages` stages
+        // each takes ceil(items / CUs) rounds of them.  Measured at 512x512 (scripts/b1_time.py): one window 16 % idle -> the
+        // split gains 4.7 %; three windows 10.5 % -> 2.1 %; two windows 7.5 % -> it LOSES 1.8 % (the side launches cost their own
+        // prologues, epilogues and 8 B per gate column and pixel); four windows 0 %.
         bool underfilled = ctx->epart_mode == 1;
-        for (int l = 1; l < L && !underfilled; ++l) {   // the k_wino launches of a step: A_l (l < L - 1) and the gates of level l
-            const long long tiles = (long long)((hl(l) + 15) / 16) * ((wl(l) + 15) / 16) * n;
-            const long long items[2] = {m->gate_t1[l].d_Wwino ? tiles * m->gate_t1[l].ncb : 0,
-                                        l < L - 1 && m->a_conv[l].d_Wwino ? tiles * m->a_conv[l].ncb : 0};
-            for (long long it : items) {
-                if (!it) continue;
-                const long long rounds = (it + ctx->num_cus - 1) / ctx->num_cus;
-                if ((double)it / (double)(rounds * ctx->num_cus) < 0.8) underfilled = true;
+        if (!underfilled) {
+            double busy = 0.0, span = 0.0;
+            for (int l = 1; l < L; ++l) {   // the k_wino launches of a step: the gates of level l and A_l (l < L - 1)
+                const long long tiles = (long long)((hl(l) + 15) / 16) * ((wl(l) + 15) / 16) * n;
+                const int s_e = (2 * m->stack[l]) / 4, s_u = l < L - 1 ? m->rstack[l + 1] / 4 : 0;
+                const long long it[2] = {m->gate_t1[l].d_Wwino ? tiles * m->gate_t1[l].ncb : 0,
+                                         l < L - 1 && m->a_conv[l].d_Wwino ? tiles * m->a_conv[l].ncb : 0};
+                const int st[2] = {s_e + s_u, s_e};
+                for (int k = 0; k < 2; ++k) {
+                    if (!it[k]) continue;
+                    busy += (double)it[k] / ctx->num_cus * st[k];
+                    span += (double)((it[k] + ctx->num_cus - 1) / ctx->num_cus) * st[k];
+                }
             }
+            underfilled = span > 0.0 && 1.0 - busy / span >= 0.10;
         }
         if (underfilled)
             for (int l = 1; l < L - 1; ++l) {
