@@ -156,7 +156,6 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
         // (highest dispatch priority: the side launches on stream2 -- lowest -- are there to fill what this stream leaves idle)
         int prio_least = 0, prio_greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-        if (getenv("TEZIP_PRIO_DEBUG")) fprintf(stderr, "[tezip] stream priority range: least %d greatest %d\n", prio_least, prio_greatest);
         if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
             delete ctx;
             return TZ_ERR_HIP;
