@@ -161,6 +161,7 @@ extern "C" int tz_ctx_create(int device, void* hip_stream, tz_ctx** out) {
             return TZ_ERR_HIP;
         }
         ctx->own_stream = true;
+        if (prio_greatest == prio_least && ctx->epart_mode < 0) ctx->epart_mode = 0;   // no priorities on this device: no side launches by default
     }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
@@ -677,24 +678,42 @@ __global__ void k_dwp_init(DwpState* st, int p, int nt, int* idx_table, int stri
     if (p < nt) key[p] = 1;        // compress.py:219-220
 }
 
-// One wave; lane 0 decides.  part[nblk]: the frame's per-block squared-error sums (k_sse), added in
-// block order exactly as tzk_sse does on the host.
-__global__ void k_dwp_decide(DwpState* st, const double* __restrict__ part, int nblk, int idx, int nt, double fe_pad,
-                             double threshold, int* idx_table, int stride, uint8_t* key, uint8_t* gfirst, double* mse,
-                             int* c0_flag) {
-    // all lanes fetch the partials at once (one memory round trip per kDwpLds of them), lane 0 adds
-    // them in order
+// The DWP step's window SSE and its decision in ONE launch (round 5; until then k_sse, then a one-workgroup k_dwp_decide,
+// then a conditional C0 broadcast: three dependent launches behind every predictor step of a B = 1 rollout).  Every
+// workgroup writes its block's partial sum (the arithmetic of k_sse: tz_sse_block) and takes a ticket; the workgroup that
+// draws the last ticket -- every partial was performed before its ticket, both as device-scope atomics, and is read back
+// with atomics -- adds them in block order exactly as tzk_sse does on the host, and lane 0 decides.
+// No workgroup waits for another one.  part[nblk]; *ticket is 0 on entry and is left at 0.
+__global__ __launch_bounds__(256) void k_sse_decide(const uint8_t* __restrict__ orig, const float* __restrict__ pred, int H, int W, int Hp,
+                                                     int Wp, int nblk, double* part, unsigned* ticket, DwpState* st, int idx, int nt,
+                                                     double fe_pad, double threshold, int* idx_table, int stride, uint8_t* key,
+                                                     uint8_t* gfirst, double* mse, int* c0_flag) {
+    __shared__ double s[256];
     __shared__ double s_part[kDwpLds];
+    __shared__ unsigned s_last;
+    const double mine = tz_sse_block(orig, pred, H, W, Hp, Wp, blockIdx.x, s);
+    if (threadIdx.x == 0) {
+        // The partial goes out as a device-scope ATOMIC and the ticket is taken with an increment that DEPENDS on that
+        // atomic's return value: the ticket cannot be drawn before the partial is performed where every XCD sees it, and no
+        // fence is needed -- an agent-scope fence writes back / invalidates a whole per-XCD L2 on this chip (measured: the
+        // kernel with __threadfence() on both sides took 22 us).  The reader below uses atomics too.
+        const unsigned long long old = atomicExch((unsigned long long*)(part + blockIdx.x), (unsigned long long)__double_as_longlong(mine));
+        s_last = atomicAdd(ticket, 1u + (unsigned)(old & 0ull)) == (unsigned)(nblk - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
     double t = 0.0;
     for (int b0 = 0; b0 < nblk; b0 += kDwpLds) {
         const int nb = min(kDwpLds, nblk - b0);
         __syncthreads();
-        for (int b = threadIdx.x; b < nb; b += blockDim.x) s_part[b] = part[b0 + b];
+        for (int b = threadIdx.x; b < nb; b += blockDim.x)
+            s_part[b] = __longlong_as_double((long long)atomicAdd((unsigned long long*)(part + b0 + b), 0ull));   // (from L2)
         __syncthreads();
         if (threadIdx.x == 0)
             for (int b = 0; b < nb; ++b) t = t + s_part[b];
     }
     if (threadIdx.x != 0) return;
+    *ticket = 0u;
     int key_idx = st->key_idx;
     double run = st->run + t;
     const double stop = run / ((double)(idx - key_idx + 1) * fe_pad);   // compress.py:246
@@ -718,8 +737,11 @@ __global__ void k_dwp_decide(DwpState* st, const double* __restrict__ part, int 
     }
 }
 
-__global__ void k_bcast_frame_if(const float* __restrict__ src, size_t fe, const int* __restrict__ flag, float* __restrict__ dst) {
-    if (!*flag) return;
+// slot 0 of every group the DWP loop opened holds C0 (compress.py:258): one launch behind the loop, frame = blockIdx.y
+// (nothing in the loop reads such a slot: the step after a boundary starts from the real frame)
+__global__ void k_bcast_frames_flagged(const float* __restrict__ src, size_t fe, const int* __restrict__ flag, float* __restrict__ pred) {
+    if (!flag[blockIdx.y]) return;
+    float* dst = pred + (size_t)blockIdx.y * fe;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < fe; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
@@ -1132,11 +1154,14 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
         if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_gf);
         if (rc == TZ_OK) rc = tz_pool_alloc(ctx, sizeof(double) * nt, &d_mse);
         if (rc == TZ_OK) rc = tz_pool_alloc(ctx, sizeof(int) * nt, &d_flag);
+        void* d_ticket = nullptr;
+        if (rc == TZ_OK) rc = tz_pool_alloc(ctx, 256, &d_ticket);
         if (rc == TZ_OK) rc = tz_upload(ctx, d_key, key.data(), nt);
         if (rc == TZ_OK) rc = tz_upload(ctx, d_gf, gfirst.data(), nt);
         if (rc == TZ_OK) {
             hipError_t e = hipMemsetAsync(d_mse, 0, sizeof(double) * nt, ctx->stream);
             if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, sizeof(int) * nt, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_ticket, 0, 256, ctx->stream);
             if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "DWP state: %s", hipGetErrorString(e));
         }
         const float* c0 = nullptr;
@@ -1150,16 +1175,19 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
         for (int idx = p + 1; idx < nt && rc == TZ_OK; ++idx) {
             rc = tz_model_predict_batch_dev(ctx, 1, ctx->d_sched, maxB, ctx->d_frames, H, W, ctx->d_pred, ctx->d_pred);
             if (rc != TZ_OK) break;
-            rc = tzk_sse_launch(ctx, ctx->d_frames + (size_t)idx * H * W * 3, ctx->d_pred + (size_t)idx * fe_pad, 1, H, W,
-                                ctx->Hp, ctx->Wp, (double*)d_part);
-            if (rc != TZ_OK) break;
-            hipLaunchKernelGGL(k_dwp_decide, dim3(1), dim3(256), 0, ctx->stream, (DwpState*)d_state, (const double*)d_part, nblk,
-                               idx, nt, (double)fe_pad, threshold, ctx->d_sched, maxB, (uint8_t*)d_key, (uint8_t*)d_gf,
-                               (double*)d_mse, (int*)d_flag);
-            // slot 0 of the new group holds C0 (258); the last frame keeps its prediction (260-262)
-            if (idx != nt - 1)
-                hipLaunchKernelGGL(k_bcast_frame_if, dim3(gx), dim3(256), 0, ctx->stream, c0, fe_pad, (const int*)d_flag + idx,
-                                   ctx->d_pred + (size_t)idx * fe_pad);
+            {
+                tz_prof_scope ps(ctx, TZP_SSE);
+                hipLaunchKernelGGL(k_sse_decide, dim3(nblk), dim3(256), 0, ctx->stream, ctx->d_frames + (size_t)idx * H * W * 3,
+                                   ctx->d_pred + (size_t)idx * fe_pad, H, W, ctx->Hp, ctx->Wp, nblk, (double*)d_part, (unsigned*)d_ticket,
+                                   (DwpState*)d_state, idx, nt, (double)fe_pad, threshold, ctx->d_sched, maxB, (uint8_t*)d_key,
+                                   (uint8_t*)d_gf, (double*)d_mse, (int*)d_flag);
+            }
+            if (hipGetLastError() != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "DWP launch failed");
+        }
+        // slot 0 of every group opened on the way holds C0 (258); the last frame keeps its prediction (260-262: k_sse_decide
+        // does not flag it)
+        if (rc == TZ_OK && nt > 1) {
+            hipLaunchKernelGGL(k_bcast_frames_flagged, dim3(std::min(gx, 128), nt), dim3(256), 0, ctx->stream, c0, fe_pad, (const int*)d_flag, ctx->d_pred);
             if (hipGetLastError() != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "DWP launch failed");
         }
         if (rc == TZ_OK) {

@@ -2169,31 +2169,9 @@ int tzk_reconstruct(tz_ctx* ctx, const float* pred, const uint8_t* key, const ui
 __global__ __launch_bounds__(256) void k_sse(const uint8_t* __restrict__ orig, const float* __restrict__ pred, int H,
                                              int W, int Hp, int Wp, int nblk, double* __restrict__ partial) {
     __shared__ double s[256];
-    int f = blockIdx.y, b = blockIdx.x;
-    size_t n = (size_t)Hp * Wp * 3;
-    const float* p = pred + (size_t)f * n;
-    const uint8_t* o = orig + (size_t)f * H * W * 3;
-    double acc = 0.0;
-    for (int j = 0; j < 16; ++j) {
-        size_t i = (size_t)b * 4096 + (size_t)j * 256 + threadIdx.x;
-        double sq = 0.0;
-        if (i < n) {
-            size_t pix = i / 3;
-            int c = (int)(i - pix * 3), y = (int)(pix / Wp), x = (int)(pix - (size_t)y * Wp);
-            float xv = 0.0f;
-            if (y < H && x < W) xv = (float)o[((size_t)y * W + x) * 3 + c] / 255.0f;
-            double d = (double)xv - (double)p[i];
-            sq = d * d;
-        }
-        acc = acc + sq;
-    }
-    s[threadIdx.x] = acc;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-        if ((int)threadIdx.x < st) s[threadIdx.x] = s[threadIdx.x] + s[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[(size_t)f * nblk + b] = s[0];
+    const int f = blockIdx.y, b = blockIdx.x;
+    const double t = tz_sse_block(orig + (size_t)f * H * W * 3, pred + (size_t)f * ((size_t)Hp * Wp * 3), H, W, Hp, Wp, b, s);
+    if (threadIdx.x == 0) partial[(size_t)f * nblk + b] = t;
 }
 
 int tzk_sse_blocks(int Hp, int Wp) { return (int)(((size_t)Hp * Wp * 3 + 4095) / 4096); }

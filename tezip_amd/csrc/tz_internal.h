@@ -154,6 +154,43 @@ int tz_payload_settle(tz_ctx* ctx);  // waits for a deferred payload transfer st
         if (_s != TZ_OK) return _s; \
     } while (0)
 
+// ---- window SSE: one 4096-element block of one padded frame (compress.py:246), the fixed order of tz_codec.hip k_sse:
+// thread t sums elements t, t + 256, ... of the block, then a halving tree over the 256 partials; the result is valid on
+// thread 0.  `s` = 256 doubles of LDS.  Shared by k_sse and by the DWP step kernel of tz_api.hip (k_sse_decide).
+static __device__ __forceinline__ double tz_sse_block(const uint8_t* __restrict__ o, const float* __restrict__ p, int H, int W, int Hp,
+                                                      int Wp, int b, double* s) {
+    // (32-bit index arithmetic: a padded frame has fewer than 2^29 elements, tz_model_prepare; the 64-bit divisions this
+    // loop used to do per element were 27 us per 512x512 frame -- 4 % of a one-window predictor step)
+    const unsigned n = (unsigned)Hp * (unsigned)Wp * 3u, uWp = (unsigned)Wp;
+    // all 32 loads of the thread first (they are independent; issued one iteration at a time their round trips added up to
+    // most of the kernel), then the sum in its fixed order
+    float pv[16], xv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const unsigned i = (unsigned)b * 4096u + (unsigned)j * 256u + threadIdx.x;
+        pv[j] = 0.0f;
+        xv[j] = 0.0f;
+        if (i < n) {
+            const unsigned pix = i / 3u, c = i - pix * 3u, y = pix / uWp, x = pix - y * uWp;
+            pv[j] = p[i];
+            if (y < (unsigned)H && x < (unsigned)W) xv[j] = (float)o[((size_t)y * W + x) * 3 + c] / 255.0f;
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double d = (double)xv[j] - (double)pv[j];
+        acc = acc + d * d;   // (an element past the end of the frame adds +0.0, as before)
+    }
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) s[threadIdx.x] = s[threadIdx.x] + s[threadIdx.x + st];
+        __syncthreads();
+    }
+    return s[0];
+}
+
 // ---- device memory helpers -------------------------------------------------------------
 bool tz_is_device_ptr(const void* p);
 int tz_poison_byte();                                 // TEZIP_POISON diagnostic: 0x100 | byte, or 0
