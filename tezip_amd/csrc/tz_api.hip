@@ -1154,14 +1154,17 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
         if (rc == TZ_OK) rc = tz_pool_alloc(ctx, nt, &d_gf);
         if (rc == TZ_OK) rc = tz_pool_alloc(ctx, sizeof(double) * nt, &d_mse);
         if (rc == TZ_OK) rc = tz_pool_alloc(ctx, sizeof(int) * nt, &d_flag);
-        void* d_ticket = nullptr;
+        void *d_ticket = nullptr, *d_slot0 = nullptr;   // (d_slot0: one int 0 = "the prediction is the input of slot 0 of the next step")
+        bool prev_fused = false;
         if (rc == TZ_OK) rc = tz_pool_alloc(ctx, 256, &d_ticket);
+        if (rc == TZ_OK) rc = tz_pool_alloc(ctx, 256, &d_slot0);
         if (rc == TZ_OK) rc = tz_upload(ctx, d_key, key.data(), nt);
         if (rc == TZ_OK) rc = tz_upload(ctx, d_gf, gfirst.data(), nt);
         if (rc == TZ_OK) {
             hipError_t e = hipMemsetAsync(d_mse, 0, sizeof(double) * nt, ctx->stream);
             if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, sizeof(int) * nt, ctx->stream);
             if (e == hipSuccess) e = hipMemsetAsync(d_ticket, 0, 256, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_slot0, 0, 256, ctx->stream);
             if (e != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "DWP state: %s", hipGetErrorString(e));
         }
         const float* c0 = nullptr;
@@ -1173,7 +1176,14 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
         }
         const int gx = (int)std::min<size_t>((fe_pad + 255) / 256, 1024);
         for (int idx = p + 1; idx < nt && rc == TZ_OK; ++idx) {
-            rc = tz_model_predict_batch_dev(ctx, 1, ctx->d_sched, maxB, ctx->d_frames, H, W, ctx->d_pred, ctx->d_pred);
+            // the prediction kernel also writes the level-0 error maps of the NEXT step as if that step went on from this
+            // prediction (as in the static schedule); the next step's error unit then runs for a key-frame start only --
+            // which of the two it is, k_sse_decide says on the device
+            bool fused = false;
+            static const bool spec = !getenv("TEZIP_DWP_SPEC") || atoi(getenv("TEZIP_DWP_SPEC")) != 0;   // (0: measurements)
+            rc = tz_model_predict_batch_dev(ctx, 1, ctx->d_sched, maxB, ctx->d_frames, H, W, ctx->d_pred, ctx->d_pred, 0,
+                                            spec ? (const int*)d_slot0 : nullptr, false, &fused, prev_fused);
+            prev_fused = fused;
             if (rc != TZ_OK) break;
             {
                 tz_prof_scope ps(ctx, TZP_SSE);

@@ -1563,10 +1563,13 @@ __global__ __launch_bounds__(256) void k_to_fragments(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_err0(const uint8_t* __restrict__ frames_u8, int H, int W,
                                               const float* __restrict__ in_stack, const int* __restrict__ is_key,
                                               const int* __restrict__ in_idx, const float* __restrict__ ahat0, int Hp,
-                                              int Wp, int C, int Cs, float* __restrict__ e0) {
+                                              int Wp, int C, int Cs, float* __restrict__ e0, int keys_only) {
     int n = blockIdx.y;
     long long npx = (long long)Hp * Wp;
     const bool key = is_key[n] != 0;
+    // (keys_only: the prediction kernel of the step before has already written this item's maps from its own output -- the
+    // DWP loop, where only the device knows whether the next step starts from a key frame instead)
+    if (keys_only && !key) return;
     const long long fi = in_idx[n];
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (long long)gridDim.x * blockDim.x) {
         int y = (int)(p / Wp), x = (int)(p - (long long)y * Wp);

@@ -269,9 +269,10 @@ int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int
 // gives each group its own range of the max_batch slots)
 // d_next_slot (may be NULL): per item the activation slot its prediction will occupy as the INPUT of the next call on
 // this stream (-1: none) -- the prediction kernel then also writes that call's level-0 error maps (*fused_next says whether
-// it did), and that call may be told to skip_err0.
+// it did), and that call may be told to skip_err0 -- or, when only the device knows whether an item of that call starts from a
+// key frame instead (DWP), to launch the error unit for err0_keys_only.
 int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride, const uint8_t* d_frames_u8, int H, int W,
                                const float* d_in_stack, float* d_out_stack, int slot0 = 0, const int* d_next_slot = nullptr,
-                               bool skip_err0 = false, bool* fused_next = nullptr);
+                               bool skip_err0 = false, bool* fused_next = nullptr, bool err0_keys_only = false);
 int tz_model_c0_dev(tz_ctx* ctx, const float** c0);
 int tz_model_dims(tz_ctx* ctx, int* Hp, int* Wp, int* max_batch);

@@ -821,7 +821,7 @@ int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int
 // on the device.  Nothing here allocates or copies.
 int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride, const uint8_t* d_frames_u8, int H, int W,
                                const float* d_in_stack, float* d_out_stack, int slot0, const int* d_next_slot, bool skip_err0,
-                               bool* fused_next) {
+                               bool* fused_next, bool err0_keys_only) {
     tz_model* m = ctx->model;
     if (!m || !m->prepared) return tz_fail(ctx, TZ_ERR_STATE, "model not prepared");
     if (n < 1 || slot0 < 0 || slot0 + n > m->maxB) return tz_fail(ctx, TZ_ERR_INVALID, "batch %d at slot %d outside 1..%d", n, slot0, m->maxB);
@@ -834,7 +834,8 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         tz_prof_scope ps(ctx, TZP_ERR0);
         int gx = (int)std::min<long long>((npx(0) + 255) / 256, 2048);
         hipLaunchKernelGGL(k_err0, dim3(gx, n), dim3(256), 0, ctx->stream, d_frames_u8, H, W, d_in_stack, d_idx,
-                           d_idx + stride, m->Ahat0[0], Hp, Wp, m->stack[0], m->e0s, m->E[0] + (long long)slot0 * npx(0) * m->e0s);
+                           d_idx + stride, m->Ahat0[0], Hp, Wp, m->stack[0], m->e0s, m->E[0] + (long long)slot0 * npx(0) * m->e0s,
+                           err0_keys_only ? 1 : 0);
         TZ_HIP(ctx, hipGetLastError());
     }
     // Small grids (64x64-class frames): the launches of a step are latency chains on a mostly idle chip,
