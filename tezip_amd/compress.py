@@ -472,5 +472,8 @@ def _log_io(what, job, ranges):
     d = os.environ.get("TEZIP_IO_LOG")
     if d:
         rank = job[0] if job else 0
-        with open(os.path.join(d, "%s.rank%d" % (what, rank)), "w") as f:
-            f.write(" ".join("%d:%d" % r for r in ranges) + "\n")
+        try:   # (a diagnostic: it must never be what a job fails on, least of all from a `finally`)
+            with open(os.path.join(d, "%s.rank%d" % (what, rank)), "w") as f:
+                f.write(" ".join("%d:%d" % r for r in ranges) + "\n")
+        except OSError:
+            pass
