@@ -54,3 +54,30 @@ def test_deferred_payloads_equal_blocking_ones():
         np.testing.assert_array_equal(bufs[1], want[2][0])
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("h,w", [(64, 96), (61, 90), (21, 30)])
+def test_pinned_pageable_and_device_stacks_roll_out_alike(h, w):
+    """The key frames of a PINNED stack are fetched by the compute stream itself (k_fetch_frames; frames of a size that
+    is a multiple of 16 bytes), every other host stack goes through the copy engine, a device stack is copied on the
+    device: same key mask, same predictions, same payload."""
+    import torch
+    ctx = _lib.Context(0)
+    try:
+        ctx.load_model(CFG, CFG.init_weights(seed=5, bias_scale=0.2))
+        ctx.prepare(_lib.pad8(h), _lib.pad8(w), max_batch=3)
+        nt = 11
+        frames = synth.translating_scene(nt, h, w, seed=77)
+        res = []
+        for stack in (frames, _lib.pinned_copy(frames), torch.from_numpy(frames).cuda()):
+            key, _ = ctx.rollout(stack, 1, 4)
+            pred = ctx.get_predictions()
+            payload, table, _ = ctx.encode("abs", [1.0], True)
+            res.append((key, pred, np.array(payload), table))
+        for other in res[1:]:
+            np.testing.assert_array_equal(other[0], res[0][0])
+            np.testing.assert_array_equal(other[1], res[0][1])
+            np.testing.assert_array_equal(other[2], res[0][2])
+            np.testing.assert_array_equal(other[3], res[0][3])
+    finally:
+        ctx.close()
