@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round 5 note for round 6: the UPSAMPLED source of a gate convolution -- 3x3 taps on a x2 nearest
+"""Round 5 (the form passes this check and was dropped for its weight stream): the UPSAMPLED source of a gate convolution -- 3x3 taps on a x2 nearest
 upsampled map = per output parity class a 2x2-tap filter on the half-resolution grid (the collapsed taps of TZ-PA1 / TZ-PA2)
 -- evaluated as Winograd F(2x2, 2x2) per class: 9 multiplies per 2x2 outputs of a class instead of 16.  Float32 error of
 both forms against a float64 evaluation, chains along the channels as an MFMA k-loop accumulates them.  CPU only.
