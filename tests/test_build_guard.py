@@ -148,3 +148,52 @@ def test_k_wino_reads_no_accumulator_in_the_shadow_of_an_mfma(tmp_path):
                 waited += int(nop.group(1)) + 1 if nop else 1
                 j -= 1
     assert seen >= 7 and readers >= 7 * 96   # every instantiation reads its accumulators somewhere
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="no ROCm LLVM tools")
+def test_k_sse_decide_performs_its_partial_before_it_draws_its_ticket(tmp_path):
+    """k_sse_decide (tz_api.hip; the DWP decision of compress.py:245-264 in one launch): every workgroup publishes its
+    block's partial sum and then takes a ticket; the workgroup with the last ticket adds the partials.  The partial must
+    have been PERFORMED before the ticket increment is issued -- two relaxed atomics on different addresses are not
+    ordered by issue order.  Round 5 expressed that with `1u + (old & 0)`, which the compiler folded: the object code had
+    a non-returning swap and no wait in front of the add.  Read off the code object just built:
+    the exchange is the returning form (`sc0`), an `s_waitcnt vmcnt(0)` follows it with no other vector-memory
+    instruction and no branch in between, and only then comes the ticket's `global_atomic_add ... sc0`; the reader's
+    loads of part[] are agent-scope atomic loads (`global_load_dwordx2 ... sc1`, which bypass the CU's L1; an atomic
+    exchange does not leave its line in the writer's L2) and all come behind that add."""
+    obj = os.path.join(ROOT, "tezip_amd", "csrc", "tz_api.o")
+    if not os.path.exists(obj):
+        from tezip_amd import build
+        build.build()
+    work = tmp_path / "co"
+    work.mkdir()
+    shutil.copy(obj, work / "k.o")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objdump"), "--offloading", "k.o"], cwd=work, stdout=subprocess.DEVNULL)
+    co = [f for f in os.listdir(work) if "amdgcn" in f]
+    text = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co[0]], cwd=work, text=True)
+    body = None
+    for fn in re.split(r"\n(?=[0-9a-f]+ <)", text):
+        m = re.match(r"[0-9a-f]+ <([^>]+)>:", fn)
+        if m and "k_sse_decide" in m.group(1):
+            assert body is None, "two k_sse_decide functions"
+            body = [l.split("//")[0].strip() for l in fn.splitlines()[1:] if l.strip()]
+    assert body, "k_sse_decide not in tz_api.o"
+    swaps = [i for i, ins in enumerate(body) if ins.startswith("global_atomic_swap")]
+    assert len(swaps) == 1, [body[i] for i in swaps]
+    sw = swaps[0]
+    assert body[sw].startswith("global_atomic_swap_x2") and body[sw].rstrip().endswith("sc0"), body[sw]   # returning form
+    adds = [i for i, ins in enumerate(body) if re.match(r"global_atomic_add(_u32)? ", ins)]
+    assert adds and all(body[i].rstrip().endswith("sc0") for i in adds), [body[i] for i in adds]
+    ticket = min(i for i in adds if i > sw)
+    between = body[sw + 1:ticket]
+    assert "s_waitcnt vmcnt(0)" in between, between
+    wait = sw + 1 + between.index("s_waitcnt vmcnt(0)")
+    gap = body[sw + 1:wait]
+    assert not any(i.startswith(("global_", "buffer_", "flat_", "scratch_", "s_cbranch", "s_branch")) for i in gap), gap
+    assert not any(i < sw for i in adds), "a ticket add in front of the partial"
+    # the last-ticket workgroup reads part[] with sc1 loads (never a plain load: that may be served by this CU's L1);
+    # the first 64-bit load without sc1 behind them is DwpState::run, read by lane 0 after the sum
+    first_store = min(i for i, ins in enumerate(body) if ins.startswith("global_store") and i > ticket)
+    readers = [i for i, ins in enumerate(body) if ins.startswith("global_load_dwordx2") and ticket < i < first_store]
+    assert readers and all(body[i].rstrip().endswith("sc1") for i in readers), [body[i] for i in readers]
+    assert not any(ins.startswith("global_load_dwordx2") and ins.rstrip().endswith("sc1") for ins in body[:ticket])

@@ -55,3 +55,47 @@ def test_results_do_not_depend_on_stale_device_memory():
     ref = _run(None)
     for poison in (255, 0, 165):
         assert _run(poison) == ref, "TEZIP_POISON=%d changes the result" % poison
+
+
+DWP_JOB = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import coracle
+from oracle import oracle as O
+from tezip_amd import _lib, synth
+from tezip_amd.prednet import PredNetConfig
+cfg = PredNetConfig(stack_sizes=(3, 16, 32))
+wts = cfg.init_weights(seed=3, bias_scale=0.2)
+ctx = _lib.Context(0)
+ctx.load_model(cfg, wts)
+for (nt, H, W, p) in [(14, 128, 160, 0), (10, 61, 90, 2)]:
+    hp, wp = _lib.pad8(H), _lib.pad8(W)
+    frames = synth.turbulence(nt, H, W, seed=6)
+    net = coracle.CPredNet(wts, cfg.stack_sizes, cfg.R_stack_sizes, hp, wp)
+    class P:
+        def c0(self, a, b):
+            return net.c0()
+        def next(self, f):
+            return net.next(np.asarray(f, np.float32))
+    probe = O.rollout(frames, p, None, 1e9, P())
+    thr = float(np.median(probe["mse"]))
+    ref = O.rollout(frames, p, None, thr, P())
+    ctx.prepare(hp, wp, max_batch=4)
+    for rep in range(3):   # part[] is re-poisoned every time the pool hands it out: every DWP step meets NaN bit patterns
+        key, mse = ctx.rollout(frames, p, None, thr, want_mse=True)
+        assert np.isfinite(mse).all(), mse
+        np.testing.assert_array_equal(key, ref["key"])
+        np.testing.assert_allclose(mse[p + 1:], ref["mse"], rtol=1e-12)
+print("dwp ok")
+'''
+
+
+def test_dwp_decision_never_reads_a_partial_it_did_not_wait_for():
+    """k_sse_decide's part[] filled with 0xFF bytes (NaN bit patterns) before every rollout: a last-ticket workgroup that
+    read a slot before its writer's exchange had been performed would put a NaN into mse[] (and take no boundary there).
+    The window MSE log and the key mask must equal the oracle's (compress.py:245-264).  The ordering itself is read off the
+    object code in tests/test_build_guard.py; this is its dynamic half."""
+    env = dict(os.environ, TEZIP_POISON="255")
+    out = subprocess.run([sys.executable, "-c", DWP_JOB % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "dwp ok" in out.stdout, out.stderr[-2000:]

@@ -693,12 +693,17 @@ __global__ __launch_bounds__(256) void k_sse_decide(const uint8_t* __restrict__ 
     __shared__ unsigned s_last;
     const double mine = tz_sse_block(orig, pred, H, W, Hp, Wp, blockIdx.x, s);
     if (threadIdx.x == 0) {
-        // The partial goes out as a device-scope ATOMIC and the ticket is taken with an increment that DEPENDS on that
-        // atomic's return value: the ticket cannot be drawn before the partial is performed where every XCD sees it, and no
-        // fence is needed -- an agent-scope fence writes back / invalidates a whole per-XCD L2 on this chip (measured: the
-        // kernel with __threadfence() on both sides took 22 us).  The reader below uses atomics too.
-        const unsigned long long old = atomicExch((unsigned long long*)(part + blockIdx.x), (unsigned long long)__double_as_longlong(mine));
-        s_last = atomicAdd(ticket, 1u + (unsigned)(old & 0ull)) == (unsigned)(nblk - 1);
+        // The partial goes out as a device-scope RETURNING exchange; its return value is consumed by an asm the compiler
+        // cannot see through, which also drains vmcnt: the exchange has been performed (its old value has come back) before
+        // the ticket increment is even issued.  Two relaxed atomics on different addresses are NOT ordered by issue order
+        // (different L2 channels); a C-level "dependency" such as `1u + (old & 0)` is folded away by the compiler and left
+        // a non-returning swap with no wait in front of the add (round 5's defect; tests/test_build_guard.py now reads
+        // the sequence swap sc0 -> s_waitcnt vmcnt(0) -> add off the object code).  No agent-scope fence: that writes
+        // back / invalidates a whole per-XCD L2 (measured: 22 us with __threadfence() on both sides).  The reader below
+        // loads part[] with agent-scope atomic loads (`sc1`), after its own ticket add has returned and a barrier.
+        unsigned long long old = atomicExch((unsigned long long*)(part + blockIdx.x), (unsigned long long)__double_as_longlong(mine));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(old) : : "memory");
+        s_last = atomicAdd(ticket, 1u) == (unsigned)(nblk - 1);
     }
     __syncthreads();
     if (!s_last) return;
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(256) void k_sse_decide(const uint8_t* __restrict__ 
         const int nb = min(kDwpLds, nblk - b0);
         __syncthreads();
         for (int b = threadIdx.x; b < nb; b += blockDim.x)
-            s_part[b] = __longlong_as_double((long long)atomicAdd((unsigned long long*)(part + b0 + b), 0ull));   // (from L2)
+            s_part[b] = __hip_atomic_load(part + b0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 load: never this CU's L1
         __syncthreads();
         if (threadIdx.x == 0)
             for (int b = 0; b < nb; ++b) t = t + s_part[b];
