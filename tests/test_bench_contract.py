@@ -87,3 +87,43 @@ def test_the_line_says_which_frames_per_second_value_is(bench):
     # gates of level 1 (E_1 as Winograd + up(R_2) collapsed), gates of level 2, and A_1 (128 = 2 x 64 columns)
     assert bench.wino_executed_flops_per_px0(wide) == 2 * ((4 * 128 + 4 * 128) * 4 * 64 / 4 + 4 * 256 * 4 * 128 / 16 + 4 * 128 * 128 / 4)
     assert '"configs"' in src and '"cfg5_sweep"' in src      # every BASELINE.json config has a driver-run number
+
+
+def test_the_line_carries_the_host_side_and_the_steps_own_elementwise_roofline(bench):
+    """VERDICT r05 items 2 and 7 (checked on the source: the line itself needs a GPU).  SURVEY.md 8(d): PNG decode and zstd are
+    excluded from the GPU number and reported separately -- `host_pipeline`: compress.run / decompress.run wall seconds on the
+    cfg3 job as PNG files, stage times, zstd level and thread count; `roofline_encode_tail`: the HBM roofline of the
+    elementwise tail the timed step launches, beside the stand-alone `roofline_delta`."""
+    import inspect
+    main, leg = inspect.getsource(bench.main), inspect.getsource(bench.host_pipeline_leg)
+    assert 'extras["host_pipeline"] = host_pipeline_leg(' in main
+    for key in ("compress_run_s", "decompress_run_s", "compress_frames_per_s", "decompress_frames_per_s", "compress_stages_s",
+                "decompress_stages_s", "zstd_threads", "zstd_level", "png_threads", "zstd9_share_of_compress_run",
+                "round_trip_max_abs_error", "output_bytes"):
+        assert '"%s"' % key in leg, key
+    from tezip_amd import compress, decompress
+    csrc, usrc = inspect.getsource(compress), inspect.getsource(decompress)
+    for stage in ("list + probe", "first window decoded", "remaining windows decoded + staged", "rollout", "encode (payload resident)",
+                  "key_frame.dat + entropy.dat", "zstd-9 key_frame.dat (worker)", "payload fetch + zstd-9 entropy.dat"):
+        assert '"%s"' % stage in csrc, stage
+    for stage in ("zstd-d entropy.dat + stage to HBM", "zstd-d key_frame.dat + stage to HBM", "rollout (decoder)",
+                  "decode tail (frames resident)", "frames fetch + PNG encode"):
+        assert '"%s"' % stage in usrc, stage
+    assert '"roofline_encode_tail":' in main and '"bytes_per_element": tail_bpe' in main and '"roofline_delta":' in main
+
+
+def test_stage_log_collects_without_printing(monkeypatch, capsys):
+    """compress.STAGE_LOG (what the host_pipeline leg reads): marks and worker-side durations land in the list, nothing is
+    printed unless TEZIP_TIMING is set, and nothing is recorded when no list is installed."""
+    from tezip_amd import compress
+    monkeypatch.delenv("TEZIP_TIMING", raising=False)
+    monkeypatch.setattr(compress, "STAGE_LOG", [])
+    st = compress._Stages("decompress")
+    st.mark("a")
+    st.add("b (worker)", 0.25)
+    assert [(r, n) for r, n, _ in compress.STAGE_LOG] == [("decompress", "a"), ("decompress", "b (worker)")]
+    assert compress.STAGE_LOG[1][2] == 0.25 and compress.STAGE_LOG[0][2] >= 0.0
+    monkeypatch.setattr(compress, "STAGE_LOG", None)
+    compress._Stages().mark("c")
+    out = capsys.readouterr()
+    assert out.out == "" and out.err == ""

@@ -217,6 +217,36 @@ def _failing_worker(rank, world, port, stage):
         dist.destroy_process_group()
 
 
+def _contract_worker(rank, world, port, contracts):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), os.path.join(here, "golden")]
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        frames, pred = _case()
+        eng = OracleEngine(pred)
+        eng.contract = lambda: contracts[rank]
+        agree = len({c for c in contracts if c}) <= 1
+        try:
+            res = tzdist.compress_sharded(eng, frames, 0, 4, "abs", [0.0], True)
+        except RuntimeError as e:   # EVERY rank raises: nobody goes on into the histogram all-reduce alone
+            assert not agree and "different arithmetic contracts" in str(e) and "TZ-PA1" in str(e) and "TZ-PA2" in str(e), str(e)
+        else:
+            assert agree and (res is None) == (rank != 0)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("contracts", [(2, 1), (2, 2), (0, 2)])
+def test_ranks_must_agree_on_the_arithmetic_contract(contracts):
+    """One stream is decoded under ONE contract (the one rank 0 stamps into tezip_amd.json): ranks whose TEZIP_PA differ
+    are found out in the first all_gather of compress_sharded; an engine without a contract (0: the CPU
+    engines of these tests) takes no part in the comparison."""
+    import torch.multiprocessing as mp
+    mp.spawn(_contract_worker, args=(2, _free_port(), contracts), nprocs=2, join=True)
+
+
 @pytest.mark.parametrize("stage", ["encode_begin", "build_table", "encode_finish", "decode_prepare", "undelta", "reconstruct"])
 def test_a_failing_rank_stops_every_rank(stage):
     """A failure in ANY compute stage between two collectives (not only the first one) reaches the

@@ -57,8 +57,9 @@ def test_compress_records_the_contract_and_uncompress_adopts_it(job, monkeypatch
 
 def test_contradicting_pa_is_refused_with_a_message(job, capsys):
     udir = str(job["tmp"] / "out")
-    with pytest.raises(SystemExit):
+    with pytest.raises(SystemExit) as stop:
         tezip.main(tezip.build_parser().parse_args(["-u", job["mdir"], job["cdir"], udir, "--pa", "1"]))
+    assert stop.value.code == 2                       # a refused decode is not a success
     out = capsys.readouterr().out
     assert "ERROR:" in out and "TZ-PA2" in out and "TZ-PA1" in out
     assert not os.path.exists(udir) or not [f for f in os.listdir(udir) if f.endswith(".png")]
@@ -68,9 +69,21 @@ def test_another_model_is_refused(job, capsys, monkeypatch):
     monkeypatch.delenv("TEZIP_PA", raising=False)
     other = str(job["tmp"] / "other_model")
     weights.save_model(other, FULL, FULL.init_weights(seed=7, bias_scale=0.1), 64, 96)
-    with pytest.raises(SystemExit):
+    with pytest.raises(SystemExit) as stop:
         decompress.run(other, job["cdir"], str(job["tmp"] / "out"), True, False)
+    assert stop.value.code == 2
     assert "not the model" in capsys.readouterr().out
+
+
+def test_refused_decode_ends_the_process_with_status_2(job):
+    """The same refusal seen by a launcher: `python -m tezip_amd.tezip -u ... --pa 1` returns 2, not 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "tezip_amd.tezip", "-u", job["mdir"], job["cdir"], str(job["tmp"] / "out2"), "--pa", "1"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    assert "ERROR:" in r.stdout
 
 
 def test_directory_without_sidecar_decodes_by_the_old_rule(job, monkeypatch):

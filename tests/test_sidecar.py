@@ -74,3 +74,22 @@ def test_reference_decoder_never_opens_it():
     assert "listdir" not in src and "glob" not in src and "scandir" not in src
     for name in ("filename.txt", "key_frame.dat", "entropy.dat"):
         assert name in src
+
+
+def test_a_refused_decode_exits_with_status_2(tmp_path, capsys, monkeypatch):
+    """decompress.adopt_contract: a damaged / contradicting tezip_amd.json ends the run with exit status 2, not the
+    reference's `exit()` (status 0) -- this error class does not exist in the reference.  No context is
+    opened on the way: the refusal comes before any GPU work."""
+    from tezip_amd import decompress
+    monkeypatch.delenv("TEZIP_PA", raising=False)
+    open(tmp_path / sidecar.NAME, "w").write("{")
+    with pytest.raises(SystemExit) as stop:
+        decompress.adopt_contract(str(tmp_path), W, False)
+    assert stop.value.code == 2 and "damaged" in capsys.readouterr().out
+    sidecar.write(str(tmp_path), 2, W, 256, 256)
+    monkeypatch.setenv("TEZIP_PA", "1")
+    with pytest.raises(SystemExit) as stop:
+        decompress.adopt_contract(str(tmp_path), W, False)
+    assert stop.value.code == 2
+    monkeypatch.setenv("TEZIP_PA", "2")
+    assert decompress.adopt_contract(str(tmp_path), W, False) == 2

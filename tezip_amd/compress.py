@@ -188,22 +188,42 @@ PAYLOAD_CHUNK = 8 << 20  # int16 elements fetched and fed to zstd at a time
 KEY_PREFETCH_BYTES = 256 << 20  # key frames held on the host at once (more than that: streamed one by one)
 
 
-class _Stages:
-    """Stage wall times of compress.run on stderr when TEZIP_TIMING is set (scripts/host_pipeline.py)."""
+STAGE_LOG = None   # a list installed by a caller (bench.py's host_pipeline leg): every run appends (run, stage, seconds)
 
-    def __init__(self):
+
+class _Stages:
+    """Stage wall times of compress.run / decompress.run: on stderr when TEZIP_TIMING is set (scripts/host_pipeline.py),
+    into compress.STAGE_LOG when a caller installed a list there.  `add` records a duration measured elsewhere (a worker
+    thread's: such a stage overlaps the ones marked around it)."""
+
+    def __init__(self, run="compress"):
         self.on = bool(os.environ.get("TEZIP_TIMING"))
+        self.run = run
         self.t0 = self.last = time.perf_counter()
 
-    def mark(self, name):
+    def add(self, name, seconds):
+        if STAGE_LOG is not None:
+            STAGE_LOG.append((self.run, name, float(seconds)))
         if self.on:
             import sys
+            print("[tezip timing] %-34s %7.3f s  (overlapped)" % (name, seconds), file=sys.stderr)
+
+    def mark(self, name, ctx=None):
+        """ctx: the stage queued device work that may still be running -- when (and only when) stage times are wanted,
+        wait for it, so that the time lands on the stage that queued it and not on the next one that synchronises."""
+        if self.on or STAGE_LOG is not None:
+            if ctx is not None:
+                ctx.synchronize()
             now = time.perf_counter()
-            print("[tezip timing] %-34s %7.3f s  (at %.3f s)" % (name, now - self.last, now - self.t0), file=sys.stderr)
+            if STAGE_LOG is not None:
+                STAGE_LOG.append((self.run, name, now - self.last))
+            if self.on:
+                import sys
+                print("[tezip timing] %-34s %7.3f s  (at %.3f s)" % (name, now - self.last, now - self.t0), file=sys.stderr)
             self.last = now
 
 
-def _stream_outputs(ctx, out_dir, nt, H, W, key, table, warm_up, shuffled, pool):
+def _stream_outputs(ctx, out_dir, nt, H, W, key, table, warm_up, shuffled, pool, stages=None):
     """key_frame.dat and entropy.dat (compress.py:271-278, 375-400) from the context-resident frames
     and payload, piece by piece: nothing of size nt*H*W lives on the host."""
     n = nt * H * W * 3
@@ -215,11 +235,15 @@ def _stream_outputs(ctx, out_dir, nt, H, W, key, table, warm_up, shuffled, pool)
         key_frames = {i: ctx.frames_get(i, 1)[0] for i in key_idx}
 
         def key_file():
+            t0 = time.perf_counter()
             with open(os.path.join(out_dir, "key_frame.dat"), mode='wb') as f:
                 sc = zstd.StreamCompressor(f, n, 9, max(1, zstd.default_threads() // 4))
                 for i in range(nt):
                     sc.write(key_frames.get(i, zero))
-                return sc.close()
+                size = sc.close()
+            if stages:
+                stages.add("zstd-9 key_frame.dat (worker)", time.perf_counter() - t0)
+            return size
 
         kf = pool.submit(key_file)
     else:
@@ -242,6 +266,7 @@ def _stream_outputs(ctx, out_dir, nt, H, W, key, table, warm_up, shuffled, pool)
         tail = np.array([-1], dtype=np.int64)
     trailer = np.concatenate([tail, [SHUFFLE_MARK if shuffled else 1, nt, H, W, 3], [warm_up]]).astype(np.int16)
     bufs = [np.empty(min(PAYLOAD_CHUNK, n), np.int16) for _ in range(2)]
+    t_e = time.perf_counter()
     with open(os.path.join(out_dir, "entropy.dat"), mode='wb') as f:
         sc = zstd.StreamCompressor(f, n * 2 + trailer.nbytes, 9, zstd.default_threads())
         for k, off in enumerate(range(0, n, PAYLOAD_CHUNK)):
@@ -250,6 +275,8 @@ def _stream_outputs(ctx, out_dir, nt, H, W, key, table, warm_up, shuffled, pool)
             sc.write(piece)
         sc.write(trailer)
         esize = sc.close()
+    if stages:
+        stages.add("payload fetch + zstd-9 entropy.dat", time.perf_counter() - t_e)
     return kf.result(), esize
 
 
@@ -307,7 +334,7 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
             ctx.frames_put(*head)
             for f0, view in chunks:
                 ctx.frames_put(f0, view)   # pageable ring buffer: free again when the call returns
-            stages.mark("remaining windows decoded + staged")
+            stages.mark("remaining windows decoded + staged", ctx)
             if VERBOSE:
                 ctx.prof_enable(True)
             t0 = time.time()
@@ -318,9 +345,9 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
                     if key[i] and i > PREPROCESS:
                         print("move key point")
                 print("predict:{0}".format(time.time() - t0) + "[sec]")
-            stages.mark("rollout")
+            stages.mark("rollout", ctx)
             _, table, _ = ctx.encode(MODE, BOUND_VALUE, ENTROPY_RUN, payload="resident", shuffle=SHUFFLE)
-            stages.mark("encode (payload resident)")
+            stages.mark("encode (payload resident)", ctx)
             if VERBOSE:
                 prof = ctx.prof_get()
                 print("error_bound:{0}".format(prof["quant"][0] / 1e3) + "[sec]")
@@ -330,7 +357,7 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
                     # the spatial-delta kernel here (timed above), what is left is the host-side sort
                     print("table_create:{0}".format(prof["table_create"][0] / 1e3) + "[sec]")
                     print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
-            _stream_outputs(ctx, OUTPUT_DIR, nt, H, W, key, table if ENTROPY_RUN else None, PREPROCESS, SHUFFLE, pool)
+            _stream_outputs(ctx, OUTPUT_DIR, nt, H, W, key, table if ENTROPY_RUN else None, PREPROCESS, SHUFFLE, pool, stages)
             doc = sidecar.write(OUTPUT_DIR, ctx.rollout_contract(), wts, hp, wp)   # the contract the predictions were made under
             if VERBOSE:
                 print("arithmetic contract:", doc["arithmetic_contract"])

@@ -3,6 +3,7 @@
 spatial delta (a prefix scan on the GPU instead of the reference's Python loop) and the
 reconstruction run in libtezip_hip.so."""
 import os
+import sys
 import time
 
 import numpy as np
@@ -50,13 +51,15 @@ TAIL_ELEMS = _lib.TZ_NBINS + 8  # the longest trailer: table (<= 2111 symbols) +
 
 def adopt_contract(DATA_DIR, wts, VERBOSE):
     """The arithmetic contract this directory must be decoded under (tezip_amd/sidecar.py): the one tezip_amd.json
-    records; without that file --pa / TEZIP_PA, else None = by frame size.  A contradiction ends the run like the
-    reference's own input errors do (message + exit)."""
+    records; without that file --pa / TEZIP_PA, else None = by frame size.  A contradiction (a --pa that disagrees with the
+    sidecar, another model's weights, a damaged tezip_amd.json) ends the run with a message and EXIT STATUS 2: this error
+    class has no counterpart in the reference, so its `print` + `exit()` habit (status 0) is not mirrored -- a launcher
+    must not see success when no frame was written."""
     try:
         contract = sidecar.resolve(sidecar.read(DATA_DIR), wts)
     except sidecar.SidecarMismatch as e:
         print("ERROR:", e)
-        exit()
+        sys.exit(2)
     if VERBOSE and contract:
         print("arithmetic contract: TZ-PA%d" % contract)
     return contract
@@ -70,7 +73,8 @@ def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shap
     (this build's opt-in byte-shuffled payload)."""
     from concurrent.futures import ThreadPoolExecutor
     from PIL import Image
-    from .compress import io_threads
+    from .compress import _Stages, io_threads
+    stages = _Stages("decompress")
     paths = {n: os.path.join(DATA_DIR, n) for n in ("key_frame.dat", "entropy.dat")}
     for n in ("key_frame.dat", "entropy.dat"):
         if not os.path.exists(paths[n]):
@@ -81,6 +85,7 @@ def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shap
         ctx.load_model(cfg, wts)
         if contract:
             ctx.set_contract(contract)
+        stages.mark("context + model load")
         tail = np.zeros(0, np.int16)
         total = off = 0
         with open(paths["entropy.dat"], "rb") as f:
@@ -98,6 +103,7 @@ def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shap
                 tail = np.concatenate([tail, p16[-TAIL_ELEMS:]])[-TAIL_ELEMS:]
         if off != total:
             raise ValueError("entropy.dat: truncated stream")
+        stages.mark("zstd-d entropy.dat + stage to HBM", ctx)
         warm_up, shape, tlen = int(tail[-1]), tuple(int(v) for v in tail[-6:-1]), int(tail[-7])
         if tlen < -1 or tlen > tail.size - 7:
             raise ValueError("corrupt table length %d" % tlen)
@@ -122,6 +128,7 @@ def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shap
             print("number of images", nt)
             exit()
         ctx.prepare(hp, wp, 64 if nt > 64 else max(1, nt))
+        stages.mark("model prepare")
         fb = H * W * C
         per = max(1, (16 << 20) // fb)
         ctx.frames_begin(nt, H, W)
@@ -133,13 +140,16 @@ def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shap
                 first += k
         if first != nt:
             raise ValueError("key_frame.dat: truncated stream")
+        stages.mark("zstd-d key_frame.dat + stage to HBM", ctx)
         if VERBOSE:
             ctx.prof_enable(True)
         t0 = time.time()
         ctx.rollout_decode(None, warm_up)
         if VERBOSE:
             print("predict:{0}".format(time.time() - t0) + "[sec]")
+        stages.mark("rollout (decoder)", ctx)
         ctx.decode(None, table, out="resident")
+        stages.mark("decode tail (frames resident)", ctx)
         if VERBOSE:
             prof = ctx.prof_get()
             if table is not None:
@@ -164,6 +174,7 @@ def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shap
             for fs in busy:
                 for ft in fs:
                     ft.result()
+        stages.mark("frames fetch + PNG encode")
     finally:
         ctx.close()
     return True
@@ -175,8 +186,9 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
         exit()
     job = tzdist.active()
     rank0 = job is None or job[0] == 0
-    if rank0 and not os.path.exists(OUTPUT_DIR):
-        os.mkdir(OUTPUT_DIR)
+    # every rank of a sharded job writes the images of its own windows: each makes the directory (on one node they race for
+    # the same one, hence exist_ok; on node-local paths each node gets its share -- INTEGRATION.md section 3)
+    os.makedirs(OUTPUT_DIR, exist_ok=True)
     isRGB = True
     try:
         with open(os.path.join(DATA_DIR, 'filename.txt'), 'r', encoding='UTF-8') as f:
@@ -260,8 +272,8 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
         Image.fromarray(frames[j]).save(os.path.join(OUTPUT_DIR, file_names[first + j]))
 
     if job:
-        # the output directory was made by rank 0 before anything else; the ranks meet once more so that none returns
-        # (and the launcher none reports success) before every file is written -- or learns that a rank could not
+        # the ranks meet once more so that none returns (and the launcher none reports success) before every file is
+        # written -- or learns that a rank could not
         import torch.distributed as dist
         err = None
         try:

@@ -72,6 +72,10 @@ class HipEngine:
         hist, first, last = self.ctx.encode_begin(mode, bound, entropy)
         return key, hist, first, last
 
+    def contract(self):
+        """The arithmetic contract (1 = TZ-PA1, 2 = TZ-PA2) this rank's predictions were made under."""
+        return int(self.ctx.rollout_contract())
+
     def encode_finish(self, carry, table):
         nt, h, w = self.ctx._shape
         y = self._new(nt * h * w * 3, self.torch.int16)
@@ -318,15 +322,17 @@ def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True,
     shards = plan_shards(nt, warm_up, window, world)
     f0, f1 = shards[rank]
     klen = max(b - a for a, b in shards)
-    ok, err, key, hist, first, last, fe = 1, None, np.zeros(0, bool), None, 0, 0, 0
+    ok, err, key, hist, first, last, fe, pa = 1, None, np.zeros(0, bool), None, 0, 0, 0, 0
     try:
         if f1 > f0:
             mine = fetch(f0, f1)
             fe = int(np.prod(mine.shape[1:]))
             key, hist, first, last = engine.encode_begin(mine, warm_up if rank == 0 else 0, window, mode, bound, entropy)
+            if hasattr(engine, "contract"):
+                pa = engine.contract()
     except Exception as e:  # the other ranks are about to enter a collective: tell them
         ok, err = 0, e
-    head = [ok, int(f1 > f0 and ok), int(last), fe]
+    head = [ok, int(f1 > f0 and ok), int(last), fe, pa]
     kpad = np.zeros(klen, np.int64)
     kpad[: len(key)] = np.asarray(key, np.int64)
     infos = _all_gather_i64(head + kpad.tolist(), dist)
@@ -334,6 +340,12 @@ def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True,
         raise err
     _raise_if_any_failed([int(i[0]) for i in infos], "window-sharded encode")
     fe = max(int(i[3]) for i in infos)
+    # one stream, one arithmetic contract: the decoder replays every window under the contract rank 0 stamps into
+    # tezip_amd.json, so a rank whose TEZIP_PA differs would have written windows nobody can regenerate
+    pas = sorted({int(i[4]) for i in infos if int(i[1]) and int(i[4])})
+    if len(pas) > 1:
+        raise RuntimeError("the ranks of this job predicted under different arithmetic contracts %s "
+                           "(TEZIP_PA / --pa must agree on every rank)" % ["TZ-PA%d" % v for v in pas])
     carry = None
     for r in range(rank - 1, -1, -1):
         if infos[r][1]:
@@ -377,7 +389,7 @@ def compress_sharded(engine, frames, warm_up, window, mode, bound, entropy=True,
             raise err
         raise
     gather = _gather_shards_begin(engine, y, [(b - a) * fe * 2 for a, b in shards], dist, self_p2p=self_p2p)
-    keys = np.concatenate([np.asarray(i[4: 4 + (b - a)]) for i, (a, b) in zip(infos, shards)]).astype(bool)
+    keys = np.concatenate([np.asarray(i[5: 5 + (b - a)]) for i, (a, b) in zip(infos, shards)]).astype(bool)
     pending = PendingCompress(gather, rank, table, keys, to_host)
     return pending.wait() if wait else pending
 
