@@ -896,7 +896,8 @@ def configs_leg(job, ctx, cfg, frames3, dev):
     resident (frames in HBM, payload into HBM, table on the host), every result decoded again and checked:
       cfg1  64x64 moving blobs, 40 frames, -w 20, lossless          (configs[0])
       cfg2  128x160 KITTI-like, 40 frames, -w 10, lossless          (configs[1])
-      cfg5_dwp  512x512 turbulence, 80 frames, DWP (-t inside the observed window-MSE range), lossless   (configs[4])"""
+      cfg5_dwp  512x512 turbulence, 80 frames, DWP (-t inside the observed window-MSE range), lossless   (configs[4])
+      cfg4_dwp  1024x1024 detector frames, 80 frames, DWP (one window at a time, B = 1 steps), lossless  (configs[3]'s data under -t)"""
     from tezip_amd import synth
     out = {}
 
@@ -935,6 +936,14 @@ def configs_leg(job, ctx, cfg, frames3, dev):
     thr = float(mse[16])           # the window MSE of compress.py:246 reaches it after about 16 frames
     run("cfg5_dwp", frames3, None, thr, 1, 3)
     out["cfg5_dwp"]["threshold"] = thr
+    # cfg4's frames under -t: B = 1 steps at 1024x1024 (the "E-part ahead" decision outside 512x512)
+    f4 = detector_cuda(0, 80, 1024, 1024, 4, dev)
+    ctx.prepare(1024, 1024, 1)
+    _, mse4 = ctx.rollout(f4[:41], 0, None, 1e9, want_mse=True)
+    thr4 = float(mse4[16])
+    run("cfg4_dwp", f4, None, thr4, 1, 2)
+    out["cfg4_dwp"]["threshold"] = thr4
+    del f4
     return out
 
 

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""the "E-part ahead" rule (tz_prednet.hip) outside 512x512.  One process per (shape, batch, TEZIP_EPART)
-cell -- the switch is read when the context is made -- each timing an SWP rollout of `batch` windows of 20 steps, best of 5,
-and reporting how many k_wino launches a step made (5 fused, 7 split at the reference's four levels).
+"""the "E-part ahead" rule (tz_prednet.hip) outside 512x512.  One process per TEZIP_EPART setting -- the
+switch is read when the context is made -- each timing, for every (shape, batch), an SWP rollout of `batch` windows of 20
+steps (best of 5) and counting the k_wino launches a step made (5 fused, 7 split at the reference's four levels).  Shapes below
+256x256 pixels run under TEZIP_PA=2 (by default they take TZ-PA1, which has no k_wino launches to split).
 
-  python scripts/epart_shapes.py cell H W batch        # one cell (TEZIP_EPART from the environment)
-  python scripts/epart_shapes.py                       # the table: every shape x batch x {0, default, 1}
+  python scripts/epart_shapes.py mode        # every shape under the TEZIP_EPART of the environment
+  python scripts/epart_shapes.py             # the table: fused (0) vs default vs forced (1)
 """
 import os
 import subprocess
@@ -14,12 +15,14 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SHAPES = [(1024, 1024, 1), (376, 1248, 1), (256, 256, 1), (256, 256, 2), (256, 256, 3), (256, 256, 4),
-          (512, 512, 1), (512, 512, 2), (512, 512, 3), (512, 512, 4), (128, 160, 1), (1024, 1024, 2)]
+SHAPES = [(64, 64, 1), (64, 64, 4), (128, 160, 1), (128, 160, 4), (128, 160, 8), (192, 192, 1), (192, 192, 4),
+          (256, 256, 1), (256, 256, 2), (256, 256, 3), (256, 256, 4), (256, 256, 5), (256, 256, 6), (256, 512, 1), (256, 512, 2),
+          (384, 384, 1), (384, 384, 2), (384, 384, 3), (376, 1248, 1), (512, 512, 1), (512, 512, 2), (512, 512, 3), (512, 512, 4),
+          (720, 1280, 1), (1024, 1024, 1)]
 STEPS = 20
 
 
-def cell(h, w, batch):
+def mode():
     import numpy as np
     import torch
     from tezip_amd import _lib
@@ -27,52 +30,53 @@ def cell(h, w, batch):
     cfg = PredNetConfig()
     ctx = _lib.Context(0)
     ctx.load_model(cfg, cfg.init_weights(seed=123))
-    ctx.prepare(_lib.pad8(h), _lib.pad8(w), batch)
-    nt = STEPS * batch
     rng = np.random.default_rng(5)
-    f = torch.from_numpy(rng.integers(0, 256, (nt, h, w, 3), dtype=np.uint8)).cuda()
-    ctx.prof_enable(True)
-    ctx.prof_reset()
-    ctx.rollout(f, 0, STEPS)
-    launches = ctx.prof_get()["wino_pa2"][1]
-    ctx.prof_enable(False)
-    for _ in range(2):
+    for h, w, batch in SHAPES:
+        ctx.prepare(_lib.pad8(h), _lib.pad8(w), batch)
+        ctx.set_contract(2)
+        nt = STEPS * batch
+        f = torch.from_numpy(rng.integers(0, 256, (nt, h, w, 3), dtype=np.uint8)).cuda()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
         ctx.rollout(f, 0, STEPS)
-    best = 1e9
-    for _ in range(5):
-        t0 = time.perf_counter()
-        ctx.rollout(f, 0, STEPS)
-        best = min(best, time.perf_counter() - t0)
+        launches = ctx.prof_get()["wino_pa2"][1]
+        ctx.prof_enable(False)
+        for _ in range(2):
+            ctx.rollout(f, 0, STEPS)
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ctx.rollout(f, 0, STEPS)
+            best = min(best, time.perf_counter() - t0)
+        print("CELL %d %d %d %.3f %d" % (h, w, batch, best * 1e3, launches), flush=True)
+        del f
     ctx.close()
-    print("CELL %d %d %d %s %.3f %d" % (h, w, batch, os.environ.get("TEZIP_EPART", "default"), best * 1e3, launches), flush=True)
 
 
 def main():
-    if len(sys.argv) == 5 and sys.argv[1] == "cell":
-        return cell(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
-    rows = []
+    if len(sys.argv) == 2 and sys.argv[1] == "mode":
+        return mode()
+    res = {}
+    for m in ("0", None, "1"):
+        env = dict(os.environ)
+        env.pop("TEZIP_EPART", None)
+        if m is not None:
+            env["TEZIP_EPART"] = m
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "mode"], env=env, capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            print("TEZIP_EPART=%s failed:\n%s" % (m, r.stderr[-2000:]), flush=True)
+            return 1
+        for ln in r.stdout.splitlines():
+            if ln.startswith("CELL"):
+                _, h, w, b, ms, launches = ln.split()
+                res[(int(h), int(w), int(b), m)] = (float(ms), int(launches))
+    print("| frame | windows | fused ms | default ms | default is | default vs fused | forced split ms | forced vs fused | k_wino launches per step fused / default / forced |")
+    print("|---|---|---|---|---|---|---|---|---|")
     for h, w, b in SHAPES:
-        res = {}
-        for mode in ("0", None, "1"):
-            env = dict(os.environ)
-            env.pop("TEZIP_EPART", None)
-            if mode is not None:
-                env["TEZIP_EPART"] = mode
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "cell", str(h), str(w), str(b)], env=env,
-                               capture_output=True, text=True, timeout=600)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith("CELL")]
-            if r.returncode != 0 or not line:
-                print("cell %dx%d B=%d EPART=%s failed:\n%s" % (h, w, b, mode, r.stderr[-1500:]), flush=True)
-                return 1
-            _, _, _, _, _, ms, launches = line[-1].split()
-            res[mode] = (float(ms), int(launches))
-        per_step = 19 * 1   # predictor steps of one rollout (windows run side by side)
-        fused, dflt, forced = res["0"], res[None], res["1"]
-        engaged = dflt[1] != fused[1]
-        rows.append((h, w, b, fused[0], dflt[0], forced[0], engaged, fused[1] // per_step, forced[1] // per_step))
-        print("%4dx%-4d B=%d  fused %8.3f ms  default %8.3f ms (%s, %+5.1f %%)  forced %8.3f ms (%+5.1f %%)   k_wino launches/step fused %d forced %d"
-              % (h, w, b, fused[0], dflt[0], "SPLIT" if engaged else "fused", (fused[0] / dflt[0] - 1) * 100, forced[0],
-                 (fused[0] / forced[0] - 1) * 100, fused[1] // per_step, forced[1] // per_step), flush=True)
+        fused, dflt, forced = res[(h, w, b, "0")], res[(h, w, b, None)], res[(h, w, b, "1")]
+        print("| %dx%d | %d | %.3f | %.3f | %s | %+.1f %% | %.3f | %+.1f %% | %d / %d / %d |"
+              % (h, w, b, fused[0], dflt[0], "split" if dflt[1] != fused[1] else "fused", (fused[0] / dflt[0] - 1) * 100, forced[0],
+                 (fused[0] / forced[0] - 1) * 100, fused[1] // 19, dflt[1] // 19, forced[1] // 19), flush=True)
     return 0
 
 

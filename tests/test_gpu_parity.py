@@ -425,6 +425,20 @@ CASES = [
     (8, 16, 8, 0, None, 0.0, "abs", [0.0], True),     # DWP threshold 0: every prediction is rejected
     (8, 16, 8, 1, None, 1e9, "rel", [0.05], True),    # DWP threshold never reached: one window
     (5, 8, 8, 0, 2, None, "absrel", [0.0, 0.5], True),  # absrel with abs bound 0: lossless shortcut
+    # round 6: tolerances that cannot merge two different deltas run as an ELEMENTWISE map inside the fused lossless kernel
+    # (k_delta_sd_fused<.., QMAP>, E <= 0.499), unpadded frames only; the value of a run of equal deltas d is
+    # trunc((fl(d+E) + fl(d-E)) / 2), which is not always d.  Compared below with the oracle AND with the general
+    # quantiser (the delta tap takes tzk_error_bound)
+    (10, 16, 24, 0, 4, None, "abs", [0.3], True),
+    (10, 16, 24, 2, 3, None, "abs", [0.255], True),      # warm-up frames: not quantised, non-zero deltas pass through
+    (9, 64, 64, 1, 4, None, "abs", [0.499], True),       # the last tolerance the map takes
+    (9, 64, 64, 0, 4, None, "abs", [0.4995], True),      # ... and the first one the general quantiser keeps
+    (10, 16, 24, 0, 5, None, "rel", [1e-3], True),       # BASELINE.json cfg3's bound: E = range * 1e-3 <= 0.255 per chain
+    (10, 32, 40, 2, 4, None, "rel", [0.00195], False),   # 255 * b = 0.497
+    (8, 16, 24, 0, None, "auto", "rel", [1e-3], True),   # DWP
+    (9, 16, 24, 0, 4, None, "absrel", [0.4, 0.9], True),
+    (9, 16, 24, 1, 4, None, "absrel", [3.0, 0.001], True),
+    (6, 16, 16, 0, 3, None, "abs", [1e-300], True),      # E so small that d + E == d: still not the lossless shortcut
 ]
 
 

@@ -243,6 +243,7 @@ extern "C" int tz_ctx_destroy(tz_ctx* ctx) {
     for (int l = 0; l < TZ_MAX_LEVELS; ++l) {
         if (ctx->ev_epart_src[l]) (void)hipEventDestroy(ctx->ev_epart_src[l]);
         if (ctx->ev_epart_done[l]) (void)hipEventDestroy(ctx->ev_epart_done[l]);
+        if (l < 2 && ctx->ev_cal[l]) (void)hipEventDestroy(ctx->ev_cal[l]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);

@@ -92,6 +92,7 @@ struct tz_ctx {
     // "E-part ahead" (round 5, tz_model_predict_batch_dev): per level, E_l ready on the compute stream / the launch over it
     // finished on stream2
     hipEvent_t ev_epart_src[TZ_MAX_LEVELS] = {nullptr}, ev_epart_done[TZ_MAX_LEVELS] = {nullptr};
+    hipEvent_t ev_cal[2] = {nullptr, nullptr};   // epart_measure: timing events on the compute stream (tz_prednet.hip)
     int epart_mode = -1;              // TEZIP_EPART: -1 where launches cannot fill the chip (default), 0 never, 1 wherever possible
     static constexpr int kStages = 4;
     static constexpr size_t kStageBytes = (size_t)8 << 20;

@@ -54,6 +54,8 @@ struct tz_model {
     float *G0f[TZ_MAX_LEVELS] = {0}, *C0f[TZ_MAX_LEVELS] = {0};  // G0 / C0 in accumulator-fragment order (k_to_fragments)
     float *E[TZ_MAX_LEVELS] = {0}, *R1[TZ_MAX_LEVELS] = {0};
     float* P[TZ_MAX_LEVELS] = {0};   // gate accumulators after the E_l part of the chain (split launches of small grids), or null
+    int Pcap[TZ_MAX_LEVELS] = {0};   // ... how many batch slots P[l] holds (<= maxB: at most kPBytes per level)
+    std::vector<signed char> epart_choice;   // [n]: "E-part ahead" for batches of n items: -1 not measured yet, 0 fused, 1 split
     PackedConv a_conv[TZ_MAX_LEVELS], gate_t1[TZ_MAX_LEVELS], ahat0_t1;
     float* d_zero = nullptr;  // zero page for LDS-DMA halo pixels
     int e0s = 0;              // floats per pixel of E[0]: 2*stack[0] rounded up to 8 (k_conv16b reads 16-byte quads)
@@ -394,6 +396,9 @@ static int launch_wino(tz_ctx* ctx, int NT, int epi, bool ups, const ConvArgs& a
 // encoder and decoder both know: TZ-PA2 from 256 x 256 pixels on, TZ-PA1 below (there the per-frame convolutions are
 // latency chains on a mostly idle chip and run on k_convlat).
 static constexpr long long TZ_PA2_MIN_PIXELS = 256 * 256;
+static constexpr size_t kPBytes = (size_t)160 << 20;      // P[l]: at most this much per level (tz_model_prepare)
+static constexpr double kEpartMinIdle = 0.06;   // "E-part ahead": below this idle share of a step's k_wino launches the split is not even tried
+static constexpr float kEpartMinGain = 0.98f;   // ... and it is kept only where it measures at least 2 % faster than the fused step
 static int effective_contract(const tz_ctx* ctx) {
     if (ctx->contract) return ctx->contract;
     const tz_model* m = ctx->model;
@@ -674,6 +679,7 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
     m->Wp = Wp;
     m->maxB = max_batch;
     m->cap = max_batch;
+    m->epart_choice.assign((size_t)max_batch + 1, (signed char)-1);
     auto hl = [&](int l) { return Hp >> l; };
     auto wl = [&](int l) { return Wp >> l; };
     for (int l = 0; l < L; ++l) {
@@ -686,9 +692,18 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         TZ_TRY(dmalloc(ctx, m, (void**)&m->E[l], (size_t)max_batch * npx * ec * 4));
         TZ_TRY(dmalloc(ctx, m, (void**)&m->R1[l], (size_t)max_batch * npx * R * 4));
         // split gate launches (small grids only, see tz_model_predict_batch_dev): [item][pixel][4R] accumulators
-        // (also the hand-over buffer of a gate convolution that runs as two k_wino launches: "E-part ahead" below)
-        if (l >= 1 && l < L - 1 && (size_t)max_batch * npx * 4 * R * 4 <= ((size_t)160 << 20))
-            TZ_TRY(dmalloc(ctx, m, (void**)&m->P[l], (size_t)max_batch * npx * 4 * R * 4));
+        // (also the hand-over buffer of a gate convolution that runs as two k_wino launches: "E-part ahead" below).
+        // As many batch slots as fit kPBytes, whatever max_batch is (until round 5: all of max_batch or nothing, so a
+        // context prepared for many windows never split its trailing small batches): a batch of n items uses the buffer
+        // only where n <= Pcap[l], and "E-part ahead" only while the hand-over stays cache-resident (see there).
+        if (l >= 1 && l < L - 1) {
+            const size_t per_item = npx * 4 * R * 4;
+            const int slots = (int)std::min<size_t>((size_t)max_batch, kPBytes / per_item);
+            if (slots >= 1) {
+                TZ_TRY(dmalloc(ctx, m, (void**)&m->P[l], (size_t)slots * per_item));
+                m->Pcap[l] = slots;
+            }
+        }
     }
     TZ_TRY(dmalloc(ctx, m, (void**)&m->d_idx, sizeof(int) * 3 * max_batch));
     TZ_TRY(dmalloc(ctx, m, (void**)&m->d_zero, 256));
@@ -819,12 +834,121 @@ int tz_model_predict_batch(tz_ctx* ctx, int n, const int* h_in_is_key, const int
 
 // Launch-only form: d_idx holds [is_key | in_idx | out_idx], each `stride` ints apart, already
 // on the device.  Nothing here allocates or copies.
+// Which levels CAN run their gate convolution as two launches for a batch of n items (structure only), and how much of the
+// chip the step's k_wino launches leave idle: a launch of `items` workgroup-items of `stages` stages each takes
+// ceil(items / CUs) rounds of them.
+static bool epart_levels(tz_ctx* ctx, tz_model* m, int n, bool* lv, double* idle) {
+    const int L = m->L;
+    for (int l = 0; l < TZ_MAX_LEVELS; ++l) lv[l] = false;
+    *idle = 0.0;
+    if (!(effective_contract(ctx) == 2 && ctx->conv_impl && ctx->stream2 && !ctx->split_rollout)) return false;
+    auto hl = [&](int l) { return m->Hp >> l; };
+    auto wl = [&](int l) { return m->Wp >> l; };
+    double busy = 0.0, span = 0.0;
+    for (int l = 1; l < L; ++l) {   // the k_wino launches of a step: the gates of level l and A_l (l < L - 1)
+        const long long tiles = (long long)((hl(l) + 15) / 16) * ((wl(l) + 15) / 16) * n;
+        const int s_e = (2 * m->stack[l]) / 4, s_u = l < L - 1 ? m->rstack[l + 1] / 4 : 0;
+        const long long it[2] = {m->gate_t1[l].d_Wwino ? tiles * m->gate_t1[l].ncb : 0,
+                                 l < L - 1 && m->a_conv[l].d_Wwino ? tiles * m->a_conv[l].ncb : 0};
+        const int st[2] = {s_e + s_u, s_e};
+        for (int k = 0; k < 2; ++k) {
+            if (!it[k]) continue;
+            busy += (double)it[k] / ctx->num_cus * st[k];
+            span += (double)((it[k] + ctx->num_cus - 1) / ctx->num_cus) * st[k];
+        }
+    }
+    if (span > 0.0) *idle = 1.0 - busy / span;
+    bool any = false;
+    for (int l = 1; l < L - 1; ++l) {
+        lv[l] = m->P[l] && n <= m->Pcap[l] && m->gate_t1[l].d_Wwino && m->gate_t1[l].NT == 4 && m->gate_t1[l].segs.size() == 2 &&
+                (m->rstack[l + 1] % 16) == 0 && (2 * m->stack[l]) % 16 == 0;
+        any = any || lv[l];
+    }
+    return any;
+}
+
+static int predict_batch_impl(tz_ctx* ctx, int n, const int* d_idx, int stride, const uint8_t* d_frames_u8, int H, int W,
+                              const float* d_in_stack, float* d_out_stack, int slot0, const int* d_next_slot, bool skip_err0,
+                              bool* fused_next, bool err0_keys_only, bool use_epart);
+
+// "E-part ahead" by measurement (round 6).  Rounds 5's rule -- split where the step's k_wino launches leave >= 10 % of the
+// chip idle -- was calibrated at 512x512 only and is wrong elsewhere in both directions (profiles/r06/epart_shapes.md: 256x256
+// one window +16 % left unused, 384x384 two windows -4.7 % taken, 256x256 five windows -7 % / six windows +14 %: whether the
+// side workgroups land on CUs the critical path is about to ask for depends on how every launch's last round falls, and on
+// the command processor's handling of stream priorities, which HIP does not promise).  So the first call for a batch size
+// n of a prepared model MEASURES: the same step -- a pure function of its inputs when the level-0 error maps are formed
+// here (skip_err0 off) -- runs fused and split, one untimed and two timed passes each, HIP events on the compute stream,
+// and the split is kept for that n where it is at least 2 % faster.  Both forms give the same bits (tests/test_gpu_epart.py),
+// so the outcome of the measurement never shows in the results; it costs six extra steps once per (prepare, n).
+// TEZIP_EPART=0 / 1 still forbid / force it.  Not tried at all where the idle share is under 6 % (every such case measured
+// slower) or no level can split.
+static int epart_measure(tz_ctx* ctx, int n, const int* d_idx, int stride, const uint8_t* d_frames_u8, int H, int W,
+                         const float* d_in_stack, float* d_out_stack, int slot0, const int* d_next_slot, int* choice) {
+    if (!ctx->ev_cal[0]) {
+        TZ_HIP(ctx, hipEventCreate(&ctx->ev_cal[0]));
+        TZ_HIP(ctx, hipEventCreate(&ctx->ev_cal[1]));
+    }
+    const bool prof = ctx->prof_on;
+    ctx->prof_on = false;                        // (the measurement's launches are not the caller's)
+    float best[2] = {1e30f, 1e30f};
+    int rc = TZ_OK;
+    for (int rep = 0; rep < 3 && rc == TZ_OK; ++rep)
+        for (int mode = 0; mode < 2 && rc == TZ_OK; ++mode) {
+            bool dummy;
+            hipError_t e = hipEventRecord(ctx->ev_cal[0], ctx->stream);
+            rc = predict_batch_impl(ctx, n, d_idx, stride, d_frames_u8, H, W, d_in_stack, d_out_stack, slot0, d_next_slot, false,
+                                    &dummy, false, mode == 1);
+            if (e == hipSuccess) e = hipEventRecord(ctx->ev_cal[1], ctx->stream);
+            if (e == hipSuccess) e = hipEventSynchronize(ctx->ev_cal[1]);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev_cal[0], ctx->ev_cal[1]);
+            if (e != hipSuccess && rc == TZ_OK) rc = tz_fail(ctx, TZ_ERR_HIP, "E-part measurement: %s", hipGetErrorString(e));
+            if (rep > 0) best[mode] = std::min(best[mode], ms);
+        }
+    ctx->prof_on = prof;
+    *choice = best[1] < kEpartMinGain * best[0] ? 1 : 0;
+    if (getenv("TEZIP_EPART_LOG"))
+        fprintf(stderr, "[tezip] E-part ahead, %dx%d batch %d: fused %.1f us, split %.1f us -> %s\n", ctx->model->Hp, ctx->model->Wp, n,
+                best[0] * 1e3f, best[1] * 1e3f, *choice ? "split" : "fused");
+    return rc;
+}
+
 int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride, const uint8_t* d_frames_u8, int H, int W,
                                const float* d_in_stack, float* d_out_stack, int slot0, const int* d_next_slot, bool skip_err0,
                                bool* fused_next, bool err0_keys_only) {
     tz_model* m = ctx->model;
     if (!m || !m->prepared) return tz_fail(ctx, TZ_ERR_STATE, "model not prepared");
     if (n < 1 || slot0 < 0 || slot0 + n > m->maxB) return tz_fail(ctx, TZ_ERR_INVALID, "batch %d at slot %d outside 1..%d", n, slot0, m->maxB);
+    bool use = ctx->epart_mode == 1;
+    if (ctx->epart_mode < 0) {
+        bool lv[TZ_MAX_LEVELS];
+        double idle;
+        if (!epart_levels(ctx, m, n, lv, &idle)) {
+            use = false;                                       // (depends on the contract in force: not cached)
+        } else {
+            if (m->epart_choice[n] < 0) {
+                if (idle < kEpartMinIdle) {
+                    m->epart_choice[n] = 0;
+                } else {
+                    int choice = 0;
+                    TZ_TRY(epart_measure(ctx, n, d_idx, stride, d_frames_u8, H, W, d_in_stack, d_out_stack, slot0, d_next_slot, &choice));
+                    m->epart_choice[n] = (signed char)choice;
+                    // the measurement's last pass left the NEXT step's level-0 error maps where this step's were: form them again
+                    skip_err0 = false;
+                    err0_keys_only = false;
+                }
+            }
+            use = m->epart_choice[n] == 1;
+        }
+    }
+    return predict_batch_impl(ctx, n, d_idx, stride, d_frames_u8, H, W, d_in_stack, d_out_stack, slot0, d_next_slot, skip_err0, fused_next,
+                              err0_keys_only, use);
+}
+
+static int predict_batch_impl(tz_ctx* ctx, int n, const int* d_idx, int stride, const uint8_t* d_frames_u8, int H, int W,
+                              const float* d_in_stack, float* d_out_stack, int slot0, const int* d_next_slot, bool skip_err0,
+                              bool* fused_next, bool err0_keys_only, bool use_epart) {
+    tz_model* m = ctx->model;
     const int L = m->L, Hp = m->Hp, Wp = m->Wp;
     auto hl = [&](int l) { return Hp >> l; };
     auto wl = [&](int l) { return Wp >> l; };
@@ -880,38 +1004,12 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
     // own on stream2 as soon as E_l exists, leaves every chain as it stands behind the output transform in P_l (float32, what
     // the fused kernel holds in registers at that point), and the launch on the critical path starts from P_l and walks the
     // upsampled source only.  Same chains, same order, same bits; the workgroups of the side launch fill the CUs the
-    // critical path leaves idle.  At B = 4 (cfg3) every launch is a whole number of chip-rounds: off.
+    // critical path leaves idle.  At B = 4 (cfg3) every launch is a whole number of chip-rounds: off.  WHERE it pays is
+    // measured, not predicted: tz_model_predict_batch_dev / epart_measure above.
     bool epart[TZ_MAX_LEVELS] = {false};
-    if (effective_contract(ctx) == 2 && ctx->conv_impl && ctx->stream2 && !ctx->split_rollout && ctx->epart_mode != 0) {
-        // How much of the chip the step's k_wino launches leave idle: a launch of `items` workgroup-items of `stages` stages
-        // each takes ceil(items / CUs) rounds of them.  Measured at 512x512 (scripts/b1_time.py): one window 16 % idle -> the
-        // split gains 4.7 %; three windows 10.5 % -> 2.1 %; two windows 7.5 % -> it LOSES 1.8 % (the side launches cost their own
-        // prologues, epilogues and 8 B per gate column and pixel); four windows 0 %.
-        bool underfilled = ctx->epart_mode == 1;
-        if (!underfilled) {
-            double busy = 0.0, span = 0.0;
-            for (int l = 1; l < L; ++l) {   // the k_wino launches of a step: the gates of level l and A_l (l < L - 1)
-                const long long tiles = (long long)((hl(l) + 15) / 16) * ((wl(l) + 15) / 16) * n;
-                const int s_e = (2 * m->stack[l]) / 4, s_u = l < L - 1 ? m->rstack[l + 1] / 4 : 0;
-                const long long it[2] = {m->gate_t1[l].d_Wwino ? tiles * m->gate_t1[l].ncb : 0,
-                                         l < L - 1 && m->a_conv[l].d_Wwino ? tiles * m->a_conv[l].ncb : 0};
-                const int st[2] = {s_e + s_u, s_e};
-                for (int k = 0; k < 2; ++k) {
-                    if (!it[k]) continue;
-                    busy += (double)it[k] / ctx->num_cus * st[k];
-                    span += (double)((it[k] + ctx->num_cus - 1) / ctx->num_cus) * st[k];
-                }
-            }
-            underfilled = span > 0.0 && 1.0 - busy / span >= 0.10;
-        }
-        if (underfilled)
-            for (int l = 1; l < L - 1; ++l) {
-                // (by itself only where the side launch is a chip-round or more of work: on smaller grids a step is a chain of
-                // launch latencies, which two more launches do not shorten)
-                const long long items = (long long)((hl(l) + 15) / 16) * ((wl(l) + 15) / 16) * n * m->gate_t1[l].ncb;
-                epart[l] = m->P[l] && m->gate_t1[l].d_Wwino && m->gate_t1[l].NT == 4 && m->gate_t1[l].segs.size() == 2 &&
-                           (m->rstack[l + 1] % 16) == 0 && (2 * m->stack[l]) % 16 == 0 && (ctx->epart_mode == 1 || items >= ctx->num_cus);
-            }
+    if (use_epart) {   // decided by the caller: forced (TEZIP_EPART=1) or measured for this batch size (epart_measure)
+        double idle;
+        epart_levels(ctx, m, n, epart, &idle);
     }
     auto epart_launch = [&](int l) -> int {   // the launch over E_l, on stream2, behind the A convolution that wrote E_l
         if (!ctx->ev_epart_src[l]) {
@@ -952,7 +1050,8 @@ int tz_model_predict_batch_dev(tz_ctx* ctx, int n, const int* d_idx, int stride,
         ConvArgs a;
         aconv_args(l, a);
         // (not under TZ-PA2 where the gate convolution is a k_wino one: the split halves are TZ-PA1 chains)
-        if (m->P[l] && m->gate_t1[l].NT == 4 && m->gate_t1[l].segs.size() == 2 && !(effective_contract(ctx) == 2 && m->gate_t1[l].d_Wwino)) {
+        if (m->P[l] && slot0 + n <= m->Pcap[l] && m->gate_t1[l].NT == 4 && m->gate_t1[l].segs.size() == 2 &&
+            !(effective_contract(ctx) == 2 && m->gate_t1[l].d_Wwino)) {
             ConvArgs ge;
             gate_args(l, ge);
             ge.nsrc = 1;                      // the chain over E_l only
