@@ -456,12 +456,13 @@ def main():
     # kernel" stated for what the timed step runs, not only for the stand-alone tz_delta_encode.  Algorithmic bytes as
     # DESIGN section 5 counts them: through the quantiser 5 in (pred f32 + orig u8) + 2 out (run values) / 2 in + 2 out (fill,
     # spatial delta, offset, histogram -> symbols) / 2 in + 2 out (rank remap) = 15 B per element; where the tolerance
-    # cannot merge two different deltas (E < 0.5: an elementwise map) or the job is lossless, ONE fused pass
-    # 5 in + 2 out, then the remap 2 in + 2 out = 11 B per element.
+    # cannot merge two different deltas (E <= 0.499: an elementwise map, round 6) or the job is lossless, ONE fused pass
+    # 5 in + 2 out, then the remap 2 in + 2 out = 11 B per element (+ 1 B of the original for the per-chain range of
+    # rel / absrel: 12).
     tail_keys = ("delta", "quant", "spatial_delta_hist", "lut_remap")
     tail_ms = sum(prof[k][0] for k in tail_keys if k in prof)
-    tail_through_quantiser = prof.get("quant", (0.0, 0))[1] > 0
-    tail_bpe = 15.0 if tail_through_quantiser else 11.0
+    tail_through_quantiser = prof.get("spatial_delta_hist", (0.0, 0))[1] > 0   # k_q_fill_sym / k_sdelta ran: not the one-pass form
+    tail_bpe = 15.0 if tail_through_quantiser else (12.0 if prof.get("quant", (0.0, 0))[1] > 0 else 11.0)
     tail_bytes = tail_bpe * frames.shape[0] * H * W * 3
     tail_gbs = tail_bytes / (tail_ms * 1e-3) / 1e9 if tail_ms > 0 else 0.0
 
@@ -741,7 +742,8 @@ def main():
             "roofline_encode_tail": {"kernel": "the elementwise tail the timed step launches behind the rollout: "
                                                + ("k_q_tiles + stitch kernels + k_q_fill_sym + k_lut (deltas formed inside the quantiser)"
                                                   if tail_through_quantiser else
-                                                  "k_delta_sd_fused (delta + elementwise bound map + spatial delta + offset + histogram in one pass) + k_lut"),
+                                                  "k_delta_sd_fused (delta + elementwise bound map + spatial delta + offset + histogram in one pass; "
+                                                  "k_q_minmax for the per-chain range of rel) + k_lut"),
                                      "bound": "hbm", "achieved": tail_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": tail_gbs / PEAK_HBM_GBS,
                                      "traffic": None, "bytes_per_element": tail_bpe, "bytes_per_step": tail_bytes,
                                      "ms_per_step": tail_ms, "ms_per_step_by_stage": {k: prof[k][0] for k in tail_keys if k in prof},

@@ -1,8 +1,9 @@
 """'E-part ahead' (round 5, tz_prednet.hip): under TZ-PA2 a gate convolution of a level with an upsampled source can run
 as two k_wino launches -- the same-resolution phase on a second stream as soon as E_l exists (RAW epilogue into P_l), the
 upsampled phase on the critical path starting from P_l (k_wino<..., NOSAME>).  Same chains, same order: every result
-must be bit-identical to the fused launch and to the C oracle's TZ-PA2 statement.  On by itself only where a step's
-launches cannot fill the chip (one window at a time at 512x512); TEZIP_EPART=1 forces it, =0 forbids it."""
+must be bit-identical to the fused launch and to the C oracle's TZ-PA2 statement.  TEZIP_EPART=1 forces it, =0 forbids it;
+by default (round 6) the first step of a batch size MEASURES both forms and keeps the split where it is >= 2 % faster
+(tz_prednet.hip epart_measure; profiles/r06/epart_shapes.md) -- never where the step's launches fill the chip anyway."""
 import numpy as np
 import pytest
 
@@ -56,9 +57,9 @@ def test_forced_split_is_bit_identical_to_the_fused_launch_and_the_oracle(monkey
 
 
 def test_default_engages_at_one_window_of_512_and_not_at_four(monkeypatch):
-    """The heuristic: a step whose k_wino launches leave more than a fifth of a chip-round idle (B = 1 at 512x512: the
-    level-3 gates are 192 workgroups on 256 CUs) splits, the cfg3 bench shape (4 windows: whole rounds everywhere) does not.
-    Either way the rollout equals the C oracle's."""
+    """The measured decision where its outcome is not in doubt: B = 1 at 512x512 (the level-3 gates are 192 workgroups on 256
+    CUs; the split measures +5..6 %) splits, the cfg3 bench shape (4 windows: whole rounds everywhere, nothing idle, never
+    even tried) does not.  Either way the rollout equals the C oracle's; the measurement's own launches are not counted."""
     frames = synth.turbulence(6, 512, 512, seed=9)
     w = FULL.init_weights(seed=123)
     net = coracle.CPredNet(w, FULL.stack_sizes, FULL.R_stack_sizes, 512, 512)
@@ -95,3 +96,38 @@ def test_default_engages_at_one_window_of_512_and_not_at_four(monkeypatch):
         assert c.prof_get()["wino_pa2"][1] == 5
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("hp,wp,batch,expect", [(256, 256, 1, 7), (1024, 1024, 1, 5), (384, 384, 2, None), (256, 256, 5, None)])
+def test_measured_decision_outside_512(monkeypatch, hp, wp, batch, expect):
+    """shapes the round-5 rule was never measured at.  256x256 one window: the split is worth +16 %
+    (the old rule left it off); 1024x1024 one window: whole chip-rounds, fused, not measured at all; 384x384 two windows
+    and 256x256 five windows: the old rule's worst cases (-4.7 %, -7 % when forced) -- whatever the measurement picks
+    there, the predictions are the fused launch's bits, also on the step that ran the measurement."""
+    rng = np.random.default_rng(hp + 3 * batch)
+    w = FULL.init_weights(seed=123)
+    nt, window = 3 * batch, 3
+    frames = rng.integers(0, 256, (nt, hp, wp, 3), dtype=np.uint8)
+    stacks, counts = {}, {}
+    for mode in (0, None):
+        c = _ctx(monkeypatch, mode)
+        try:
+            c.load_model(FULL, w)
+            c.prepare(hp, wp, max_batch=batch)
+            assert c.get_contract() == 2
+            c.prof_enable(True)
+            c.prof_reset()
+            c.rollout(frames, 0, window)              # the first step of the default context measures (prof off meanwhile)
+            counts[mode] = c.prof_get()["wino_pa2"][1]
+            c.prof_enable(False)
+            stacks[mode] = c.get_predictions()
+            c.rollout(frames, 0, window)              # ... the second rollout runs on the cached decision
+            np.testing.assert_array_equal(c.get_predictions(), stacks[mode])
+        finally:
+            c.close()
+    np.testing.assert_array_equal(stacks[None], stacks[0])
+    steps = window - 1
+    assert counts[0] == 5 * steps
+    assert counts[None] in (5 * steps, 7 * steps)
+    if expect is not None:
+        assert counts[None] == expect * steps, counts

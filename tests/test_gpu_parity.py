@@ -435,7 +435,7 @@ CASES = [
     (9, 64, 64, 0, 4, None, "abs", [0.4995], True),      # ... and the first one the general quantiser keeps
     (10, 16, 24, 0, 5, None, "rel", [1e-3], True),       # BASELINE.json cfg3's bound: E = range * 1e-3 <= 0.255 per chain
     (10, 32, 40, 2, 4, None, "rel", [0.00195], False),   # 255 * b = 0.497
-    (8, 16, 24, 0, None, "auto", "rel", [1e-3], True),   # DWP
+    (9, 16, 24, 0, None, "auto", "rel", [1e-3], True),   # DWP (8 window MSEs: their median is no element -- no tie with the threshold)
     (9, 16, 24, 0, 4, None, "absrel", [0.4, 0.9], True),
     (9, 16, 24, 1, 4, None, "absrel", [3.0, 0.001], True),
     (6, 16, 16, 0, 3, None, "abs", [1e-300], True),      # E so small that d + E == d: still not the lossless shortcut

@@ -1203,6 +1203,9 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
         // slot 0 of every group opened on the way holds C0 (258); the last frame keeps its prediction (260-262: k_sse_decide
         // does not flag it)
         if (rc == TZ_OK && nt > 1) {
+            // (gridDim.y = nt: rollout_setup refuses nt > 32767 -- the trailer stores it as int16, compress.py:390-394 -- so
+            // the 65535 limit of a grid's y dimension is never reached)
+            static_assert(32767 <= 65535, "nt limit vs gridDim.y");
             hipLaunchKernelGGL(k_bcast_frames_flagged, dim3(std::min(gx, 128), nt), dim3(256), 0, ctx->stream, c0, fe_pad, (const int*)d_flag, ctx->d_pred);
             if (hipGetLastError() != hipSuccess) rc = tz_fail(ctx, TZ_ERR_HIP, "DWP launch failed");
         }
