@@ -209,7 +209,9 @@ def spawn_ranks(n, argv):
     and the child is a fresh process, not an exec of this one."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    have = torch.cuda.device_count()
+    # (a rehearsal asked for explicitly never counts devices here: on a one-GPU box the pool allows six processes with the
+    # GPU open, and hipGetDeviceCount in this launcher would be one of them)
+    have = 0 if env.get("TEZIP_BENCH_SINGLE_DEVICE") else torch.cuda.device_count()
     if have < n:  # rehearsal on a smaller box: all ranks share GPU 0, gloo carries the exchange
         print("bench.py: %d GPU(s) visible for --gpus %d: rehearsing with all ranks on GPU 0 over gloo" % (have, n),
               file=sys.stderr)

@@ -66,6 +66,9 @@ def main():
         if r.returncode != 0:
             print("TEZIP_EPART=%s failed:\n%s" % (m, r.stderr[-2000:]), flush=True)
             return 1
+        for ln in r.stderr.splitlines():   # TEZIP_EPART_LOG=1: what every measurement saw
+            if ln.startswith("[tezip] E-part"):
+                print(ln, file=sys.stderr, flush=True)
         for ln in r.stdout.splitlines():
             if ln.startswith("CELL"):
                 _, h, w, b, ms, launches = ln.split()
