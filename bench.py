@@ -467,6 +467,11 @@ def main():
     tail_bpe = 15.0 if tail_through_quantiser else (12.0 if prof.get("quant", (0.0, 0))[1] > 0 else 11.0)
     tail_bytes = tail_bpe * frames.shape[0] * H * W * 3
     tail_gbs = tail_bytes / (tail_ms * 1e-3) / 1e9 if tail_ms > 0 else 0.0
+    # counter traffic of the same tail, per step, from the committed PMC passes (the kernels of the form that ran)
+    tail_kernels = (("k_q_minmax", "k_q_tiles<", "k_q_bstitch<", "k_q_chain", "k_q_last", "k_q_fill_sym<", "k_lut") if tail_through_quantiser
+                    else (("k_q_minmax",) if tail_bpe == 12.0 else ()) + ("k_delta_sd_fused<", "k_lut"))
+    tail_parts = [measured_traffic(k) for k in tail_kernels]
+    tail_traffic = sum(tail_parts) if tail_parts and all(v is not None for v in tail_parts) else None
 
     extras = {}
     ratio = None
@@ -747,7 +752,8 @@ def main():
                                                   "k_delta_sd_fused (delta + elementwise bound map + spatial delta + offset + histogram in one pass; "
                                                   "k_q_minmax for the per-chain range of rel) + k_lut"),
                                      "bound": "hbm", "achieved": tail_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": tail_gbs / PEAK_HBM_GBS,
-                                     "traffic": None, "bytes_per_element": tail_bpe, "bytes_per_step": tail_bytes,
+                                     "traffic": tail_traffic, "traffic_kernels": list(tail_kernels),
+                                     "bytes_per_element": tail_bpe, "bytes_per_step": tail_bytes,
                                      "ms_per_step": tail_ms, "ms_per_step_by_stage": {k: prof[k][0] for k in tail_keys if k in prof},
                                      "share_of_step_device_time": tail_ms / max(step_dev_ms, 1e-9)},
             "kernel_ms_per_step": {k: v[0] for k, v in prof.items()},

@@ -99,3 +99,42 @@ def test_dwp_decision_never_reads_a_partial_it_did_not_wait_for():
     env = dict(os.environ, TEZIP_POISON="255")
     out = subprocess.run([sys.executable, "-c", DWP_JOB % ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "dwp ok" in out.stdout, out.stderr[-2000:]
+
+
+ROCTX_JOB = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from tezip_amd import _lib, synth
+from tezip_amd.prednet import PredNetConfig
+cfg = PredNetConfig(stack_sizes=(3, 16, 32))
+ctx = _lib.Context(0)
+ctx.load_model(cfg, cfg.init_weights(seed=5, bias_scale=0.1))
+frames = synth.turbulence(9, 64, 80, seed=2)
+ctx.prepare(64, 80, max_batch=2)
+key, _ = ctx.rollout(frames, 0, 4)
+payload, table, _ = ctx.encode("abs", [2.0], True)
+ctx.rollout_decode(np.where(key[:, None, None, None], frames, 0).astype(np.uint8), 0)
+dec = ctx.decode(payload, table)
+h = hashlib.sha256()
+for a in (key, payload, table, dec):
+    h.update(np.ascontiguousarray(a).tobytes())
+print("digest", h.hexdigest())
+'''
+
+
+def test_roctx_ranges_change_nothing_and_the_library_opens():
+    """TEZIP_ROCTX=1 (SURVEY.md section 5: roctx ranges around the stages): the ROCTx library of this image opens without a
+    warning and the job's results are the ones without it.  (That the ranges show up in a trace is checked where a trace
+    is taken: scripts/gpu_r06_final.sh -> profiles/r06/roctx_ranges.txt.)"""
+    outs = {}
+    for flag in (None, "1"):
+        env = dict(os.environ)
+        env.pop("TEZIP_ROCTX", None)
+        if flag:
+            env["TEZIP_ROCTX"] = flag
+        r = subprocess.run([sys.executable, "-c", ROCTX_JOB % ROOT], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "no ROCTx library" not in r.stderr, r.stderr[-500:]
+        outs[flag] = [ln for ln in r.stdout.splitlines() if ln.startswith("digest")][-1]
+    assert outs[None] == outs["1"]

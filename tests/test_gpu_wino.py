@@ -58,7 +58,8 @@ def test_predictor_bit_exact_vs_the_oracle_under_pa2(ctx, hp, wp, bias):
     ctx.predict_next(frames[:1])
     prof = ctx.prof_get()
     ctx.prof_enable(False)
-    assert prof["wino_pa2"][1] == 5 and prof["conv16_lds_dma"][1] == 0 and prof["convlat_small_grid"][1] == 0
+    # (5 k_wino launches per step fused, 7 where the measured "E-part ahead" decision split the level-1 / level-2 gates)
+    assert prof["wino_pa2"][1] in (5, 7) and prof["conv16_lds_dma"][1] == 0 and prof["convlat_small_grid"][1] == 0
 
 
 def test_pa2_is_the_same_function_as_pa1_in_another_summation_order(ctx):

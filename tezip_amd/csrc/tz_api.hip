@@ -1,6 +1,7 @@
 // Context, staging helpers, rollout state machine and the encode/decode drivers of
 // libtezip_hip.so.  Reference control flow: /root/reference/src/compress.py:183-373 and
 // /root/reference/src/decompress.py:105-256 (cited per function).
+#include <dlfcn.h>
 #include <stdarg.h>
 
 #include <algorithm>
@@ -528,7 +529,53 @@ int tz_dev_out_finish(tz_ctx* ctx, std::vector<tz_out>& outs) {
 }
 
 // --------------------------------------------------------------------------- profiling
+static const char* kProfNames[TZP_COUNT] = {"conv3x3_mfma", "err0", "delta", "quant", "spatial_delta_hist",
+                                            "lut_remap", "undelta_scan", "reconstruct", "sse",
+                                            "conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general",
+                                            "convlat_small_grid", "wino_pa2", "table_create", "quant_serial_chains"};
+
+namespace {
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi() {
+        const char* e = getenv("TEZIP_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        void* h = nullptr;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (h) {
+            push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+        }
+        if (!push || !pop) {
+            push = nullptr;
+            pop = nullptr;
+            fprintf(stderr, "[tezip] TEZIP_ROCTX is set but no ROCTx library could be opened (%s): no ranges\n", dlerror() ? dlerror() : "symbols missing");
+        }
+    }
+};
+const RoctxApi& roctx_api() {
+    static RoctxApi api;
+    return api;
+}
+}  // namespace
+
+bool tz_roctx_push(const char* name) {
+    const RoctxApi& r = roctx_api();
+    if (!r.push) return false;
+    r.push(name);
+    return true;
+}
+void tz_roctx_pop() {
+    const RoctxApi& r = roctx_api();
+    if (r.pop) r.pop();
+}
+
 tz_prof_scope::tz_prof_scope(tz_ctx* c, int k) : ctx(c), cls(k) {
+    rx = tz_roctx_push(k >= 0 && k < TZP_COUNT ? kProfNames[k] : "tz_stage");
     if (!ctx->prof_on) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
         a = b = nullptr;
@@ -537,16 +584,12 @@ tz_prof_scope::tz_prof_scope(tz_ctx* c, int k) : ctx(c), cls(k) {
     (void)hipEventRecord(a, ctx->stream);
 }
 tz_prof_scope::~tz_prof_scope() {
+    if (rx) tz_roctx_pop();
     if (!a || !b) return;
     (void)hipEventRecord(b, ctx->stream);
     ctx->prof[cls].pending.push_back({a, b});
     ctx->prof[cls].pending_sub.push_back(sub);
 }
-
-static const char* kProfNames[TZP_COUNT] = {"conv3x3_mfma", "err0", "delta", "quant", "spatial_delta_hist",
-                                            "lut_remap", "undelta_scan", "reconstruct", "sse",
-                                            "conv16_lds_dma", "conv16b_level0", "conv_small_valu", "conv3x3_general",
-                                            "convlat_small_grid", "wino_pa2", "table_create", "quant_serial_chains"};
 
 extern "C" int tz_prof_enable(tz_ctx* ctx, int on) {
     if (!ctx) return TZ_ERR_INVALID;
@@ -1068,6 +1111,7 @@ extern "C" int tz_payload_get(tz_ctx* ctx, size_t offset, size_t count, int16_t*
 
 extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int W, int warm_up, int window,
                           double threshold, uint8_t* key_mask, double* mse_log) {
+    tz_roctx_range roctx_("tz_rollout");
     if (!ctx) return TZ_ERR_INVALID;
     ctx->enc_pending = false;   // a tz_encode_begin belongs to the rollout before it
     if (window < 0) return tz_fail(ctx, TZ_ERR_INVALID, "window must be >= 0");
@@ -1241,6 +1285,7 @@ extern "C" int tz_rollout(tz_ctx* ctx, const uint8_t* frames, int nt, int H, int
 
 extern "C" int tz_rollout_decode(tz_ctx* ctx, const uint8_t* key_frames, int nt, int H, int W, int warm_up,
                                  uint8_t* key_mask) {
+    tz_roctx_range roctx_("tz_rollout_decode");
     if (!ctx) return TZ_ERR_INVALID;
     ctx->enc_pending = false;
     int rc = rollout_setup(ctx, key_frames, nt, H, W, warm_up);
@@ -1434,6 +1479,7 @@ static int encode_front(tz_ctx* ctx, int mode, double b0, double b1, int entropy
 
 extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t* payload, int16_t* table,
                          int* table_len, int16_t* delta_out) {
+    tz_roctx_range roctx_("tz_encode");
     if (!ctx || !table_len || ((entropy & 1) && !table)) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode needs a tz_rollout first");
     TZ_TRY(tz_check_pred_contract(ctx, "tz_encode"));
@@ -1526,6 +1572,7 @@ extern "C" int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entrop
 // the context's resident payload buffer between the two calls and are remapped in place.
 extern "C" int tz_encode_begin(tz_ctx* ctx, int mode, double b0, double b1, int entropy, unsigned long long* hist,
                                int16_t* edge) {
+    tz_roctx_range roctx_("tz_encode_begin");
     if (!ctx || !edge || (entropy && !hist)) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode_begin needs a tz_rollout first");
     TZ_TRY(tz_check_pred_contract(ctx, "tz_encode_begin"));
@@ -1557,6 +1604,7 @@ extern "C" int tz_encode_begin(tz_ctx* ctx, int mode, double b0, double b1, int 
 
 extern "C" int tz_encode_finish(tz_ctx* ctx, int has_carry, int16_t carry, const int16_t* table, int table_len,
                                 int16_t* payload) {
+    tz_roctx_range roctx_("tz_encode_finish");
     if (!ctx) return TZ_ERR_INVALID;
     if (!ctx->enc_pending) return tz_fail(ctx, TZ_ERR_STATE, "tz_encode_finish needs a tz_encode_begin first");
     if (ctx->enc_entropy != (table_len >= 0) || (table_len > 0 && !table) || table_len > TZ_MAX_TABLE)
@@ -1671,6 +1719,7 @@ extern "C" int tz_decode_delta(tz_ctx* ctx, const int16_t* delta, uint8_t* frame
 
 extern "C" int tz_decode(tz_ctx* ctx, const int16_t* payload, size_t payload_len, const int16_t* table, int table_len,
                          uint8_t* frames_out) {
+    tz_roctx_range roctx_("tz_decode");
     if (!ctx) return TZ_ERR_INVALID;
     if (!ctx->have_rollout || !ctx->rollout_is_decode) return tz_fail(ctx, TZ_ERR_STATE, "tz_decode needs a tz_rollout_decode first");
     TZ_TRY(tz_check_pred_contract(ctx, "tz_decode"));

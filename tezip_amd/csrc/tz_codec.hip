@@ -1892,6 +1892,7 @@ int tzk_shuffle(tz_ctx* ctx, const int16_t* in, size_t n, uint8_t* out, int inve
 static constexpr unsigned SCAN_POLL_LIMIT = 1u << 22;   // polls of ONE status word before a thread gives up (a healthy wait is
                                                         // tens of polls; 2^22 L2 round trips are seconds)
 static constexpr int SCAN_EPT = 16;                 // elements per thread
+static constexpr int SCAN_KEEP = 4;                 // wave-tiles of a wave's run that stay in registers between the two phases
 static constexpr int SCAN_G = 4096;                 // blocks of a launch: two rounds of the 2048 the chip holds (measured at
                                                     // 62.9 M elements, fused tail: 1024 108 us, 2048 107, 4096 96, 8192 110)
 
@@ -1960,6 +1961,7 @@ struct ScanRecon {
     const uint8_t* key_mask;  // [frame]
     unsigned long long fe;    // elements per frame
     uint8_t* out;
+    int keep_regs;            // (every launch, RECON or not) 1: a wave's run stays in registers between the phases; TEZIP_SCAN_KEEP=0: A/B
 };
 
 // status[g] = epoch << 16 | (sum of block g's chunk mod 2^16); the words of a launch carry its epoch (1..65535, the
@@ -1991,15 +1993,36 @@ __global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, 
     }
     const int g = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t chunk0 = ((size_t)g * 4 + wv) * (size_t)wtiles * SCAN_WT;   // of this wave
-    // (1) the sum of the wave's run, then of the block's
+    // (1) the sum of the wave's run, then of the block's.  Round 6: a wave's run of up to SCAN_KEEP tiles STAYS IN REGISTERS
+    // for phase 3 (two int16 per register, 32 registers; the loops are unrolled so that nothing is indexed at run time):
+    // the payload is read once instead of twice -- the second read came from HBM (counter traffic 557 MB against 440 MB
+    // algorithmic at 62.9 M elements).  Launches with longer runs (more than SCAN_G * 4 * SCAN_KEEP
+    // wave-tiles: 67 M elements) read twice as before.
     unsigned s = 0;
-    for (int t = 0; t < wtiles; ++t) {
-        const size_t base = chunk0 + (size_t)t * SCAN_WT + (size_t)lane * SCAN_EPT;
-        if (base >= n) break;
-        int v[SCAN_EPT];
-        scan_load16<LUT>(in, base, n, vec != 0, !has_carry, sl, post_offset, v);
+    const bool keep = wtiles <= SCAN_KEEP && rc.keep_regs;   // (uniform over the launch)
+    unsigned kept[SCAN_KEEP][SCAN_EPT / 2];
+    if (keep) {
 #pragma unroll
-        for (int k = 0; k < SCAN_EPT; ++k) s += (unsigned)v[k];
+        for (int t = 0; t < SCAN_KEEP; ++t) {
+            const size_t base = chunk0 + (size_t)t * SCAN_WT + (size_t)lane * SCAN_EPT;
+            int v[SCAN_EPT];
+#pragma unroll
+            for (int k = 0; k < SCAN_EPT; ++k) v[k] = 0;
+            if (t < wtiles && base < n) scan_load16<LUT>(in, base, n, vec != 0, !has_carry, sl, post_offset, v);
+#pragma unroll
+            for (int k = 0; k < SCAN_EPT; ++k) s += (unsigned)v[k];
+#pragma unroll
+            for (int k = 0; k < SCAN_EPT / 2; ++k) kept[t][k] = ((unsigned)v[2 * k] & 0xFFFFu) | ((unsigned)v[2 * k + 1] << 16);
+        }
+    } else {
+        for (int t = 0; t < wtiles; ++t) {
+            const size_t base = chunk0 + (size_t)t * SCAN_WT + (size_t)lane * SCAN_EPT;
+            if (base >= n) break;
+            int v[SCAN_EPT];
+            scan_load16<LUT>(in, base, n, vec != 0, !has_carry, sl, post_offset, v);
+#pragma unroll
+            for (int k = 0; k < SCAN_EPT; ++k) s += (unsigned)v[k];
+        }
     }
     s = wave_scan_incl(s);
     if (lane == 63) wsum[wv] = s;
@@ -2037,9 +2060,8 @@ __global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, 
         fr = chunk0 / rc.fe;
         rr = chunk0 - fr * rc.fe;
     }
-    for (int t = 0; t < wtiles; ++t) {
+    auto tile = [&](int t, const unsigned* kv) {   // kv: the tile's values as phase 1 left them, or nullptr: load them again
         const size_t base = chunk0 + (size_t)t * SCAN_WT + (size_t)lane * SCAN_EPT;
-        if (chunk0 + (size_t)t * SCAN_WT >= n) break;   // uniform for the wave
         int bv[SCAN_EPT];
         if (RECON) {
             unsigned long long f = fr, r = rr + (unsigned long long)lane * SCAN_EPT;
@@ -2071,7 +2093,15 @@ __global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, 
             }
         }
         int v[SCAN_EPT];
-        scan_load16<LUT>(in, base, n, vec != 0, !has_carry, sl, post_offset, v);
+        if (kv) {
+#pragma unroll
+            for (int k = 0; k < SCAN_EPT / 2; ++k) {
+                v[2 * k] = (int)(short)(kv[k] & 0xFFFFu);
+                v[2 * k + 1] = (int)(short)(kv[k] >> 16);
+            }
+        } else {
+            scan_load16<LUT>(in, base, n, vec != 0, !has_carry, sl, post_offset, v);
+        }
         unsigned q = 0;
 #pragma unroll
         for (int k = 0; k < SCAN_EPT; ++k) q += (unsigned)v[k];
@@ -2109,6 +2139,16 @@ __global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, 
             for (int k = 0; k < SCAN_EPT; ++k)
                 if (base + k < n) out[base + k] = r[k];
         }
+    };
+    if (keep) {
+#pragma unroll
+        for (int t = 0; t < SCAN_KEEP; ++t)
+            if (t < wtiles && chunk0 + (size_t)t * SCAN_WT < n) tile(t, kept[t]);   // (uniform for the wave)
+    } else {
+        for (int t = 0; t < wtiles; ++t) {
+            if (chunk0 + (size_t)t * SCAN_WT >= n) break;   // uniform for the wave
+            tile(t, nullptr);
+        }
     }
 }
 
@@ -2133,11 +2173,13 @@ static int scan_launch(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, 
     }
     const unsigned epoch = ++ctx->scan_epoch;
     const int vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
-    const ScanRecon none = {};
+    static const int keep_regs = !getenv("TEZIP_SCAN_KEEP") || atoi(getenv("TEZIP_SCAN_KEEP")) != 0;   // (0: A/B against the two reads)
+    ScanRecon rcv = recon ? *recon : ScanRecon{};
+    rcv.keep_regs = keep_regs;
 #define TZ_SCAN_LAUNCH(L, R)                                                                                              \
     hipLaunchKernelGGL((k_scan2p<L, R>), dim3(G), dim3(256), 0, ctx->stream, in, n, (int)tpb, has_carry, carry, vec,      \
                        (const int16_t*)d_lut, post_offset, ctx->d_scan_status, epoch, (epoch + ctx->scan_dbg_skew) & 0xFFFFu,       \
-                       ctx->scan_dbg_limit ? ctx->scan_dbg_limit : SCAN_POLL_LIMIT, ctx->d_fault, out, recon ? *recon : none)
+                       ctx->scan_dbg_limit ? ctx->scan_dbg_limit : SCAN_POLL_LIMIT, ctx->d_fault, out, rcv)
     if (recon) {
         if (h_lut2112) TZ_SCAN_LAUNCH(true, true);
         else TZ_SCAN_LAUNCH(false, true);

@@ -229,8 +229,24 @@ struct tz_prof_scope {
     int cls;
     int sub = -1;  // optional second class the same interval is added to (set before the scope ends)
     hipEvent_t a = nullptr, b = nullptr;
+    bool rx = false;   // a ROCTx range is open (TEZIP_ROCTX=1)
     tz_prof_scope(tz_ctx* c, int k);
     ~tz_prof_scope();
+};
+
+// ROCTx ranges ("same -v lines + rocprofv3 / roctx ranges"): with TEZIP_ROCTX=1 the library opens
+// librocprofiler-sdk-roctx.so (else libroctx64.so) and brackets every C-ABI stage call and every stage class of
+// tz_prof_scope with roctxRangePushA / roctxRangePop, so that `rocprofv3 --marker-trace --kernel-trace` shows the launches
+// of a stage under its name.  Off (the default): one branch on a cached flag.  A library that cannot be opened is said
+// once on stderr and the run goes on without ranges -- a diagnostic must never be what a job fails on.
+bool tz_roctx_push(const char* name);   // returns whether a range was opened
+void tz_roctx_pop();
+struct tz_roctx_range {
+    bool on;
+    explicit tz_roctx_range(const char* name) : on(tz_roctx_push(name)) {}
+    ~tz_roctx_range() {
+        if (on) tz_roctx_pop();
+    }
 };
 
 // ---- kernels' host launchers (device pointers only) ---------------------------------------

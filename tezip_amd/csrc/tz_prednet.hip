@@ -630,6 +630,7 @@ extern "C" int tz_model_load(tz_ctx* ctx, int nb_layers, const int* stack_sizes,
 }
 
 extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
+    tz_roctx_range roctx_("tz_model_prepare");
     if (!ctx) return TZ_ERR_INVALID;
     tz_model* m = ctx->model;
     if (!m) return tz_fail(ctx, TZ_ERR_STATE, "tz_model_prepare before tz_model_load");
