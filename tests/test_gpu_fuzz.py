@@ -134,3 +134,45 @@ def test_whole_jobs_random_small_shapes_vs_oracle(ctx, seed):
         ctx.rollout_decode(ref["key_frame"].reshape(nt, h, w, 3), p)
         dec = ctx.decode(payload, table)
         np.testing.assert_array_equal(dec, O.decode_stream(ref["stream"], ref["key_frame"], pred), err_msg=msg)
+
+
+SMALL_E = [("abs", lambda r: [float(r.choice([0.1, 0.25, 0.255, 0.3, 0.45, 0.499, 0.4991, 0.5, 1e-9]))]),
+           ("rel", lambda r: [float(r.choice([1e-4, 1e-3, 0.0019, 0.00195, 0.00196, 0.002]))]),
+           ("absrel", lambda r: [float(r.choice([0.3, 0.499, 5.0])), float(r.choice([0.0005, 0.0019, 0.5]))])]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_whole_jobs_small_tolerances_vs_oracle(ctx, seed):
+    """Round 6: tolerances around the limit of the elementwise quantiser map (k_delta_sd_fused<.., QMAP>: worst-case E <=
+    0.499 -- below it every run is a run of equal deltas; just above it the general quantiser runs) on UNPADDED frames (the
+    fused encode), full-range and narrow-range data (rel: E = range * b per chain), with warm-up frames (not quantised);
+    payload, table and decoded frames against the oracle's."""
+    from tezip_amd.prednet import PredNetConfig
+    cfg = PredNetConfig(stack_sizes=(3, 16, 32))
+    rng = np.random.default_rng(4000 + seed)
+    wts = cfg.init_weights(seed=60 + seed, bias_scale=0.2)
+    for case in range(6):
+        h, w = int(rng.choice([8, 16, 24, 40])), int(rng.choice([8, 16, 32, 48]))
+        nt, p = int(rng.integers(6, 12)), int(rng.integers(0, 3))
+        window = int(rng.integers(2, 6))
+        mode, mk = SMALL_E[int(rng.integers(0, 3))]
+        bound = mk(rng)
+        entropy = bool(rng.random() < 0.7)
+        frames = _style(rng, int(rng.choice([0, 1, 5])), (nt, h, w, 3))
+        frames[:, 0, 0, 0] |= 1
+        net = coracle.CPredNet(wts, cfg.stack_sizes, cfg.R_stack_sizes, h, w)
+        pred = _Predictor(net)
+        ref = O.compress_oracle(frames, p, window, None, mode, bound, pred, entropy)
+        ctx.load_model(cfg, wts)
+        ctx.prepare(h, w, max_batch=4)
+        key, _ = ctx.rollout(frames, p, window, None)
+        np.testing.assert_array_equal(key, ref["key"])
+        payload, table, _ = ctx.encode(mode, bound, entropy)
+        sp, rt, _, _ = O.parse_stream(ref["stream"])
+        msg = "seed %d case %d: nt %d %dx%d p %d w %d %s %s" % (seed, case, nt, h, w, p, window, mode, bound)
+        np.testing.assert_array_equal(payload, sp, err_msg=msg)
+        if entropy:
+            np.testing.assert_array_equal(table, rt, err_msg=msg)
+        ctx.rollout_decode(ref["key_frame"].reshape(nt, h, w, 3), p)
+        dec = ctx.decode(payload, table)
+        np.testing.assert_array_equal(dec, O.decode_stream(ref["stream"], ref["key_frame"], pred), err_msg=msg)
