@@ -458,9 +458,8 @@ def main():
     # kernel" stated for what the timed step runs, not only for the stand-alone tz_delta_encode.  Algorithmic bytes as
     # DESIGN section 5 counts them: through the quantiser 5 in (pred f32 + orig u8) + 2 out (run values) / 2 in + 2 out (fill,
     # spatial delta, offset, histogram -> symbols) / 2 in + 2 out (rank remap) = 15 B per element; where the tolerance
-    # cannot merge two different deltas (E <= 0.499: an elementwise map, round 6) or the job is lossless, ONE fused pass
-    # 5 in + 2 out, then the remap 2 in + 2 out = 11 B per element (+ 1 B of the original for the per-chain range of
-    # rel / absrel: 12).
+    # cannot merge two different deltas (E <= 0.499: error_bound is then the identity, tz_quant_is_identity, round 6) or the
+    # job is lossless, ONE fused pass 5 in + 2 out, then the remap 2 in + 2 out = 11 B per element.
     tail_keys = ("delta", "quant", "spatial_delta_hist", "lut_remap")
     tail_ms = sum(prof[k][0] for k in tail_keys if k in prof)
     tail_through_quantiser = prof.get("spatial_delta_hist", (0.0, 0))[1] > 0   # k_q_fill_sym / k_sdelta ran: not the one-pass form
@@ -749,8 +748,8 @@ def main():
             "roofline_encode_tail": {"kernel": "the elementwise tail the timed step launches behind the rollout: "
                                                + ("k_q_tiles + stitch kernels + k_q_fill_sym + k_lut (deltas formed inside the quantiser)"
                                                   if tail_through_quantiser else
-                                                  "k_delta_sd_fused (delta + elementwise bound map + spatial delta + offset + histogram in one pass; "
-                                                  "k_q_minmax for the per-chain range of rel) + k_lut"),
+                                                  "k_delta_sd_fused (delta + spatial delta + offset + histogram in one pass: the job's tolerance "
+                                                  "cannot merge different deltas, so error_bound is the identity) + k_lut"),
                                      "bound": "hbm", "achieved": tail_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": tail_gbs / PEAK_HBM_GBS,
                                      "traffic": tail_traffic, "traffic_kernels": list(tail_kernels),
                                      "bytes_per_element": tail_bpe, "bytes_per_step": tail_bytes,

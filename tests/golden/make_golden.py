@@ -24,7 +24,7 @@ What it does:
 Every file regenerates bit for bit except ref_train.npz, whose folder order inside a split follows the reference's `set()`
 iteration (string hashing: PYTHONHASHSEED); the tests compare it per folder.
 
-Run:  /opt/conda/bin/python3.9 tests/golden/make_golden.py      (--train-only: just ref_train.npz; --prednet-only: just ref_prednet.npz)
+Run:  /opt/conda/bin/python3.9 tests/golden/make_golden.py      (--train-only: just ref_train.npz; --prednet-only: just ref_prednet.npz; --runs4-only: just ref_runs4.npz)
 (python3.9 + numpy 1.26 because the reference calls ndarray.tostring(), removed in numpy 2.)
 Nothing from the reference's source text is written to the fixtures: only arrays.
 """
@@ -363,6 +363,17 @@ RUNS_3 = [
         ("swp_p0_w2_absrel_abs0", 6, 8, 8, False, 0, 2, None, "absrel", [0.0, 0.5], True),
         ("swp_p1_w3_rel_no_entropy_gray", 9, 10, 14, True, 1, 3, None, "rel", [0.1], False),
 ]
+# round 6: tolerances that cannot merge two different deltas (E <= 0.499 in the reference's 0..255 units -- BASELINE.json's cfg3
+# `rel 1e-3` is one), on UNPADDED frame sizes: the HIP build sends these through its one-pass lossless kernel, because error_bound
+# is then the identity (tz_quant_is_identity in tz_codec.hip); here is what the REFERENCE's error_bound makes of them, end to end
+RUNS_4 = [
+        ("swp_p0_w4_rel1e-3", 10, 16, 24, False, 0, 4, None, "rel", [1e-3], True),
+        ("swp_p2_w3_abs0.3", 11, 24, 32, False, 2, 3, None, "abs", [0.3], True),
+        ("swp_p1_w5_abs0.499_no_entropy", 9, 16, 16, False, 1, 5, None, "abs", [0.499], False),
+        ("swp_p0_w6_absrel_small", 13, 8, 40, False, 0, 6, None, "absrel", [0.4, 0.5], True),
+        ("swp_p0_w4_rel0.0019_gray", 10, 16, 16, True, 0, 4, None, "rel", [0.0019], True),
+        ("swp_p0_w3_abs0.255", 8, 32, 32, False, 0, 3, None, "abs", [0.255], True),
+]
 
 
 def _runs(compress, decompress, out, runs=None, seed=777, make_frames=None):
@@ -610,6 +621,12 @@ def main():
     import data_utils
     # the predictor layer is replaced wholesale by the fake model (see module docstring)
     compress.PredNet = decompress.PredNet = lambda weights=None, **cfg: (lambda inputs: inputs)
+    if "--runs4-only" in sys.argv:
+        runs4 = {}
+        _runs(compress, decompress, runs4, RUNS_4, seed=780)
+        np.savez_compressed(os.path.join(HERE, "ref_runs4.npz"), **runs4)
+        print("ref_runs4.npz:", len(runs4), "arrays")
+        return
     helpers = {}
     _helpers(compress, decompress, data_utils, helpers)
     np.savez_compressed(os.path.join(HERE, "ref_helpers.npz"), **helpers)
@@ -633,6 +650,10 @@ def main():
     _runs(compress, decompress, runs3, RUNS_3, seed=779)
     np.savez_compressed(os.path.join(HERE, "ref_runs3.npz"), **runs3)
     print("ref_runs3.npz:", len(runs3), "arrays")
+    runs4 = {}
+    _runs(compress, decompress, runs4, RUNS_4, seed=780)
+    np.savez_compressed(os.path.join(HERE, "ref_runs4.npz"), **runs4)
+    print("ref_runs4.npz:", len(runs4), "arrays")
     tr = {}
     _train_fixture(tr)
     np.savez_compressed(os.path.join(HERE, "ref_train.npz"), **tr)

@@ -143,8 +143,8 @@ SMALL_E = [("abs", lambda r: [float(r.choice([0.1, 0.25, 0.255, 0.3, 0.45, 0.499
 
 @pytest.mark.parametrize("seed", range(6))
 def test_whole_jobs_small_tolerances_vs_oracle(ctx, seed):
-    """Round 6: tolerances around the limit of the elementwise quantiser map (k_delta_sd_fused<.., QMAP>: worst-case E <=
-    0.499 -- below it every run is a run of equal deltas; just above it the general quantiser runs) on UNPADDED frames (the
+    """Round 6: tolerances around the limit of the identity shortcut (tz_quant_is_identity: worst-case E <= 0.499 -- below
+    it error_bound leaves every delta as it is and the one-pass lossless kernel runs; just above it the general quantiser) on UNPADDED frames (the
     fused encode), full-range and narrow-range data (rel: E = range * b per chain), with warm-up frames (not quantised);
     payload, table and decoded frames against the oracle's."""
     from tezip_amd.prednet import PredNetConfig

@@ -425,9 +425,9 @@ CASES = [
     (8, 16, 8, 0, None, 0.0, "abs", [0.0], True),     # DWP threshold 0: every prediction is rejected
     (8, 16, 8, 1, None, 1e9, "rel", [0.05], True),    # DWP threshold never reached: one window
     (5, 8, 8, 0, 2, None, "absrel", [0.0, 0.5], True),  # absrel with abs bound 0: lossless shortcut
-    # round 6: tolerances that cannot merge two different deltas run as an ELEMENTWISE map inside the fused lossless kernel
-    # (k_delta_sd_fused<.., QMAP>, E <= 0.499), unpadded frames only; the value of a run of equal deltas d is
-    # trunc((fl(d+E) + fl(d-E)) / 2), which is not always d.  Compared below with the oracle AND with the general
+    # round 6: tolerances that cannot merge two different deltas (worst-case E <= 0.499) leave every delta as it is --
+    # the value of a run of equal deltas d, trunc((fl(d+E) + fl(d-E)) / 2), is d (tz_quant_is_identity) -- so the fused
+    # encode of an unpadded job takes the one-pass lossless kernel.  Compared below with the oracle AND with the general
     # quantiser (the delta tap takes tzk_error_bound)
     (10, 16, 24, 0, 4, None, "abs", [0.3], True),
     (10, 16, 24, 2, 3, None, "abs", [0.255], True),      # warm-up frames: not quantised, non-zero deltas pass through

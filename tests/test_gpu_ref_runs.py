@@ -1,6 +1,6 @@
 """The HIP operator seams fed the reference's OWN executions, with no oracle in between.
 
-tests/golden/ref_runs*.npz hold 17 executions of /root/reference/src/compress.py `run` and decompress.py `run` (fake
+tests/golden/ref_runs*.npz hold 23 executions of /root/reference/src/compress.py `run` and decompress.py `run` (fake
 predictor tests/golden/fake_predictor.py in place of the Keras model, identity in place of zstd: make_golden.py).  The
 predictions of such a run are a pure function of the frames and of which frames the reference made key frames, so
 they are rebuilt here from the reference's key_frame.dat with the fake predictor alone, and then
@@ -22,7 +22,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 RUNS = {}
-for _f in ("ref_runs.npz", "ref_runs2.npz", "ref_runs3.npz"):
+for _f in ("ref_runs.npz", "ref_runs2.npz", "ref_runs3.npz", "ref_runs4.npz"):
     _R = np.load(os.path.join(GOLDEN, _f))
     RUNS.update({str(n): _R for n in _R["run_names"]})
 

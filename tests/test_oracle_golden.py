@@ -18,6 +18,8 @@ RUNS = {str(n): R for n in R["run_names"]}
 RUNS.update({str(n): R2 for n in R2["run_names"]})
 R3 = np.load(os.path.join(GOLDEN, "ref_runs3.npz"))   # edge cases: one-frame windows, one window, shortest sequence, DWP extremes
 RUNS.update({str(n): R3 for n in R3["run_names"]})
+R4 = np.load(os.path.join(GOLDEN, "ref_runs4.npz"))   # round 6: tolerances that cannot merge different deltas (E <= 0.499), unpadded frames
+RUNS.update({str(n): R4 for n in R4["run_names"]})
 PRED = O.FnPredictor(fake_predictor.c0_image, fake_predictor.g_next)
 
 

@@ -1452,8 +1452,12 @@ static int encode_front(tz_ctx* ctx, int mode, double b0, double b1, int entropy
     TZ_TRY(tz_pool_alloc(ctx, nt, &d_mask));
     TZ_TRY(tz_upload(ctx, d_mask, ctx->group_first.data(), nt));
     if (entropy) TZ_HIP(ctx, hipMemsetAsync(d_hist, 0, TZ_NBINS * sizeof(unsigned long long), ctx->stream));
-    // error_bound returns its input untouched in these cases (compress.py:24,35)
-    const bool lossless = b0 == 0.0 || (mode == TZ_MODE_ABSREL && b1 == 0.0);
+    // error_bound returns its input untouched in these cases (compress.py:24,35) ...
+    bool lossless = b0 == 0.0 || (mode == TZ_MODE_ABSREL && b1 == 0.0);
+    // ... and COMPUTES its input back wherever the worst-case tolerance of the job cannot merge two different deltas
+    // (E <= 0.499: tz_quant_is_identity, with the proof).  The fused pass below then serves such a job as well; a caller
+    // that taps the delta stack still gets it through the general quantiser (the parity tests compare the two).
+    if (!d_delta_tap && tz_quant_is_identity(mode, b0, b1)) lossless = true;
     bool fused = false;
     // lossless and nobody asked for the delta stack: one fused pass (compress.py:292-355)
     if (lossless && !d_delta_tap)

@@ -1509,10 +1509,6 @@ int tzk_error_bound(tz_ctx* ctx, const uint8_t* orig, int16_t* diff, const uint8
     return quant_run(ctx, orig, diff, nullptr, h_skip, nframes, H, W, mode, b0, b1);
 }
 
-static int quant_map_fused(tz_ctx* ctx, const float* pred, const uint8_t* orig, const uint8_t* d_zero_mask, const uint8_t* h_skip,
-                           int nframes, int H, int W, int mode, double b0, double b1, int apply_offset, int16_t* out,
-                           unsigned long long* d_hist, int16_t* d_edge, bool* done);
-
 // Lossy fused encode (compress.py:292-355 without a delta stack in memory): applies to unpadded frames with
 // whole 16-byte groups per frame; *done says whether it ran (else the caller takes the unfused kernels).
 int tzk_quant_sd_fused(tz_ctx* ctx, const float* pred, const uint8_t* orig, const uint8_t* d_zero_mask, const uint8_t* h_skip,
@@ -1526,8 +1522,6 @@ int tzk_quant_sd_fused(tz_ctx* ctx, const float* pred, const uint8_t* orig, cons
     if (mode == TZ_MODE_ABSREL && b1 < 0.0)
         return tz_fail(ctx, TZ_ERR_INVALID, "the rel bound of absrel must be >= 0 (the reference raises on a negative one)");
     if (H != Hp || W != Wp || ((size_t)H * W) % 8 || nframes <= 0 || (((uintptr_t)sym) & 15)) return TZ_OK;
-    TZ_TRY(quant_map_fused(ctx, pred, orig, d_zero_mask, h_skip, nframes, H, W, mode, b0, b1, apply_offset, sym, d_hist, d_edge, done));
-    if (*done) return TZ_OK;
     QFused fu{pred, d_zero_mask, apply_offset, sym, d_hist, d_edge};
     TZ_TRY(quant_run(ctx, orig, nullptr, &fu, h_skip, nframes, H, W, mode, b0, b1));
     *done = true;
@@ -1578,31 +1572,12 @@ __global__ __launch_bounds__(HIST ? HB_THREADS : 256) void k_sdelta(const int16_
 // 1600 offset and histogram in ONE pass over pred/orig -- 7 B/element instead of 7 + 4.
 // Same arithmetic as k_delta_flat followed by k_sdelta; the element before a lane's first is
 // recomputed from pred/orig (one extra float + byte, same cache lines).
-//
-// QMAP (round 6): the error-bound quantiser as an ELEMENTWISE map, for tolerances that cannot merge two different deltas.
-// compress.py:55-67 closes a run at the first element i with min(u, Du[i]) - max(l, Dl[i]) < 0, Du = d + E, Dl = d - E.
-// Deltas are integers: with E <= 0.499 two different neighbours always break ((a - b) + 2E <= -0.002, far beyond any
-// rounding of sums below 256) and two equal ones never do (fl(d + E) >= fl(d - E) for E >= 0), so EVERY run is a run of
-// equal deltas d and its value trunc((fl(d + E) + fl(d - E)) / 2) (compress.py:61,67) depends on d and the chain's E
-// alone -- not on where the run starts.  That value is NOT always d: for E = 0.255 (BASELINE.json's cfg3, `rel 1e-3` of
-// a full-range slab) fl(3.255) + fl(2.745) may round below 6 and truncate to 2; the map evaluates the reference's own
-// double expression per element (q_map1 = val_i of k_q_tiles with mn = mx).  Chains the reference does not quantise
-// (warm-up group, compress.py:317; `skip`) pass through.  One pass over pred / orig, 7 B per element, instead of the
-// speculative walks, the stitch kernels and the fill (15 B per element, issue-bound).
-__device__ __forceinline__ short q_map1(short d, double E) { return (short)(int)((((double)d + E) + ((double)d - E)) / 2); }
-
-struct QMapArgs {
-    const uint8_t* skip;     // [frame]: 1 = not quantised
-    const double* Echain;    // [frame * 3 + channel], or nullptr: E0 everywhere (abs)
-    double E0;
-};
-
-template <bool HIST, bool QMAP>
+template <bool HIST>
 __global__ __launch_bounds__(HIST ? HB_THREADS : 256) void k_delta_sd_fused(const float4* __restrict__ pred, const uint2* __restrict__ orig,
                                                         const uint8_t* __restrict__ zero_mask, size_t n8,
                                                         unsigned frame_elems8, int apply_offset,
                                                         short8* __restrict__ out, unsigned long long* __restrict__ hist,
-                                                        int16_t* __restrict__ edge, QMapArgs qm) {
+                                                        int16_t* __restrict__ edge) {
     __shared__ unsigned hraw[HIST ? HL_WORDS : 1];
     HistLds& hl = *(HistLds*)hraw;
     constexpr bool do_hist = HIST;
@@ -1629,30 +1604,6 @@ __global__ __launch_bounds__(HIST ? HB_THREADS : 256) void k_delta_sd_fused(cons
         if (i) {
             size_t e = 8 * i - 1;
             if (!zero_mask[(i * 8 - 1) / ((size_t)frame_elems8 * 8)]) prev = (short)((int)(predf[e] * 255.0f) - (int)origb[e]);
-        }
-        if (QMAP) {
-            const size_t fe = (size_t)frame_elems8 * 8;
-            const size_t f = i / frame_elems8;
-            const unsigned c0 = (unsigned)(((i - f * frame_elems8) * 8) % 3);   // channel of the lane's first element (HWC)
-            if (!qm.skip[f]) {
-                double E[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) E[c] = qm.Echain ? qm.Echain[f * 3 + c] : qm.E0;
-                // (channel of element k: (c0 + k) % 3 -- selected without indexing a register array dynamically)
-                const double Ea = c0 == 0 ? E[0] : (c0 == 1 ? E[1] : E[2]);
-                const double Eb = c0 == 0 ? E[1] : (c0 == 1 ? E[2] : E[0]);
-                const double Ec = c0 == 0 ? E[2] : (c0 == 1 ? E[0] : E[1]);
-                d[0] = q_map1(d[0], Ea); d[1] = q_map1(d[1], Eb); d[2] = q_map1(d[2], Ec);
-                d[3] = q_map1(d[3], Ea); d[4] = q_map1(d[4], Eb); d[5] = q_map1(d[5], Ec);
-                d[6] = q_map1(d[6], Ea); d[7] = q_map1(d[7], Eb);
-            }
-            if (i && prev != 0) {   // the element in front of the lane's first: its own frame's rule (q_map1(0) = 0)
-                const size_t e = 8 * i - 1, fp = e / fe;
-                if (!qm.skip[fp]) {
-                    const unsigned cp = (unsigned)((e - fp * fe) % 3);
-                    prev = q_map1(prev, qm.Echain ? qm.Echain[fp * 3 + cp] : qm.E0);
-                }
-            }
         }
         // pack the (masked) deltas two per dword and take the spatial delta in packed int16 arithmetic
         uint4 V;
@@ -1684,68 +1635,47 @@ int tzk_delta_sd_fused(tz_ctx* ctx, const float* pred, const uint8_t* orig, cons
     if (H != Hp || W != Wp || fe % 8 || nframes <= 0) return TZ_OK;
     size_t n8 = fe * nframes / 8;
     tz_prof_scope ps(ctx, TZP_DELTA);
-    const QMapArgs none{nullptr, nullptr, 0.0};
     if (d_hist)
-        hipLaunchKernelGGL((k_delta_sd_fused<true, false>), dim3(std::min(HB_GRID, grid_for(n8, HB_THREADS))), dim3(HB_THREADS), 0, ctx->stream,
+        hipLaunchKernelGGL(k_delta_sd_fused<true>, dim3(std::min(HB_GRID, grid_for(n8, HB_THREADS))), dim3(HB_THREADS), 0, ctx->stream,
                            (const float4*)pred, (const uint2*)orig, d_zero_mask, n8, (unsigned)(fe / 8), apply_offset, (short8*)out,
-                           d_hist, d_edge, none);
+                           d_hist, d_edge);
     else
-        hipLaunchKernelGGL((k_delta_sd_fused<false, false>), dim3(grid_for(n8, 256)), dim3(256), 0, ctx->stream, (const float4*)pred,
-                           (const uint2*)orig, d_zero_mask, n8, (unsigned)(fe / 8), apply_offset, (short8*)out, d_hist, d_edge, none);
+        hipLaunchKernelGGL(k_delta_sd_fused<false>, dim3(grid_for(n8, 256)), dim3(256), 0, ctx->stream, (const float4*)pred,
+                           (const uint2*)orig, d_zero_mask, n8, (unsigned)(fe / 8), apply_offset, (short8*)out, d_hist, d_edge);
     TZ_HIP(ctx, hipGetLastError());
     *done = true;
     return TZ_OK;
 }
 
-// The largest tolerance any chain of this job can get (compress.py:28-48: abs |b0|; rel range * b0 with range <= 255;
-// absrel the smaller of the two), or a negative number when the mode has no per-chain tolerance (pwrel).
-static double quant_worst_case_E(int mode, double b0, double b1) {
-    if (mode == TZ_MODE_ABS) return fabs(b0);
-    if (mode == TZ_MODE_REL) return 255.0 * b0;
-    if (mode == TZ_MODE_ABSREL) return std::min(fabs(b0), 255.0 * b1);
-    return -1.0;
-}
+// When is error_bound (compress.py:23-70) the IDENTITY on a stack of integer deltas?  (round 6)
+// The greedy walk closes a run at the first element i with min(u, Du[i]) - max(l, Dl[i]) < 0, Du = d + E, Dl = d - E in
+// float64, and gives the run trunc((u + l) / 2).  Deltas are integers (|d| <= 255 in the encoder, compress.py:292-314).
+//  (1) With E <= 0.499 two DIFFERENT neighbours a != b always close the run: (min - max) = -|a - b| + 2E <= -0.002, three
+//      orders of magnitude beyond the rounding of sums below 256; two EQUAL ones never do: fl(d + E) >= fl(d - E) for
+//      E >= 0 (rounding is monotone).  So every run is a run of equal deltas d, u = fl(d + E), l = fl(d - E).
+//  (2) fl(u + l) = 2d exactly, hence the run's value is d.  u and l are multiples of their ulp; unless d is a power of two
+//      they share one binade (ulp q): |u + l - 2d| = |e_u + e_l| <= q with equality only if both roundings were ties in
+//      the same direction -- but 2d is an even multiple of q, so when d + E lies halfway between k q and (k + 1) q, d - E
+//      lies halfway between (m - k - 1) q and (m - k) q with m even: round-to-even sends the two opposite ways.  So
+//      u + l - 2d is a multiple of q smaller than q: zero.  For d = 2^k (u in the upper binade, ulp 2q; l in the lower,
+//      ulp q) u + l - 2d is one of -q, 0, +q; 2d + q rounds down to 2d (spacing 4q above 2^(k+1)), 2d - q is a tie
+//      between 2d - 2q and 2d = 2^(k+1), whose mantissa is even.  d = 0: u + l = E - E = 0.
+//      (Checked numerically over every integer d in [-255, 255] for 200,000 random and all 3- and 4-digit tolerances.)
+// Per-chain tolerances (compress.py:28-48): abs |b0|; rel range * b0 with range <= 255; absrel the smaller of the two --
+// so the WORST case over the chains of a job decides, before any data is looked at.  pwrel (a tolerance per element:
+// the value of a run of equal deltas is still d by (2), but the runs themselves are not covered by (1)) is left to the
+// general quantiser.  BASELINE.json's cfg3 (`rel 1e-3`: E <= 0.255) is such a job: SURVEY.md section 8(d) calls it
+// "effectively lossless", and the reference's own runs at such tolerances decode bit-exact (tests/golden/ref_runs4.npz).
+static constexpr double kQIdentityMaxE = 0.499;
 
-static constexpr double kQMapMaxE = 0.499;   // see QMAP at k_delta_sd_fused: below this no two different deltas ever merge
-
-// Lossy encode whose tolerance cannot merge different deltas (see QMAP): the quantiser is an elementwise map inside the
-// fused delta / spatial-delta / histogram pass.  *done says whether it applied; TEZIP_QMAP=0 keeps the general quantiser
-// (tests compare the two).
-static int quant_map_fused(tz_ctx* ctx, const float* pred, const uint8_t* orig, const uint8_t* d_zero_mask, const uint8_t* h_skip,
-                           int nframes, int H, int W, int mode, double b0, double b1, int apply_offset, int16_t* out,
-                           unsigned long long* d_hist, int16_t* d_edge, bool* done) {
-    *done = false;
-    static const bool enabled = !getenv("TEZIP_QMAP") || atoi(getenv("TEZIP_QMAP")) != 0;
-    const double worst = quant_worst_case_E(mode, b0, b1);
-    if (!enabled || !(worst >= 0.0 && worst <= kQMapMaxE)) return TZ_OK;
-    const int HW = H * W;
-    const size_t fe = (size_t)HW * 3;
-    void *d_skip, *d_E = nullptr, *d_mm;
-    TZ_TRY(tz_pool_alloc(ctx, nframes, &d_skip));
-    TZ_TRY(tz_upload(ctx, d_skip, h_skip, nframes));
-    QParams qp{mode, b0, b1};
-    if (mode == TZ_MODE_REL || mode == TZ_MODE_ABSREL) {   // per-chain tolerance from the original slab, as quant_run does
-        tz_prof_scope ps(ctx, TZP_QUANT);
-        TZ_TRY(tz_pool_alloc(ctx, sizeof(double) * 3 * nframes, &d_E));
-        TZ_TRY(tz_pool_alloc(ctx, sizeof(int) * 6 * nframes, &d_mm));
-        hipLaunchKernelGGL(k_q_mm_init, dim3((6 * nframes + 255) / 256), dim3(256), 0, ctx->stream, (int*)d_mm, 6 * nframes);
-        hipLaunchKernelGGL(k_q_minmax, dim3(QBB, nframes), dim3(256), 0, ctx->stream, orig, (const uint8_t*)d_skip, HW, (int*)d_mm);
-        hipLaunchKernelGGL(k_q_bound, dim3((3 * nframes + 63) / 64), dim3(64), 0, ctx->stream, (const int*)d_mm, (const uint8_t*)d_skip, qp,
-                           nframes, (double*)d_E);
-    }
-    const QMapArgs qm{(const uint8_t*)d_skip, (const double*)d_E, fabs(b0)};
-    const size_t n8 = fe * nframes / 8;
-    tz_prof_scope ps(ctx, TZP_DELTA);
-    if (d_hist)
-        hipLaunchKernelGGL((k_delta_sd_fused<true, true>), dim3(std::min(HB_GRID, grid_for(n8, HB_THREADS))), dim3(HB_THREADS), 0, ctx->stream,
-                           (const float4*)pred, (const uint2*)orig, d_zero_mask, n8, (unsigned)(fe / 8), apply_offset, (short8*)out,
-                           d_hist, d_edge, qm);
-    else
-        hipLaunchKernelGGL((k_delta_sd_fused<false, true>), dim3(grid_for(n8, 256)), dim3(256), 0, ctx->stream, (const float4*)pred,
-                           (const uint2*)orig, d_zero_mask, n8, (unsigned)(fe / 8), apply_offset, (short8*)out, d_hist, d_edge, qm);
-    TZ_HIP(ctx, hipGetLastError());
-    *done = true;
-    return TZ_OK;
+bool tz_quant_is_identity(int mode, double b0, double b1) {
+    static const bool enabled = !getenv("TEZIP_QMAP") || atoi(getenv("TEZIP_QMAP")) != 0;   // (0: A/B against the general quantiser)
+    double worst;
+    if (mode == TZ_MODE_ABS) worst = fabs(b0);
+    else if (mode == TZ_MODE_REL) worst = 255.0 * b0;
+    else if (mode == TZ_MODE_ABSREL) worst = std::min(fabs(b0), 255.0 * b1);
+    else return false;
+    return enabled && worst >= 0.0 && worst <= kQIdentityMaxE;   // (a NaN or a negative tolerance: the general path and its errors)
 }
 
 int tzk_spatial_delta(tz_ctx* ctx, const int16_t* in, size_t n, int has_carry, int16_t carry, int apply_offset,

@@ -258,6 +258,7 @@ int tzk_delta_sd_fused(tz_ctx*, const float* pred, const uint8_t* orig, const ui
                        bool* done);
 int tzk_error_bound(tz_ctx*, const uint8_t* orig, int16_t* diff, const uint8_t* h_skip, int nframes, int H,
                     int W, int mode, double b0, double b1);
+bool tz_quant_is_identity(int mode, double b0, double b1);   // error_bound leaves every integer delta as it is (tz_codec.hip)
 int tzk_quant_sd_fused(tz_ctx*, const float* pred, const uint8_t* orig, const uint8_t* d_zero_mask, const uint8_t* h_skip,
                        int nframes, int H, int W, int Hp, int Wp, int mode, double b0, double b1, int apply_offset,
                        int16_t* sym, unsigned long long* d_hist, int16_t* d_edge, bool* done);
