@@ -138,7 +138,8 @@ def test_whole_jobs_random_small_shapes_vs_oracle(ctx, seed):
 
 SMALL_E = [("abs", lambda r: [float(r.choice([0.1, 0.25, 0.255, 0.3, 0.45, 0.499, 0.4991, 0.5, 1e-9]))]),
            ("rel", lambda r: [float(r.choice([1e-4, 1e-3, 0.0019, 0.00195, 0.00196, 0.002]))]),
-           ("absrel", lambda r: [float(r.choice([0.3, 0.499, 5.0])), float(r.choice([0.0005, 0.0019, 0.5]))])]
+           ("absrel", lambda r: [float(r.choice([0.3, 0.499, 5.0])), float(r.choice([0.0005, 0.0019, 0.5]))]),
+           ("pwrel", lambda r: [float(r.choice([1e-4, 1e-3, 0.0019, 0.00196, 0.002]))])]
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -155,7 +156,7 @@ def test_whole_jobs_small_tolerances_vs_oracle(ctx, seed):
         h, w = int(rng.choice([8, 16, 24, 40])), int(rng.choice([8, 16, 32, 48]))
         nt, p = int(rng.integers(6, 12)), int(rng.integers(0, 3))
         window = int(rng.integers(2, 6))
-        mode, mk = SMALL_E[int(rng.integers(0, 3))]
+        mode, mk = SMALL_E[int(rng.integers(0, 4))]
         bound = mk(rng)
         entropy = bool(rng.random() < 0.7)
         frames = _style(rng, int(rng.choice([0, 1, 5])), (nt, h, w, 3))

@@ -439,6 +439,8 @@ CASES = [
     (9, 16, 24, 0, 4, None, "absrel", [0.4, 0.9], True),
     (9, 16, 24, 1, 4, None, "absrel", [3.0, 0.001], True),
     (6, 16, 16, 0, 3, None, "abs", [1e-300], True),      # E so small that d + E == d: still not the lossless shortcut
+    (10, 16, 24, 1, 4, None, "pwrel", [0.0019], True),   # a tolerance per element, every one <= 0.4845
+    (10, 16, 24, 0, 4, None, "pwrel", [0.002], True),    # 255 * b = 0.51: the general quantiser
 ]
 
 

@@ -69,7 +69,7 @@ cfg = PredNetConfig(stack_sizes=(3, 16, 32))
 wts = cfg.init_weights(seed=3, bias_scale=0.2)
 ctx = _lib.Context(0)
 ctx.load_model(cfg, wts)
-for (nt, H, W, p) in [(14, 128, 160, 0), (10, 61, 90, 2)]:
+for (nt, H, W, p) in [(10, 64, 96, 0), (9, 45, 61, 2)]:   # (the C oracle's predictor is what this test's time goes to)
     hp, wp = _lib.pad8(H), _lib.pad8(W)
     frames = synth.turbulence(nt, H, W, seed=6)
     net = coracle.CPredNet(wts, cfg.stack_sizes, cfg.R_stack_sizes, hp, wp)
@@ -88,17 +88,40 @@ for (nt, H, W, p) in [(14, 128, 160, 0), (10, 61, 90, 2)]:
         np.testing.assert_array_equal(key, ref["key"])
         np.testing.assert_allclose(mse[p + 1:], ref["mse"], rtol=1e-12)
 print("dwp ok")
+# ... and at 512x512 (192 partials per step, the cfg5 shape; no oracle at this size): the log must be finite and the same
+# with and without the poison
+import hashlib
+full = PredNetConfig()
+ctx.load_model(full, full.init_weights(seed=123))
+ctx.prepare(512, 512, max_batch=1)
+f = synth.turbulence(14, 512, 512, seed=3)
+_, probe = ctx.rollout(f, 0, None, 1e9, want_mse=True)
+thr = float(np.sort(probe[1:])[5])
+h = hashlib.sha256()
+for rep in range(3):
+    key, mse = ctx.rollout(f, 0, None, thr, want_mse=True)
+    assert np.isfinite(mse).all(), mse
+    h.update(key.tobytes()); h.update(mse.tobytes())
+print("digest512", h.hexdigest())
 '''
 
 
 def test_dwp_decision_never_reads_a_partial_it_did_not_wait_for():
     """k_sse_decide's part[] filled with 0xFF bytes (NaN bit patterns) before every rollout: a last-ticket workgroup that
     read a slot before its writer's exchange had been performed would put a NaN into mse[] (and take no boundary there).
-    The window MSE log and the key mask must equal the oracle's (compress.py:245-264).  The ordering itself is read off the
-    object code in tests/test_build_guard.py; this is its dynamic half."""
-    env = dict(os.environ, TEZIP_POISON="255")
-    out = subprocess.run([sys.executable, "-c", DWP_JOB % ROOT], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "dwp ok" in out.stdout, out.stderr[-2000:]
+    The window MSE log and the key mask must equal the oracle's (compress.py:245-264) at two small sizes, and at 512x512
+    (192 partials per step) be finite and equal to the unpoisoned run's.  The ordering itself is read off the object code
+    in tests/test_build_guard.py; this is its dynamic half."""
+    digests = {}
+    for poison in ("255", None):
+        env = dict(os.environ)
+        env.pop("TEZIP_POISON", None)
+        if poison:
+            env["TEZIP_POISON"] = poison
+        out = subprocess.run([sys.executable, "-c", DWP_JOB % ROOT], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "dwp ok" in out.stdout, out.stderr[-2000:]
+        digests[poison] = [ln for ln in out.stdout.splitlines() if ln.startswith("digest512")][-1]
+    assert digests["255"] == digests[None]
 
 
 ROCTX_JOB = r'''

@@ -27,7 +27,7 @@ h = hashlib.sha256()
 frames = synth.turbulence(24, 512, 512, seed=3)
 ctx.prepare(512, 512, max_batch=3)
 for (p, window, mode, bound, entropy) in [(0, 8, "rel", [1e-3], True), (2, 6, "abs", [0.3], True), (0, 8, "absrel", [0.45, 0.5], False),
-                                          (1, 5, "rel", [0.0019], True), (0, 8, "abs", [0.499], True)]:
+                                          (1, 5, "rel", [0.0019], True), (0, 8, "abs", [0.499], True), (0, 8, "pwrel", [0.0015], True)]:
     key, _ = ctx.rollout(frames, p, window)
     ctx.prof_enable(True)
     ctx.prof_reset()

@@ -32,7 +32,7 @@ def test_the_value_of_a_run_of_equal_deltas_is_that_delta():
 
 
 @pytest.mark.parametrize("mode,bound", [("abs", [0.3]), ("abs", [0.499]), ("abs", [1e-12]), ("rel", [1e-3]), ("rel", [0.00195]),
-                                        ("absrel", [0.4, 0.9]), ("absrel", [7.0, 0.0015])])
+                                        ("absrel", [0.4, 0.9]), ("absrel", [7.0, 0.0015]), ("pwrel", [1e-3]), ("pwrel", [0.00195])])
 def test_both_oracles_return_their_input_at_such_tolerances(mode, bound):
     rng = np.random.default_rng(11)
     for trial in range(6):

@@ -1662,9 +1662,10 @@ int tzk_delta_sd_fused(tz_ctx* ctx, const float* pred, const uint8_t* orig, cons
 //      between 2d - 2q and 2d = 2^(k+1), whose mantissa is even.  d = 0: u + l = E - E = 0.
 //      (Checked numerically over every integer d in [-255, 255] for 200,000 random and all 3- and 4-digit tolerances.)
 // Per-chain tolerances (compress.py:28-48): abs |b0|; rel range * b0 with range <= 255; absrel the smaller of the two --
-// so the WORST case over the chains of a job decides, before any data is looked at.  pwrel (a tolerance per element:
-// the value of a run of equal deltas is still d by (2), but the runs themselves are not covered by (1)) is left to the
-// general quantiser.  BASELINE.json's cfg3 (`rel 1e-3`: E <= 0.255) is such a job: SURVEY.md section 8(d) calls it
+// so the WORST case over the chains of a job decides, before any data is looked at.  pwrel has a tolerance per ELEMENT,
+// E_i = orig_i * b0 <= 255 b0: (1) holds with the elements' own tolerances (all <= 0.499), and a run of equal deltas d has
+// u = min fl(d + E_i) = fl(d + min E_i), l = max fl(d - E_i) = fl(d - min E_i) (rounding is monotone) -- the same
+// tolerance on both sides, so (2) applies.  BASELINE.json's cfg3 (`rel 1e-3`: E <= 0.255) is such a job: SURVEY.md section 8(d) calls it
 // "effectively lossless", and the reference's own runs at such tolerances decode bit-exact (tests/golden/ref_runs4.npz).
 static constexpr double kQIdentityMaxE = 0.499;
 
@@ -1674,6 +1675,7 @@ bool tz_quant_is_identity(int mode, double b0, double b1) {
     if (mode == TZ_MODE_ABS) worst = fabs(b0);
     else if (mode == TZ_MODE_REL) worst = 255.0 * b0;
     else if (mode == TZ_MODE_ABSREL) worst = std::min(fabs(b0), 255.0 * b1);
+    else if (mode == TZ_MODE_PWREL) worst = 255.0 * b0;
     else return false;
     return enabled && worst >= 0.0 && worst <= kQIdentityMaxE;   // (a NaN or a negative tolerance: the general path and its errors)
 }
