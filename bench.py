@@ -557,7 +557,12 @@ def main():
             extras["lossy_abs2"] = {"frames_per_s": frames.shape[0] * max(3, min(args.steps, 10)) / el,
                                     "quantiser_ms_per_step": q[0], "table_symbols": len(own_state["table"]),
                                     "encode_tail_ms_per_step": {k: pq[k][0] for k in ("delta", "quant", "spatial_delta_hist", "lut_remap")},
-                                    "encode_tail_ms_total": sum(pq[k][0] for k in ("delta", "quant", "spatial_delta_hist", "lut_remap"))}
+                                    "encode_tail_ms_total": sum(pq[k][0] for k in ("delta", "quant", "spatial_delta_hist", "lut_remap")),
+                                    # the same roofline statement as roofline_encode_tail, for a tolerance that DOES merge: 15 B per
+                                    # element through the general quantiser (speculative walks, issue-bound: DESIGN.md section 5)
+                                    "encode_tail_bytes_per_element": 15.0,
+                                    "encode_tail_frac_of_hbm": 15.0 * frames.shape[0] * H * W * 3 / max(1e-9, 1e-3 * sum(
+                                        pq[k][0] for k in ("delta", "quant", "spatial_delta_hist", "lut_remap"))) / 1e9 / PEAK_HBM_GBS}
             own_step()
 
         # ------------------------------------------------------------ compression ratio (untimed; libzstd level 9 as the reference)
