@@ -296,3 +296,69 @@ def test_streaming_decompress_rejects_damaged_files(tmp_path):
         with pytest.raises((ValueError, RuntimeError)):
             decompress.run(mdir, variant(name, **repl), str(tmp_path / ("out_" + name)), True, False)
     decompress.run(mdir, good, str(tmp_path / "out_good"), True, False)   # the context is still usable afterwards
+
+
+def test_early_rollout_from_the_sidecar_gives_the_same_images_and_survives_damage(tmp_path, monkeypatch):
+    """Round 6: with `stack` in tezip_amd.json the streaming decoder stages the key frames and queues its rollout WHILE
+    entropy.dat is being decompressed on a worker thread (the reference keeps the shape in the last values of that file,
+    compress.py:390-394).  Same images as the late path (TEZIP_NO_EARLY_ROLLOUT=1, and a directory without the sidecar);
+    a sidecar whose stack contradicts the trailer, a truncated entropy.dat and a truncated key_frame.dat raise -- the
+    worker thread is gone afterwards and the next decode works."""
+    import json
+    import shutil
+    import threading
+    from PIL import Image
+    from tezip_amd import sidecar
+    cfg = PredNetConfig(stack_sizes=(3, 16, 32))
+    nt, h, w, p = 11, 24, 40, 2
+    frames = synth.translating_scene(nt, h, w, seed=12)
+    mdir = str(tmp_path / "model")
+    weights.save_model(mdir, cfg, cfg.init_weights(seed=12, bias_scale=0.1), 24, 40)
+    ddir = _write(tmp_path, frames, False)
+    good = str(tmp_path / "good")
+    compress.run(mdir, ddir, good, p, 4, None, "abs", [0.0], True, False, True)
+    doc = json.load(open(os.path.join(good, sidecar.NAME)))
+    assert doc["stack"] == [nt, h, w, p]
+
+    def decode(src, out, **env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        try:
+            decompress.run(mdir, src, str(tmp_path / out), True, False)
+        finally:
+            for k in env:
+                monkeypatch.delenv(k)
+        return np.stack([np.array(Image.open(os.path.join(str(tmp_path / out), "frame_%03d.png" % t))) for t in range(nt)])
+
+    early = decode(good, "out_early")
+    np.testing.assert_array_equal(early, frames)
+    np.testing.assert_array_equal(decode(good, "out_late", TEZIP_NO_EARLY_ROLLOUT="1"), frames)
+    bare = tmp_path / "bare"
+    shutil.copytree(good, bare)
+    os.remove(bare / sidecar.NAME)
+    np.testing.assert_array_equal(decode(str(bare), "out_bare"), frames)
+
+    def variant(name, stack=None, **repl):
+        d = tmp_path / name
+        shutil.copytree(good, d)
+        for n, data in repl.items():
+            (d / n).write_bytes(data)
+        if stack is not None:
+            dd = dict(doc, stack=stack)
+            (d / sidecar.NAME).write_text(json.dumps(dd))
+        return str(d)
+
+    ent = open(os.path.join(good, "entropy.dat"), "rb").read()
+    key = open(os.path.join(good, "key_frame.dat"), "rb").read()
+    with pytest.raises(ValueError, match="tezip_amd.json describes"):      # same sizes, another warm-up: the trailer decides
+        decode(variant("wrong_warm_up", stack=[nt, h, w, p - 1]), "o1")
+    # a hint that contradicts the model's frame size (height and width swapped: the same number of key bytes) is dropped
+    np.testing.assert_array_equal(decode(variant("swapped", stack=[nt, w, h, p]), "o2"), frames)
+    # a stack that does not even fit key_frame.dat's size is not used at all: the late path decodes
+    np.testing.assert_array_equal(decode(variant("other_size", stack=[nt + 1, h, w, p]), "o3"), frames)
+    with pytest.raises((ValueError, RuntimeError)):
+        decode(variant("cut_entropy", **{"entropy.dat": ent[: len(ent) // 2]}), "o4")
+    with pytest.raises((ValueError, RuntimeError)):
+        decode(variant("cut_key", **{"key_frame.dat": key[: len(key) // 2]}), "o5")
+    assert not [t for t in threading.enumerate() if t is not threading.current_thread() and t.daemon and "Prefetch" in repr(t._target)]
+    np.testing.assert_array_equal(decode(good, "out_again"), frames)

@@ -93,3 +93,49 @@ def test_a_refused_decode_exits_with_status_2(tmp_path, capsys, monkeypatch):
     assert stop.value.code == 2
     monkeypatch.setenv("TEZIP_PA", "2")
     assert decompress.adopt_contract(str(tmp_path), W, False) == 2
+
+
+def test_stack_is_recorded_and_only_a_plausible_one_is_used(tmp_path):
+    """Round 6: `stack` = [frames, height, width, warm_up] lets the decoder queue its rollout while entropy.dat (whose LAST
+    values hold the same numbers, compress.py:390-394) is still being decompressed.  Optional and additive: sidecars of
+    round 5 have none; junk is ignored, never trusted."""
+    doc = sidecar.write(str(tmp_path), 2, W, 512, 512, (80, 512, 510, 2))
+    assert doc["stack"] == [80, 512, 510, 2] and sidecar.stack_of(sidecar.read(str(tmp_path))) == (80, 512, 510, 2)
+    assert sidecar.stack_of(None) is None
+    assert sidecar.stack_of(sidecar.write(str(tmp_path), 1, W, 64, 64)) is None
+    for junk in ([80, 512, 510], [0, 512, 510, 0], [80, 512, 510, 80], [80, 512, 40000, 0], ["80", 512, 510, 0], "80x512", [80.5, 512, 510, 0]):
+        assert sidecar.stack_of({"stack": junk}) is None, junk
+
+
+def test_prefetch_hands_over_the_stream_in_order_and_raises_where_the_consumer_iterates(tmp_path):
+    """decompress._Prefetch: a zstd frame decompressed on a worker thread through a ring of buffers.  The pieces arrive in
+    order and complete; a truncated file raises in the consumer; a consumer that stops early does not leave the worker
+    blocked."""
+    from tezip_amd import decompress, zstd
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 7, 3_000_001, dtype=np.uint8)          # not a multiple of the piece size
+    path = tmp_path / "x.zst"
+    path.write_bytes(zstd.compress_array(data, 3, 0))
+    pre = decompress._Prefetch(str(path), piece_bytes=1 << 18, depth=2)
+    got, sizes = [], set()
+    try:
+        for size, piece in pre:
+            sizes.add(size)
+            got.append(piece.copy())     # the ring reuses a buffer depth + 2 pieces later
+    finally:
+        pre.close()
+    assert sizes == {data.size} and len(got) == 12
+    np.testing.assert_array_equal(np.concatenate(got), data)
+    (tmp_path / "cut.zst").write_bytes(path.read_bytes()[: path.stat().st_size // 2])
+    pre = decompress._Prefetch(str(tmp_path / "cut.zst"), piece_bytes=1 << 18, depth=2)
+    with pytest.raises(RuntimeError, match="zstd"):
+        try:
+            for _ in pre:
+                pass
+        finally:
+            pre.close()
+    pre = decompress._Prefetch(str(path), piece_bytes=1 << 16, depth=2)   # 46 pieces, the consumer takes one and leaves
+    it = iter(pre)
+    next(it)
+    pre.close()
+    assert not pre.t.is_alive()

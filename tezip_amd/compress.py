@@ -358,7 +358,7 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THRESHOLD, M
                     print("table_create:{0}".format(prof["table_create"][0] / 1e3) + "[sec]")
                     print("replacing_based_on_frequency:{0}".format(prof["lut_remap"][0] / 1e3) + "[sec]")
             _stream_outputs(ctx, OUTPUT_DIR, nt, H, W, key, table if ENTROPY_RUN else None, PREPROCESS, SHUFFLE, pool, stages)
-            doc = sidecar.write(OUTPUT_DIR, ctx.rollout_contract(), wts, hp, wp)   # the contract the predictions were made under
+            doc = sidecar.write(OUTPUT_DIR, ctx.rollout_contract(), wts, hp, wp, (nt, H, W, PREPROCESS))   # the contract the predictions were made under
             if VERBOSE:
                 print("arithmetic contract:", doc["arithmetic_contract"])
             stages.mark("key_frame.dat + entropy.dat")
@@ -485,7 +485,7 @@ def _run_sharded(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOW_SIZE, THR
             f.write(key_bytes)
         with open(os.path.join(OUTPUT_DIR, "entropy.dat"), mode='wb') as f:
             f.write(entropy_bytes)
-        doc = sidecar.write(OUTPUT_DIR, ctx.get_contract(), wts, hp, wp)   # every rank runs under the same TEZIP_PA / frame size
+        doc = sidecar.write(OUTPUT_DIR, ctx.get_contract(), wts, hp, wp, (nt, H, W, PREPROCESS))   # every rank runs under the same TEZIP_PA / frame size
         if VERBOSE:
             print("arithmetic contract:", doc["arithmetic_contract"])
     finally:

@@ -65,12 +65,71 @@ def adopt_contract(DATA_DIR, wts, VERBOSE):
     return contract
 
 
-def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shape, VERBOSE, device, contract=None):
+class _Prefetch:
+    """zstd.stream_decompress of one file on a worker thread (libzstd releases the GIL), its pieces copied into a ring of
+    host buffers and handed over through a bounded queue: the caller -- the only thread that touches the context -- can
+    queue the decoder's rollout first and collect the payload afterwards.  At most `depth` + 2 pieces exist at a time,
+    whatever the length of the stream.  An error on the worker is raised where the caller iterates."""
+
+    def __init__(self, path, piece_bytes=16 << 20, depth=8):
+        import queue
+        import threading
+        self.path, self.piece_bytes = path, piece_bytes
+        self.q = queue.Queue(maxsize=depth)
+        self.nbuf = depth + 2     # `depth` queued + the one the caller holds + the one being filled
+        self.stop = False
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _put(self, item):
+        import queue
+        while not self.stop:
+            try:
+                self.q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def _run(self):
+        try:
+            bufs = []
+            with open(self.path, "rb") as f:
+                for k, (size, piece) in enumerate(zstd.stream_decompress(f, piece_bytes=self.piece_bytes)):
+                    if len(bufs) < self.nbuf:
+                        bufs.append(np.empty(self.piece_bytes, np.uint8))
+                    buf = bufs[k % self.nbuf]
+                    buf[:piece.size] = piece
+                    if not self._put((size, buf[:piece.size])):
+                        return
+            self._put(None)
+        except BaseException as e:   # handed to the consumer
+            self._put(e)
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def close(self):
+        self.stop = True
+        self.t.join(timeout=5.0)
+
+
+def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shape, VERBOSE, device, contract=None, stack=None):
     """decompress.py:87-279 with nothing of size nt*H*W on the host: entropy.dat is decompressed
     piece by piece straight into HBM (the trailer is read from the last piece), key_frame.dat
     likewise, the decoded frames come back window by window and are PNG-encoded on a thread pool
     while the next window is fetched.  Returns False when the stream needs the whole-array path
-    (this build's opt-in byte-shuffled payload)."""
+    (this build's opt-in byte-shuffled payload).
+    `stack` = (nt, H, W) from tezip_amd.json (round 6), or None: the reference keeps the shape in the LAST values of
+    entropy.dat (compress.py:390-394), so without it nothing can start before the whole payload is decompressed; with it
+    the key frames are staged and the decoder's rollout is queued FIRST, entropy.dat being decompressed on a worker
+    thread meanwhile, and the trailer is checked against it when it arrives."""
     from concurrent.futures import ThreadPoolExecutor
     from PIL import Image
     from .compress import _Stages, io_threads
@@ -86,21 +145,84 @@ def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shap
         if contract:
             ctx.set_contract(contract)
         stages.mark("context + model load")
-        tail = np.zeros(0, np.int16)
-        total = off = 0
+        with open(paths["key_frame.dat"], "rb") as f:
+            head = f.read(64)
+        key_len = zstd.content_size(head)
+
+        def checks(nt, H, W):
+            hp, wp = padding_shape(H, W)
+            if model_shape is not None and (model_shape[0] != hp or model_shape[1] != wp):
+                print("ERROR:keyframe size and model size do not match.")
+                print("model size: height ", model_shape[0] - 7, "～", model_shape[0], " width ", model_shape[1] - 7, "～", model_shape[1])
+                print("key frame size: height ", H, " width ", W)
+                exit()
+            if len(file_names) != nt:
+                print("ERROR：The lengths of filename.txt and images do not match.")
+                print("filename.txt：", len(file_names))
+                print("number of images", nt)
+                exit()
+            return hp, wp
+
+        def stage_keys(nt, H, W, hp, wp):
+            """key_frame.dat into HBM (decompress.py:97-103); returns frames per fetch window"""
+            ctx.prepare(hp, wp, 64 if nt > 64 else max(1, nt))
+            stages.mark("model prepare")
+            fb = H * W * 3
+            per = max(1, (16 << 20) // fb)
+            ctx.frames_begin(nt, H, W)
+            first = 0
+            with open(paths["key_frame.dat"], "rb") as f:
+                for _, piece in zstd.stream_decompress(f, piece_bytes=per * fb):
+                    k = piece.size // fb
+                    ctx.frames_put(first, piece[: k * fb].reshape(k, H, W, 3))
+                    first += k
+            if first != nt:
+                raise ValueError("key_frame.dat: truncated stream")
+            stages.mark("zstd-d key_frame.dat + stage to HBM", ctx)
+            return per
+
+        def rollout(warm_up):
+            if VERBOSE:
+                ctx.prof_enable(True)
+            t0 = time.time()
+            ctx.rollout_decode(None, warm_up)     # (key discovery, then the predictor launches are queued)
+            if VERBOSE:
+                print("predict:{0}".format(time.time() - t0) + "[sec]")
+
         with open(paths["entropy.dat"], "rb") as f:
-            for size, piece in zstd.stream_decompress(f):
-                if total == 0:
-                    if size % 2 or size < 16:
-                        raise ValueError("entropy.dat is too short")
-                    total = size // 2
-                    ctx.payload_begin(total)
-                if piece.size % 2:
-                    raise ValueError("entropy.dat: odd-sized piece")
+            ent_size = zstd.content_size(f.read(64))
+        if ent_size % 2 or ent_size < 16:
+            raise ValueError("entropy.dat is too short")
+        total = ent_size // 2
+        # the stack is known up front only from this build's sidecar -- a HINT: it is used when it agrees with everything
+        # that can be checked now (key_frame.dat's size, the model's frame size, filename.txt), and the trailer has the last
+        # word; a hint that does not fit is dropped and the late path below reports whatever is really wrong
+        early = None
+        if stack is not None and key_len == stack[0] * stack[1] * stack[2] * 3 and len(file_names) == stack[0]:
+            hp_e, wp_e = padding_shape(stack[1], stack[2])
+            if model_shape is None or (model_shape[0] == hp_e and model_shape[1] == wp_e):
+                early = stack
+        pre = _Prefetch(paths["entropy.dat"])      # entropy.dat is being decompressed from here on
+        try:
+            per = None
+            ctx.payload_begin(total)               # (in front of the rollout: the copy stream need not wait for it)
+            if early is not None:
+                nt, H, W, warm_early = early
+                hp, wp = checks(nt, H, W)
+                per = stage_keys(nt, H, W, hp, wp)
+                rollout(warm_early)
+                stages.mark("rollout (decoder) queued")
+            tail = np.zeros(0, np.int16)
+            off = 0
+            for size, piece in pre:
+                if size != ent_size or piece.size % 2 or off * 2 + piece.size > ent_size:
+                    raise ValueError("entropy.dat: inconsistent stream")
                 p16 = piece.view(np.int16)
                 ctx.payload_put(off, p16)       # staged on the copy stream; the piece buffer is free on return
                 off += p16.size
                 tail = np.concatenate([tail, p16[-TAIL_ELEMS:]])[-TAIL_ELEMS:]
+        finally:
+            pre.close()
         if off != total:
             raise ValueError("entropy.dat: truncated stream")
         stages.mark("zstd-d entropy.dat + stage to HBM", ctx)
@@ -109,44 +231,18 @@ def _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shap
             raise ValueError("corrupt table length %d" % tlen)
         table = None if tlen == -1 else np.ascontiguousarray(tail[tail.size - 7 - tlen: tail.size - 7])
         payload_len = total - 7 - max(tlen, 0)
-        with open(paths["key_frame.dat"], "rb") as f:
-            head = f.read(64)
-        key_len = zstd.content_size(head)
         check_stream(shape, warm_up, payload_len, key_len)
         if shape[0] == SHUFFLE_MARK:
             return False
         _, nt, H, W, C = shape
-        hp, wp = padding_shape(H, W)
-        if model_shape is not None and (model_shape[0] != hp or model_shape[1] != wp):
-            print("ERROR:keyframe size and model size do not match.")
-            print("model size: height ", model_shape[0] - 7, "～", model_shape[0], " width ", model_shape[1] - 7, "～", model_shape[1])
-            print("key frame size: height ", H, " width ", W)
-            exit()
-        if len(file_names) != nt:
-            print("ERROR：The lengths of filename.txt and images do not match.")
-            print("filename.txt：", len(file_names))
-            print("number of images", nt)
-            exit()
-        ctx.prepare(hp, wp, 64 if nt > 64 else max(1, nt))
-        stages.mark("model prepare")
+        if early is not None and (nt, H, W, warm_up) != tuple(early):
+            raise ValueError("tezip_amd.json describes the stack as %r (frames, height, width, warm-up), entropy.dat's trailer as %r"
+                             % (tuple(early), (nt, H, W, warm_up)))
+        if early is None:
+            hp, wp = checks(nt, H, W)
+            per = stage_keys(nt, H, W, hp, wp)
+            rollout(warm_up)
         fb = H * W * C
-        per = max(1, (16 << 20) // fb)
-        ctx.frames_begin(nt, H, W)
-        first = 0
-        with open(paths["key_frame.dat"], "rb") as f:
-            for _, piece in zstd.stream_decompress(f, piece_bytes=per * fb):
-                k = piece.size // fb
-                ctx.frames_put(first, piece[: k * fb].reshape(k, H, W, C))
-                first += k
-        if first != nt:
-            raise ValueError("key_frame.dat: truncated stream")
-        stages.mark("zstd-d key_frame.dat + stage to HBM", ctx)
-        if VERBOSE:
-            ctx.prof_enable(True)
-        t0 = time.time()
-        ctx.rollout_decode(None, warm_up)
-        if VERBOSE:
-            print("predict:{0}".format(time.time() - t0) + "[sec]")
         stages.mark("rollout (decoder)", ctx)
         ctx.decode(None, table, out="resident")
         stages.mark("decode tail (frames resident)", ctx)
@@ -203,7 +299,9 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, GPU_FLAG, VERBOSE, device=0):
     cfg, wts, model_shape = open_model(WEIGHTS_DIR)
     contract = adopt_contract(DATA_DIR, wts, VERBOSE)
     if job is None and not os.environ.get("TEZIP_NO_STREAMING"):
-        done = _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shape, VERBOSE, device, contract)
+        # (the sidecar passed adopt_contract: it is readable or absent)
+        stack = None if os.environ.get("TEZIP_NO_EARLY_ROLLOUT") else sidecar.stack_of(sidecar.read(DATA_DIR))
+        done = _run_streaming(DATA_DIR, OUTPUT_DIR, file_names, isRGB, cfg, wts, model_shape, VERBOSE, device, contract, stack)
         if done:
             return
 

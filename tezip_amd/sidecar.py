@@ -9,7 +9,12 @@ filename.txt, key_frame.dat and entropy.dat (decompress.py:48-103), so a fourth 
 it; `-c` writes this one, `-u` adopts it:
 
   {"format": 1, "arithmetic_contract": "TZ-PA2", "contract": 2, "tz_version": 101,
-   "arch": "gfx950", "padded_frame": [512, 512], "weights_sha256": "..."}
+   "arch": "gfx950", "padded_frame": [512, 512], "weights_sha256": "...", "stack": [80, 512, 512, 0]}
+
+`stack` = [frames, height, width, warm_up] (round 6, optional): the reference stores these in the LAST seven
+values of entropy.dat (compress.py:390-394), so a decoder learns it only when the whole payload is decompressed; with
+it here the decoder runs its rollout WHILE entropy.dat is being decompressed (decompress._run_streaming) and checks the
+trailer against it afterwards.
 
   * sidecar present: the decoder runs under its contract; a --pa / TEZIP_PA that contradicts it is an
     error (the output would be off by one grey level on a fraction of 'lossless' samples, silently);
@@ -42,13 +47,15 @@ def requested_contract():
     return int(v) if v in ("1", "2") else None
 
 
-def write(out_dir, contract, wts, hp, wp):
+def write(out_dir, contract, wts, hp, wp, stack=None):
     from . import _lib
     if contract not in (1, 2):
         raise ValueError("contract must be 1 or 2, not %r" % (contract,))
     doc = {"format": FORMAT, "arithmetic_contract": "TZ-PA%d" % contract, "contract": int(contract),
            "tz_version": int(_lib.load().tz_version()), "arch": "gfx950", "padded_frame": [int(hp), int(wp)],
            "weights_sha256": weights_sha256(wts)}
+    if stack is not None:
+        doc["stack"] = [int(v) for v in stack]
     with open(os.path.join(out_dir, NAME), "w", encoding="UTF-8") as f:
         json.dump(doc, f, indent=1)
         f.write("\n")
@@ -70,6 +77,15 @@ def read(data_dir):
         raise SidecarMismatch("%s is damaged (%s); remove it only if you know which --pa the directory was compressed "
                               "with" % (path, e))
     return doc
+
+
+def stack_of(doc):
+    """(nt, H, W, warm_up) when the sidecar records a plausible stack, else None (older sidecars, the reference's directories)."""
+    st = doc.get("stack") if doc else None
+    if (isinstance(st, list) and len(st) == 4 and all(isinstance(v, int) for v in st) and all(1 <= v <= 32767 for v in st[:3])
+            and 0 <= st[3] < st[0]):
+        return tuple(st)
+    return None
 
 
 def resolve(doc, wts=None):

@@ -151,7 +151,7 @@ def run(WEIGHTS_DIR, DATA_DIR, OUTPUT_DIR, PREPROCESS, WINDOWS, MODE, BOUND_VALU
             for name in files:
                 f.write("%s\n" % name)
         from . import sidecar
-        sidecar.write(OUTPUT_DIR, contract, wts, hp, wp)
+        sidecar.write(OUTPUT_DIR, contract, wts, hp, wp, (nt, H, W, PREPROCESS))
         raw = nt * H * W * (3 if is_rgb else 1)
         with open(os.path.join(OUTPUT_DIR, "sweep.txt"), "w") as f:
             for r in rows:
