@@ -162,7 +162,12 @@ int tz_get_predictions(tz_ctx* ctx, float* out);
  * Bit 1 of `entropy` (value 2; NOT a reference feature, off in the reference's format): the
  * payload is returned byte-shuffled, i.e. as nt*H*W*3 low bytes followed by as many high bytes.
  * table: >= TZ_MAX_TABLE int16 (host), *table_len receives T (or -1 when entropy == 0).
- * delta_out (may be NULL): the int16 delta stack after quantisation, before the spatial delta. */
+ * delta_out (may be NULL): the int16 delta stack after quantisation, before the spatial delta.
+ * A job whose WORST-CASE tolerance is <= 0.499 (abs |b0|; rel / pwrel 255 b0; absrel the smaller of |b0| and 255 b1)
+ * is served by the lossless kernels: compress.py:23-70 then leaves every integer delta as it is (two different
+ * neighbours always close a run, and a run of equal deltas d gets trunc((fl(d+E) + fl(d-E)) / 2) = d; proof at
+ * tz_quant_is_identity in csrc/tz_codec.hip).  The result is the general quantiser's, byte for byte; TEZIP_QMAP=0 runs
+ * that instead. */
 int tz_encode(tz_ctx* ctx, int mode, double b0, double b1, int entropy, int16_t* payload,
               int16_t* table, int* table_len, int16_t* delta_out);
 /* Streaming delivery: tz_encode with payload == NULL keeps the payload in the context; it is then
