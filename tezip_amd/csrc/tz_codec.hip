@@ -1933,47 +1933,10 @@ __global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, 
     unsigned s = 0;
     const bool keep = wtiles <= SCAN_KEEP && rc.keep_regs;   // (uniform over the launch)
     unsigned kept[SCAN_KEEP][SCAN_EPT / 2];
-    // RECON: what the reconstruction adds the scanned deltas to -- 16 key bytes or 16 truncated predictions per lane and
-    // tile (decompress.py:252-256) -- does not depend on the scan: with the run kept in registers it is loaded HERE, in
-    // front of the wait for the other blocks' sums, one byte per element (a prediction is relu'd and clipped to [0, 1]:
-    // trunc(p * 255) is 0..255), so that phase 3 is arithmetic and stores only and all of a wave's loads are in flight at once.
-    unsigned basep[SCAN_KEEP][RECON ? 4 : 1];
-    unsigned long long fr = 0, rr = 0;   // RECON: frame and offset in it of the tile's first element
-    if (RECON) {
-        fr = chunk0 / rc.fe;
-        rr = chunk0 - fr * rc.fe;
-    }
-    auto base16 = [&](size_t base, unsigned* w) {   // advances (fr, rr) by one tile; w[4] = the lane's 16 base values as bytes
-        unsigned long long f = fr, r = rr + (unsigned long long)lane * SCAN_EPT;
-        while (r >= rc.fe) {
-            r -= rc.fe;
-            ++f;
-        }
-        rr += SCAN_WT;
-        while (rr >= rc.fe) {
-            rr -= rc.fe;
-            ++fr;
-        }
-        w[0] = w[1] = w[2] = w[3] = 0u;
-        if (base < n) {   // n is a multiple of 16 here: all 16 elements exist
-            if (rc.key_mask[f]) {
-                const uint4 k = *(const uint4*)(rc.key + base);
-                w[0] = k.x; w[1] = k.y; w[2] = k.z; w[3] = k.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 p = rc.pred[base / 4 + j];
-                    w[j] = ((unsigned)(int)(p.x * 255.0f) & 0xffu) | (((unsigned)(int)(p.y * 255.0f) & 0xffu) << 8) |
-                           (((unsigned)(int)(p.z * 255.0f) & 0xffu) << 16) | ((unsigned)(int)(p.w * 255.0f) << 24);
-                }
-            }
-        }
-    };
     if (keep) {
 #pragma unroll
         for (int t = 0; t < SCAN_KEEP; ++t) {
             const size_t base = chunk0 + (size_t)t * SCAN_WT + (size_t)lane * SCAN_EPT;
-            if (RECON && t < wtiles && chunk0 + (size_t)t * SCAN_WT < n) base16(base, basep[t]);
             int v[SCAN_EPT];
 #pragma unroll
             for (int k = 0; k < SCAN_EPT; ++k) v[k] = 0;
@@ -2024,18 +1987,42 @@ __global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, 
     run += front;
     // (3) scan the wave's run tile by tile
     const unsigned c0 = has_carry ? (unsigned)(int)carry : 0u;
-    auto tile = [&](int t, const unsigned* kv, const unsigned* bp) {   // kv / bp: the tile's values / base bytes as phase 1 left them, or nullptr: load them now
+    unsigned long long fr = 0, rr = 0;   // RECON: frame and offset in it of the tile's first element
+    if (RECON) {
+        fr = chunk0 / rc.fe;
+        rr = chunk0 - fr * rc.fe;
+    }
+    auto tile = [&](int t, const unsigned* kv) {   // kv: the tile's values as phase 1 left them, or nullptr: load them again
         const size_t base = chunk0 + (size_t)t * SCAN_WT + (size_t)lane * SCAN_EPT;
         int bv[SCAN_EPT];
         if (RECON) {
-            unsigned w[4];
-            if (bp) {
-                w[0] = bp[0]; w[1] = bp[1]; w[2] = bp[2]; w[3] = bp[3];
-            } else {
-                base16(base, w);
+            unsigned long long f = fr, r = rr + (unsigned long long)lane * SCAN_EPT;
+            while (r >= rc.fe) {
+                r -= rc.fe;
+                ++f;
             }
+            rr += SCAN_WT;
+            while (rr >= rc.fe) {
+                rr -= rc.fe;
+                ++fr;
+            }
+            if (base < n) {   // n is a multiple of 16 here: all 16 elements exist
+                if (rc.key_mask[f]) {
+                    const uint4 k = *(const uint4*)(rc.key + base);
+                    const unsigned kw[4] = {k.x, k.y, k.z, k.w};
 #pragma unroll
-            for (int j = 0; j < SCAN_EPT; ++j) bv[j] = (int)((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                    for (int j = 0; j < SCAN_EPT; ++j) bv[j] = (kw[j >> 2] >> (8 * (j & 3))) & 0xff;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 p = rc.pred[base / 4 + j];
+                        bv[4 * j] = (int)(p.x * 255.0f);
+                        bv[4 * j + 1] = (int)(p.y * 255.0f);
+                        bv[4 * j + 2] = (int)(p.z * 255.0f);
+                        bv[4 * j + 3] = (int)(p.w * 255.0f);
+                    }
+                }
+            }
         }
         int v[SCAN_EPT];
         if (kv) {
@@ -2088,11 +2075,11 @@ __global__ __launch_bounds__(256) void k_scan2p(const int16_t* __restrict__ in, 
     if (keep) {
 #pragma unroll
         for (int t = 0; t < SCAN_KEEP; ++t)
-            if (t < wtiles && chunk0 + (size_t)t * SCAN_WT < n) tile(t, kept[t], RECON ? basep[t] : nullptr);   // (uniform for the wave)
+            if (t < wtiles && chunk0 + (size_t)t * SCAN_WT < n) tile(t, kept[t]);   // (uniform for the wave)
     } else {
         for (int t = 0; t < wtiles; ++t) {
             if (chunk0 + (size_t)t * SCAN_WT >= n) break;   // uniform for the wave
-            tile(t, nullptr, nullptr);
+            tile(t, nullptr);
         }
     }
 }
