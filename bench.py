@@ -1106,8 +1106,9 @@ def host_pipeline_leg(cfg, frames_host):
         weights.save_model(mdir, cfg, cfg.init_weights(seed=123), H, W)
         os.mkdir(ddir)
         t0 = time.perf_counter()
-        for t in range(frames_host.shape[0]):
-            Image.fromarray(frames_host[t]).save(os.path.join(ddir, "f%04d.png" % t))
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=compress.io_threads()) as pool:   # (PIL's encoder releases the GIL)
+            list(pool.map(lambda t: Image.fromarray(frames_host[t]).save(os.path.join(ddir, "f%04d.png" % t)), range(frames_host.shape[0])))
         png_write_s = time.perf_counter() - t0
         png_bytes = sum(os.path.getsize(os.path.join(ddir, f)) for f in os.listdir(ddir))
         nt = frames_host.shape[0]
