@@ -398,6 +398,7 @@ static int launch_wino(tz_ctx* ctx, int NT, int epi, bool ups, const ConvArgs& a
 static constexpr long long TZ_PA2_MIN_PIXELS = 256 * 256;
 static constexpr size_t kPBytes = (size_t)160 << 20;      // P[l]: at most this much per level (tz_model_prepare)
 static constexpr double kEpartMinIdle = 0.06;   // "E-part ahead": below this idle share of a step's k_wino launches the split is not even tried
+static constexpr int kEpartSteps = 3;             // ... steps back to back per timed sample of its measurement
 static constexpr float kEpartMinGain = 0.98f;   // ... and it is kept only where it measures at least 2 % faster than the fused step
 static int effective_contract(const tz_ctx* ctx) {
     if (ctx->contract) return ctx->contract;
@@ -878,9 +879,9 @@ static int predict_batch_impl(tz_ctx* ctx, int n, const int* d_idx, int stride, 
 // side workgroups land on CUs the critical path is about to ask for depends on how every launch's last round falls, and on
 // the command processor's handling of stream priorities, which HIP does not promise).  So the first call for a batch size
 // n of a prepared model MEASURES: the same step -- a pure function of its inputs when the level-0 error maps are formed
-// here (skip_err0 off) -- runs fused and split, one untimed and two timed passes each, HIP events on the compute stream,
+// here (skip_err0 off) -- runs fused and split, one untimed and two timed samples of three back-to-back steps each, HIP events on the compute stream,
 // and the split is kept for that n where it is at least 2 % faster.  Both forms give the same bits (tests/test_gpu_epart.py),
-// so the outcome of the measurement never shows in the results; it costs six extra steps once per (prepare, n).
+// so the outcome of the measurement never shows in the results; it costs eighteen extra steps once per (prepare, n).
 // TEZIP_EPART=0 / 1 still forbid / force it.  Not tried at all where the idle share is under 6 % (every such case measured
 // slower) or no level can split.
 static int epart_measure(tz_ctx* ctx, int n, const int* d_idx, int stride, const uint8_t* d_frames_u8, int H, int W,
@@ -897,8 +898,12 @@ static int epart_measure(tz_ctx* ctx, int n, const int* d_idx, int stride, const
         for (int mode = 0; mode < 2 && rc == TZ_OK; ++mode) {
             bool dummy;
             hipError_t e = hipEventRecord(ctx->ev_cal[0], ctx->stream);
-            rc = predict_batch_impl(ctx, n, d_idx, stride, d_frames_u8, H, W, d_in_stack, d_out_stack, slot0, d_next_slot, false,
-                                    &dummy, false, mode == 1);
+            // kEpartSteps steps back to back between the two events, as a rollout queues them (the host runs ahead of the
+            // device): one step alone, with a synchronise on either side, mispredicted a cell by 6 % (384x384, two
+            // windows: split 2.9 % faster alone, 3.2 % slower in the rollout; profiles/r06/epart_measure_log.txt)
+            for (int k = 0; k < kEpartSteps && rc == TZ_OK; ++k)
+                rc = predict_batch_impl(ctx, n, d_idx, stride, d_frames_u8, H, W, d_in_stack, d_out_stack, slot0, d_next_slot, false,
+                                        &dummy, false, mode == 1);
             if (e == hipSuccess) e = hipEventRecord(ctx->ev_cal[1], ctx->stream);
             if (e == hipSuccess) e = hipEventSynchronize(ctx->ev_cal[1]);
             float ms = 0.f;
@@ -909,8 +914,8 @@ static int epart_measure(tz_ctx* ctx, int n, const int* d_idx, int stride, const
     ctx->prof_on = prof;
     *choice = best[1] < kEpartMinGain * best[0] ? 1 : 0;
     if (getenv("TEZIP_EPART_LOG"))
-        fprintf(stderr, "[tezip] E-part ahead, %dx%d batch %d: fused %.1f us, split %.1f us -> %s\n", ctx->model->Hp, ctx->model->Wp, n,
-                best[0] * 1e3f, best[1] * 1e3f, *choice ? "split" : "fused");
+        fprintf(stderr, "[tezip] E-part ahead, %dx%d batch %d: fused %.1f us, split %.1f us per step -> %s\n", ctx->model->Hp, ctx->model->Wp, n,
+                best[0] * 1e3f / kEpartSteps, best[1] * 1e3f / kEpartSteps, *choice ? "split" : "fused");
     return rc;
 }
 
