@@ -2,10 +2,14 @@
 //   (a) both kernels on ONE stream (no hand-off)
 //   (b) hipEventRecord on stream 1 + hipStreamWaitEvent on stream 2, and back            (what "E-part ahead" uses)
 //   (c) hipStreamWriteValue32 on stream 1 + hipStreamWaitValue32 on stream 2, and back   (stream memory operations, BETA)
+//   (d) the events of (b) attached to the kernels themselves (hipExtLaunchKernelGGL's stopEvent: no marker packet behind the kernel)
+//   (e) what an event RECORD between two kernels of ONE stream costs the second one (nobody waits for the event)
+//   (f) the same with the event as the first kernel's stopEvent
 // Each iteration = kernel A (s1) -> kernel B (s2, needs A) -> next A (s1, needs B).  Reported: microseconds per iteration
 // minus twice the kernel's own duration = the two hand-offs.
 // build: hipcc --offload-arch=gfx950 -O2 -o xstream_handoff scripts/microbench/xstream_handoff.hip
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -58,6 +62,33 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(s1));
         CK(hipStreamSynchronize(s2));
         if (rep) printf("(b) events                : %.2f us per iteration = 2 kernels + %.2f us for the two hand-offs\n", us(t0, now()) / N, us(t0, now()) / N - 2 * one);
+    }
+    for (int rep = 0; rep < 2; ++rep) {   // (d)
+        t0 = now();
+        for (int i = 0; i < N; ++i) {
+            hipExtLaunchKernelGGL(spin, dim3(256), dim3(256), 0, s1, nullptr, ea, 0, d, iters);
+            CK(hipStreamWaitEvent(s2, ea, 0));
+            hipExtLaunchKernelGGL(spin, dim3(256), dim3(256), 0, s2, nullptr, eb, 0, d + 512, iters);
+            CK(hipStreamWaitEvent(s1, eb, 0));
+        }
+        CK(hipStreamSynchronize(s1));
+        CK(hipStreamSynchronize(s2));
+        if (rep) printf("(d) stopEvent of the launch: %.2f us per iteration = 2 kernels + %.2f us for the two hand-offs\n", us(t0, now()) / N, us(t0, now()) / N - 2 * one);
+    }
+    for (int rep = 0; rep < 2; ++rep) {   // (e)
+        t0 = now();
+        for (int i = 0; i < 2 * N; ++i) {
+            hipLaunchKernelGGL(spin, dim3(256), dim3(256), 0, s1, d, iters);
+            CK(hipEventRecord(ea, s1));
+        }
+        CK(hipStreamSynchronize(s1));
+        if (rep) printf("(e) record behind each kernel, one stream : %.2f us per kernel (+%.2f)\n", us(t0, now()) / (2 * N), us(t0, now()) / (2 * N) - one);
+    }
+    for (int rep = 0; rep < 2; ++rep) {   // (f)
+        t0 = now();
+        for (int i = 0; i < 2 * N; ++i) hipExtLaunchKernelGGL(spin, dim3(256), dim3(256), 0, s1, nullptr, ea, 0, d, iters);
+        CK(hipStreamSynchronize(s1));
+        if (rep) printf("(f) stopEvent on each kernel, one stream  : %.2f us per kernel (+%.2f)\n", us(t0, now()) / (2 * N), us(t0, now()) / (2 * N) - one);
     }
     if (can) {
         unsigned *sig = nullptr, *sig2 = nullptr;   // (signal memory is handed out in 8-byte objects)
