@@ -93,9 +93,6 @@ struct tz_ctx {
     // finished on stream2
     hipEvent_t ev_epart_src[TZ_MAX_LEVELS] = {nullptr}, ev_epart_done[TZ_MAX_LEVELS] = {nullptr};
     hipEvent_t ev_cal[2] = {nullptr, nullptr};   // epart_measure: timing events on the compute stream (tz_prednet.hip)
-    // an event the NEXT k_wino launch carries as its completion event (hipExtLaunchKernelGGL's stopEvent: the kernel's own
-    // completion signal, no marker packet behind it in the queue); the launcher clears it when it has used it
-    hipEvent_t next_stop_event = nullptr;
     int epart_mode = -1;              // TEZIP_EPART: -1 where launches cannot fill the chip (default), 0 never, 1 wherever possible
     static constexpr int kStages = 4;
     static constexpr size_t kStageBytes = (size_t)8 << 20;

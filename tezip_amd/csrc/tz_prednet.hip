@@ -23,8 +23,6 @@
 #include <algorithm>
 #include <atomic>
 
-#include <hip/hip_ext.h>
-
 #include "tz_conv_kernels.hip.h"
 #include "tz_wino_kernels.hip.h"
 
@@ -363,13 +361,7 @@ static int launch_wino_t(tz_ctx* ctx, const ConvArgs& a0, int nbatch) {
     if (a0.ipw > 0 && a.ncb % a0.ipw == 0) a.ipw = a0.ipw;                         // (the caller knows better: side launches want short workgroups)
     if (ctx->wino_ipw > 0 && a.ncb % ctx->wino_ipw == 0) a.ipw = ctx->wino_ipw;   // (TEZIP_WINO_IPW: measurements)
     const int blocks = (a.ncb / a.ipw) * tiles;
-    if (ctx->next_stop_event) {   // (a hand-off to another stream hangs on this launch: see next_stop_event)
-        hipExtLaunchKernelGGL((k_wino<NT, EPI, UPS, NOSAME>), dim3(blocks), dim3(512), tzw::LDS_BYTES, ctx->stream, nullptr,
-                              ctx->next_stop_event, 0, a);
-        ctx->next_stop_event = nullptr;
-    } else {
-        hipLaunchKernelGGL((k_wino<NT, EPI, UPS, NOSAME>), dim3(blocks), dim3(512), tzw::LDS_BYTES, ctx->stream, a);
-    }
+    hipLaunchKernelGGL((k_wino<NT, EPI, UPS, NOSAME>), dim3(blocks), dim3(512), tzw::LDS_BYTES, ctx->stream, a);
     TZ_HIP(ctx, hipGetLastError());
     return TZ_OK;
 }
@@ -406,7 +398,6 @@ static int launch_wino(tz_ctx* ctx, int NT, int epi, bool ups, const ConvArgs& a
 static constexpr long long TZ_PA2_MIN_PIXELS = 256 * 256;
 static constexpr size_t kPBytes = (size_t)160 << 20;      // P[l]: at most this much per level (tz_model_prepare)
 static constexpr double kEpartMinIdle = 0.06;   // "E-part ahead": below this idle share of a step's k_wino launches the split is not even tried
-static const int kEpartStopEv = getenv("TEZIP_EPART_STOPEV") ? atoi(getenv("TEZIP_EPART_STOPEV")) : 1;   // (measurements) bit 0: the A launch carries the side launches' start event, bit 1: a side launch carries its own completion event
 static constexpr int kEpartSteps = 3;             // ... steps back to back per timed sample of its measurement
 static constexpr float kEpartMinGain = 0.98f;   // ... and it is kept only where it measures at least 2 % faster than the fused step
 static int effective_contract(const tz_ctx* ctx) {
@@ -964,7 +955,6 @@ static int predict_batch_impl(tz_ctx* ctx, int n, const int* d_idx, int stride, 
                               const float* d_in_stack, float* d_out_stack, int slot0, const int* d_next_slot, bool skip_err0,
                               bool* fused_next, bool err0_keys_only, bool use_epart) {
     tz_model* m = ctx->model;
-    ctx->next_stop_event = nullptr;   // (a call that failed half way must not leave its event to somebody else's launch)
     const int L = m->L, Hp = m->Hp, Wp = m->Wp;
     auto hl = [&](int l) { return Hp >> l; };
     auto wl = [&](int l) { return Wp >> l; };
@@ -1027,23 +1017,11 @@ static int predict_batch_impl(tz_ctx* ctx, int n, const int* d_idx, int stride, 
         double idle;
         epart_levels(ctx, m, n, epart, &idle);
     }
-    // Hand-offs between the two streams (round 6): the event the side launches wait for is the COMPLETION EVENT OF THE A
-    // LAUNCH ITSELF (launch_wino_t: hipExtLaunchKernelGGL's stopEvent = the dispatch packet's own signal), not a
-    // hipEventRecord behind it: a record is a marker packet of its own in the compute stream's queue, and the launch on the
-    // critical path behind it (A_2) started 12 us late.  With the event on A_1's dispatch the split wins at 20 of the 25
-    // measured (frame, windows) cells instead of 15, by up to 23 % instead of 18 % (376x1248 -0.9 -> +6.8 %, 384x384 x2
-    // -5.0 -> +4.7 %, 512x512 x3 +1.7 -> +7.6 %; profiles/r06/epart_shapes_measured.txt).  The OTHER direction stays a record
-    // behind the side launch: as that launch's stopEvent it made a 512x512 B = 1 step 20 us SLOWER (641 -> 662 us;
-    // TEZIP_EPART_STOPEV, profiles/r06/xstream_handoff.txt).  A launcher that did not take the event (the convolution did
-    // not run on k_wino) leaves it set, and it is recorded the old way.
-    auto epart_events = [&](int l) -> int {
+    auto epart_launch = [&](int l) -> int {   // the launch over E_l, on stream2, behind the A convolution that wrote E_l
         if (!ctx->ev_epart_src[l]) {
             TZ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_epart_src[l], hipEventDisableTiming));
             TZ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_epart_done[l], hipEventDisableTiming));
         }
-        return TZ_OK;
-    };
-    auto epart_launch = [&](int l, hipEvent_t src_done) -> int {   // the launch over E_l, on stream2, behind the A convolution that wrote E_l
         ConvArgs ge;
         gate_args(l, ge);
         ge.wino_stride = (ge.src[0].C + ge.src[1].C) >> 2;
@@ -1054,16 +1032,14 @@ static int predict_batch_impl(tz_ctx* ctx, int n, const int* d_idx, int stride, 
         ge.out0_nstride = npx(l) * ge.ncols;
         ge.out0 = m->P[l] + slot0 * ge.out0_nstride;
         ge.ipw = 1;   // short workgroups: a CU a side workgroup holds is one the critical path may be waiting for
-        TZ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, src_done, 0));
+        TZ_HIP(ctx, hipEventRecord(ctx->ev_epart_src[l], ctx->stream));
+        TZ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_epart_src[l], 0));
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->stream2;       // (the launchers and their profiling scopes take the context's stream)
-        if (kEpartStopEv & 2) ctx->next_stop_event = ctx->ev_epart_done[l];
         int rc = launch_conv(ctx, 4, EPI_RAW, ge, n);
         ctx->stream = main_stream;
-        const bool taken = ctx->next_stop_event == nullptr;
-        ctx->next_stop_event = nullptr;
         TZ_TRY(rc);
-        if (!taken) TZ_HIP(ctx, hipEventRecord(ctx->ev_epart_done[l], ctx->stream2));
+        TZ_HIP(ctx, hipEventRecord(ctx->ev_epart_done[l], ctx->stream2));
         return TZ_OK;
     };
     {
@@ -1106,24 +1082,13 @@ static int predict_batch_impl(tz_ctx* ctx, int n, const int* d_idx, int stride, 
                 continue;
             }
         }
+        TZ_TRY(launch_conv(ctx, pc.NT, EPI_POOL_ERR, a, n));
         // The side launches go out behind the A convolution that writes the E of the HIGHEST split level (the A convolutions
         // below it fill the chip by themselves), the highest level first: its second half is the first one the critical path
         // will ask for.
-        const bool hand_off = epart_top > 0 && l + 1 == epart_top;
-        if (hand_off) {
+        if (l + 1 == epart_top)
             for (int q = epart_top; q >= 1; --q)
-                if (epart[q]) TZ_TRY(epart_events(q));
-            if (kEpartStopEv & 1) ctx->next_stop_event = ctx->ev_epart_src[epart_top];
-        }
-        TZ_TRY(launch_conv(ctx, pc.NT, EPI_POOL_ERR, a, n));
-        if (hand_off) {
-            if (ctx->next_stop_event || !(kEpartStopEv & 1)) {   // (not a k_wino launch, or not asked for: the event goes behind it)
-                ctx->next_stop_event = nullptr;
-                TZ_HIP(ctx, hipEventRecord(ctx->ev_epart_src[epart_top], ctx->stream));
-            }
-            for (int q = epart_top; q >= 1; --q)
-                if (epart[q]) TZ_TRY(epart_launch(q, ctx->ev_epart_src[epart_top]));
-        }
+                if (epart[q]) TZ_TRY(epart_launch(q));
     }
     for (int l = L - 1; l >= 0; --l) {  // t1 top-down
         const PackedConv& pc = m->gate_t1[l];
