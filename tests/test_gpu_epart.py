@@ -134,3 +134,16 @@ def test_measured_decision_outside_512(monkeypatch, hp, wp, batch, expect):
     assert counts[None] in (5 * steps, 7 * steps)
     if expect is not None:
         assert counts[None] == expect * steps, counts
+
+
+def test_split_launches_over_random_shapes_soak():
+    """scripts/soak_epart.py as a test (40 random frame sizes 8..408 x 8..408, batches 1..5, forced split vs forbidden, bit
+    for bit): the split now runs wherever it measures faster, so a mistake in its hand-overs -- round 6 built one: a side
+    launch whose completion nobody waited for -- must show here and not in a user's images."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_epart.py"), "--cases", "40", "--seed", "7"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 mismatching" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
