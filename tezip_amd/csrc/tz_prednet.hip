@@ -697,7 +697,7 @@ extern "C" int tz_model_prepare(tz_ctx* ctx, int Hp, int Wp, int max_batch) {
         // (also the hand-over buffer of a gate convolution that runs as two k_wino launches: "E-part ahead" below).
         // As many batch slots as fit kPBytes, whatever max_batch is (until round 5: all of max_batch or nothing, so a
         // context prepared for many windows never split its trailing small batches): a batch of n items uses the buffer
-        // only where n <= Pcap[l], and "E-part ahead" only while the hand-over stays cache-resident (see there).
+        // only where n <= Pcap[l].
         if (l >= 1 && l < L - 1) {
             const size_t per_item = npx * 4 * R * 4;
             const int slots = (int)std::min<size_t>((size_t)max_batch, kPBytes / per_item);
